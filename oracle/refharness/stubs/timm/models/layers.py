@@ -1,0 +1,16 @@
+"""Stub of timm.models.layers: the two names the reference imports."""
+import torch
+import torch.nn as nn
+
+
+def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
+    return torch.nn.init.trunc_normal_(tensor, mean=mean, std=std, a=a, b=b)
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
+        super().__init__()
+        assert drop_prob == 0.0, "harness only supports drop_path 0 (pretraining default)"
+
+    def forward(self, x):
+        return x
