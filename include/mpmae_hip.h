@@ -1,0 +1,210 @@
+/*
+ * mpmae_hip.h — C ABI of libmpmae_hip.so: the MI355X (gfx950) operator library behind the
+ * MP-MAE pretraining hot path (FCMAE forward + loss + backward + AdamW).
+ *
+ * What it replaces. The reference (vishalned/MMEarth-train) is pure Python; its only native
+ * boundary on this path is the MinkowskiEngine pybind layer called from
+ *   /root/reference/models/convnextv2_sparse.py:37-45,113-129,143-150,199,218
+ *   /root/reference/models/sparse_norm_layers.py:24-33,61-77
+ * plus the stock torch ops of the dense decoder block (models/convnextv2.py:42-55), the heads
+ * (models/fcmae.py:249-265), the losses (models/fcmae.py:267-412, custom_loss.py:19-30) and the
+ * optimizer step (main_pretrain.py:312-320). Each entry point below names the reference
+ * operation(s) it stands in for.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
+ *   - `dt` selects the activation storage type: 0 = fp32 (exact-f32 MFMA, parity mode),
+ *     1 = bf16 (bf16 MFMA, fp32 accumulate). Parameters, gradients and statistics are fp32;
+ *   - no allocation, no synchronisation, no global state: the caller owns all memory and passes
+ *     workspace; work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 on success, otherwise the hipError_t of the failed launch.
+ *
+ * Row layout. A sparse stage holds only the visible patches: row = (n*keep + slot)*S*S + iy*S + ix
+ * with S points per patch side; slot <-> patch through vis[n*keep+slot] / inv[n*L+patch] (-1 =
+ * masked). Dense decoder rows are n*L + patch. Features are channels-last [rows, C].
+ */
+#ifndef MPMAE_HIP_H
+#define MPMAE_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mpmae_stream_t; /* hipStream_t */
+
+typedef struct MpmaeGeom {
+  const int* vis;  /* [N*keep] patch index of each visible slot, ascending per sample */
+  const int* inv;  /* [N*L] slot of each patch or -1; NULL = every patch visible (dense decoder) */
+  int N, keep, grid, S;
+} MpmaeGeom;
+
+/* prologue / epilogue selectors of mpmae_gemm / mpmae_wgrad */
+enum {
+  MPMAE_PRO_NONE = 0, MPMAE_PRO_LN_AFFINE = 1, MPMAE_PRO_GRN = 2, MPMAE_PRO_GRN_BWD = 3,
+  MPMAE_PRO_DOWN_GATHER = 4, MPMAE_PRO_ROW_GATHER = 5, MPMAE_PRO_IM2COL3 = 6
+};
+enum {
+  MPMAE_EPI_STORE = 0, MPMAE_EPI_GELU_SUMSQ = 1, MPMAE_EPI_RESID = 2, MPMAE_EPI_DZ_STATS = 3,
+  MPMAE_EPI_SCATTER_ROWS = 4, MPMAE_EPI_DOWN_DGRAD = 5
+};
+
+/* C[M,N] = epi( pro(A)[M,K] * B[N,K]^T + bias[N] ) */
+typedef struct MpmaeGemmArgs {
+  const void* A; const void* A2; const void* B; const float* bias;
+  void* C; const void* R;
+  int M, N, K, lda, ldb, ldc, ldr;
+  const float* p0; const float* p1;  /* prologue vectors (see enum comments in csrc/gemm.cuh) */
+  int rpg;                           /* rows per statistics group (>= M: one group) */
+  float* s0; float* s1;              /* [G][N] fp32 statistics accumulators (atomically added) */
+  const int* vis; const int* inv; const uint8_t* act; const uint8_t* act_src;
+  int keep, L, S, Cseg, grid;
+  int H;
+} MpmaeGemmArgs;
+
+/* dW[n*sn + k*sk] += sum_m proP(P)[m,n]*proQ(Q)[m,k] ; db[n] += sum_m proP(P)[m,n] */
+typedef struct MpmaeWgradArgs {
+  const void* P; const void* P2; const void* Q;
+  int M, Nn, Kk, ldp, ldq;
+  float* dW; int sn, sk; float* db;
+  const float* pp0; const float* pp1; const float* qp0; const float* qp1;
+  int rpg; int rows_per_split;
+  const int* vis; const int* inv; const uint8_t* act_src;
+  int keep, L, S, Cseg, grid, H;
+} MpmaeWgradArgs;
+
+typedef struct MpmaeDwArgs {
+  const void* x; void* out; const void* add;
+  const float* w; const float* bias;
+  int s_kh, s_kw, s_c; int flip;
+  MpmaeGeom g;
+  int C, CC, TP, tiles_side;
+  const uint8_t* act;
+} MpmaeDwArgs;
+
+typedef struct MpmaeDwWgArgs {
+  const void* x; const void* dd;
+  float* dw; float* db;
+  int s_kh, s_kw, s_c;
+  MpmaeGeom g;
+  int C, CC, TP, tiles_side, ntiles_total;
+  const uint8_t* act;
+} MpmaeDwWgArgs;
+
+typedef struct MpmaePrepDesc {
+  const float* src; void* dst;
+  int rows, cols, sr, sc, dst_ld, pad;
+} MpmaePrepDesc;
+
+typedef struct MpmaePixContArgs {
+  const void* pred; void* dpred; int ld, coff;
+  const float* target; const float* mask;
+  int C, p, grid, H, L; int norm_pix;
+  float* acc; float* patch_l; float* patch_cnt; float* patch_mean; float* patch_rstd;
+  const float* coef;
+} MpmaePixContArgs;
+
+typedef struct MpmaePixCatArgs {
+  const void* pred; void* dpred; int ld, coff;
+  const long long* target; const float* mask;
+  int K, p, grid, H, L;
+  float* acc; const float* coef;
+} MpmaePixCatArgs;
+
+typedef struct MpmaeImgArgs {
+  const void* pred; void* dpred; int ld, coff;
+  const void* target;
+  int K, N, kind;           /* kind 0: CE(argmax one-hot int64), 1: MSE over non-NaN fp32 targets */
+  float* acc; const float* coef;
+} MpmaeImgArgs;
+
+/* ---- masks / activity --------------------------------------------------------------------- */
+/* FCMAE.gen_random_mask (models/fcmae.py:214-231) on explicit noise [N,L]: mask f32 [N,L]
+ * (1 = removed), vis [N,keep], inv [N,L]. */
+int mpmae_mask_gen(const float* noise, int N, int L, int keep, float* mask, int* vis, int* inv,
+                   mpmae_stream_t stream);
+/* MinkowskiOps.to_sparse activity rule (convnextv2_sparse.py:199): act[row] = sum_c|x| != 0. */
+int mpmae_activity(const float* img, const int* vis, uint8_t* act, int N, int Cin, int H, int keep,
+                   int grid, int S, mpmae_stream_t stream);
+/* ME strided-conv output-coordinate rule: parent active iff any of its k x k children is. */
+int mpmae_activity_pool(const uint8_t* act_in, uint8_t* act_out, int Mout, int S, int k,
+                        mpmae_stream_t stream);
+
+/* ---- weight staging ------------------------------------------------------------------------ */
+/* casts / transposes fp32 master weights into the [N][K] compute-type layouts the GEMMs read;
+ * `table` is a device array of ndesc descriptors. */
+int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_elems,
+                       mpmae_stream_t stream);
+
+/* ---- MFMA GEMMs ---------------------------------------------------------------------------- */
+/* MinkowskiLinear / nn.Linear / 1x1 nn.Conv2d / MinkowskiConvolution (3x3 s1 via im2col, 2x2 s2
+ * via child gather) forward and data-gradient, with LayerNorm-affine, GELU, GRN, residual and
+ * statistics fused (convnextv2_sparse.py:41-43,55,113-116,143-150; convnextv2.py:46-52;
+ * fcmae.py:251,264). `args` is a HOST pointer (copied into the kernel argument buffer). */
+int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t stream);
+/* weight + bias gradients of the same layers (autograd of the reference ops). */
+int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits,
+                mpmae_stream_t stream);
+
+/* ---- row-wise ops -------------------------------------------------------------------------- */
+/* MinkowskiLayerNorm / LayerNorm (sparse_norm_layers.py:61-77; norm_layers.py:23-31):
+ * xhat = (x-mean)*rstd (biased var), optional y = act(xhat*gamma+beta), act 0 = id, 1 = GELU. */
+int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma,
+                 const float* beta, int act, float eps, int M, int C, const uint8_t* rowmask,
+                 mpmae_stream_t stream);
+int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat,
+                 const float* rstd, const float* gamma, const float* beta, int act, void* dx,
+                 int accumulate, float* dgamma, float* dbeta, int M, int C, const uint8_t* rowmask,
+                 mpmae_stream_t stream);
+/* MinkowskiGRN (batch-global, eps 1e-6; sparse_norm_layers.py:24-33) and GRN (per-sample,
+ * eps 1e-4; norm_layers.py:41-44): statistics finalisation for G groups of H channels. */
+int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx,
+                           float* Ainv, float* scale, mpmae_stream_t stream);
+int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv,
+                           const float* gamma, int G, int H, float* coef, float* dgamma,
+                           float* dbeta, mpmae_stream_t stream);
+/* MinkowskiDepthwiseConvolution 7x7 (convnextv2_sparse.py:37-39) / dense depthwise 7x7 pad 3
+ * (convnextv2.py:27-29): forward, data gradient (flip = 1, add = upstream residual gradient),
+ * weight + bias gradient. `args` are HOST pointers. */
+int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* args, mpmae_stream_t stream);
+int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* args, int nblocks, mpmae_stream_t stream);
+/* depthwise stem, kernel = stride = patch/8 (convnextv2_sparse.py:121-127). */
+int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const float* b, int Mout,
+                       int C, int S, int k, const uint8_t* act_in, const uint8_t* act_out,
+                       mpmae_stream_t stream);
+int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w,
+                       float* dw, float* db, int Mout, int C, int S, int k, const uint8_t* act_in,
+                       mpmae_stream_t stream);
+/* mask-token blend of forward_decoder (fcmae.py:253-255) and its parameter gradient. */
+int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D,
+                          mpmae_stream_t stream);
+int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D,
+                         mpmae_stream_t stream);
+/* global average pool over the L positions of each sample (fcmae.py:262). */
+int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mpmae_stream_t stream);
+
+/* ---- losses (fcmae.py:267-412; custom_loss.py:19-30) --------------------------------------- */
+int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* args, int npatches,
+                        mpmae_stream_t stream);
+int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* args, int npatches,
+                       mpmae_stream_t stream);
+int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* args, mpmae_stream_t stream);
+int mpmae_loss_finalize(const float* acc, const float* log_vars, int T, float loss_scale,
+                        float* losses, float* weighted, float* total, float* coef,
+                        float* dlog_vars, mpmae_stream_t stream);
+
+/* ---- optimizer (main_pretrain.py:312-320; helpers.py:509-526) ------------------------------ */
+/* hp (device) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} */
+int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
+                float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask,
+                mpmae_stream_t stream);
+int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
+
+/* library identification: returns the gfx arch the kernels were built for (950). */
+int mpmae_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPMAE_HIP_H */

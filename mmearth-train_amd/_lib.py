@@ -1,0 +1,160 @@
+"""ctypes binding of libmpmae_hip.so (C ABI declared in include/mpmae_hip.h).
+
+The product path has NO CPU / PyTorch fallback: if the HIP library is missing or an entry
+point fails, this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpmae_hip.so")
+
+c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+
+
+class Geom(C.Structure):
+    _fields_ = [("vis", c_void_p), ("inv", c_void_p),
+                ("N", c_int), ("keep", c_int), ("grid", c_int), ("S", c_int)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("A2", c_void_p), ("B", c_void_p), ("bias", c_void_p),
+                ("C", c_void_p), ("R", c_void_p),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int),
+                ("ldc", c_int), ("ldr", c_int),
+                ("p0", c_void_p), ("p1", c_void_p),
+                ("rpg", c_int),
+                ("s0", c_void_p), ("s1", c_void_p),
+                ("vis", c_void_p), ("inv", c_void_p), ("act", c_void_p), ("act_src", c_void_p),
+                ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
+                ("H", c_int)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("P", c_void_p), ("P2", c_void_p), ("Q", c_void_p),
+                ("M", c_int), ("Nn", c_int), ("Kk", c_int), ("ldp", c_int), ("ldq", c_int),
+                ("dW", c_void_p), ("sn", c_int), ("sk", c_int), ("db", c_void_p),
+                ("pp0", c_void_p), ("pp1", c_void_p), ("qp0", c_void_p), ("qp1", c_void_p),
+                ("rpg", c_int), ("rows_per_split", c_int),
+                ("vis", c_void_p), ("inv", c_void_p), ("act_src", c_void_p),
+                ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
+                ("H", c_int)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("out", c_void_p), ("add", c_void_p),
+                ("w", c_void_p), ("bias", c_void_p),
+                ("s_kh", c_int), ("s_kw", c_int), ("s_c", c_int), ("flip", c_int),
+                ("g", Geom),
+                ("C", c_int), ("CC", c_int), ("TP", c_int), ("tiles_side", c_int),
+                ("act", c_void_p)]
+
+
+class DwWgArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("dd", c_void_p), ("dw", c_void_p), ("db", c_void_p),
+                ("s_kh", c_int), ("s_kw", c_int), ("s_c", c_int),
+                ("g", Geom),
+                ("C", c_int), ("CC", c_int), ("TP", c_int), ("tiles_side", c_int),
+                ("ntiles_total", c_int),
+                ("act", c_void_p)]
+
+
+class PrepDesc(C.Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p),
+                ("rows", c_int), ("cols", c_int), ("sr", c_int), ("sc", c_int),
+                ("dst_ld", c_int), ("pad", c_int)]
+
+
+class PixContArgs(C.Structure):
+    _fields_ = [("pred", c_void_p), ("dpred", c_void_p), ("ld", c_int), ("coff", c_int),
+                ("target", c_void_p), ("mask", c_void_p),
+                ("C", c_int), ("p", c_int), ("grid", c_int), ("H", c_int), ("L", c_int),
+                ("norm_pix", c_int),
+                ("acc", c_void_p), ("patch_l", c_void_p), ("patch_cnt", c_void_p),
+                ("patch_mean", c_void_p), ("patch_rstd", c_void_p),
+                ("coef", c_void_p)]
+
+
+class PixCatArgs(C.Structure):
+    _fields_ = [("pred", c_void_p), ("dpred", c_void_p), ("ld", c_int), ("coff", c_int),
+                ("target", c_void_p), ("mask", c_void_p),
+                ("K", c_int), ("p", c_int), ("grid", c_int), ("H", c_int), ("L", c_int),
+                ("acc", c_void_p), ("coef", c_void_p)]
+
+
+class ImgArgs(C.Structure):
+    _fields_ = [("pred", c_void_p), ("dpred", c_void_p), ("ld", c_int), ("coff", c_int),
+                ("target", c_void_p),
+                ("K", c_int), ("N", c_int), ("kind", c_int),
+                ("acc", c_void_p), ("coef", c_void_p)]
+
+
+PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
+EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
+
+# every symbol include/mpmae_hip.h declares: name -> argtypes
+P = C.POINTER
+SYMBOLS = {
+    "mpmae_arch": [],
+    "mpmae_mask_gen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_activity": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mpmae_activity_pool": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mpmae_prep_weights": [c_int, c_void_p, c_int, c_int, c_void_p],
+    "mpmae_gemm": [c_int, c_int, c_int, P(GemmArgs), c_void_p],
+    "mpmae_wgrad": [c_int, c_int, c_int, P(WgradArgs), c_int, c_void_p],
+    "mpmae_ln_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
+                     c_int, c_int, c_void_p, c_void_p],
+    "mpmae_ln_bwd": [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "mpmae_grn_fwd_finalize": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_grn_bwd_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                               c_void_p, c_void_p, c_void_p],
+    "mpmae_dwconv7_fwd": [c_int, P(DwArgs), c_void_p],
+    "mpmae_dwconv7_wgrad": [c_int, P(DwWgArgs), c_int, c_void_p],
+    "mpmae_dwstride_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                           c_void_p, c_void_p, c_void_p],
+    "mpmae_dwstride_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                           c_int, c_int, c_void_p, c_void_p],
+    "mpmae_fill_mask_token": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mpmae_mask_token_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mpmae_pool_rows": [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mpmae_loss_pix_cont": [c_int, c_int, P(PixContArgs), c_int, c_void_p],
+    "mpmae_loss_pix_cat": [c_int, c_int, P(PixCatArgs), c_int, c_void_p],
+    "mpmae_loss_img": [c_int, c_int, P(ImgArgs), c_void_p],
+    "mpmae_loss_finalize": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
+    "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                    c_size_t, c_void_p, c_void_p],
+    "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libmpmae_hip.so; raises HipLibraryError if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SYMBOLS.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    if lib.mpmae_arch() != 950:
+        raise HipLibraryError("libmpmae_hip.so was not built for gfx950")
+    _lib = lib
+    return lib
+
+
+def check(err: int, what: str):
+    if err != 0:
+        raise HipLibraryError(f"{what} failed with hipError {err}")

@@ -1,0 +1,276 @@
+// extern "C" surface of libmpmae_hip.so (see include/mpmae_hip.h). gfx950 only.
+#include "common.cuh"
+#include "gemm.cuh"
+#include "rows.cuh"
+#include "dwconv.cuh"
+#include "misc.cuh"
+#include "loss.cuh"
+
+#define S_(s) reinterpret_cast<hipStream_t>(s)
+#define RET() return (int)hipGetLastError()
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int grid1d(long long total, int per_block = 256, int cap = 16384) {
+  long long g = (total + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// C linkage comes from the declarations in include/mpmae_hip.h
+
+int mpmae_arch(void) { return 950; }
+
+int mpmae_mask_gen(const float* noise, int N, int L, int keep, float* mask, int* vis, int* inv, mpmae_stream_t s) {
+  hipLaunchKernelGGL(mask_gen_kernel, dim3(N), dim3(256), 2 * L * sizeof(float), S_(s), noise, L, keep, mask, vis, inv);
+  RET();
+}
+
+int mpmae_activity(const float* img, const int* vis, uint8_t* act, int N, int Cin, int H, int keep, int grid, int S,
+                   mpmae_stream_t s) {
+  const int total = N * keep * S * S;
+  hipLaunchKernelGGL(activity_kernel, dim3(grid1d(total)), dim3(256), 0, S_(s), img, vis, act, N, Cin, H, keep, grid, S);
+  RET();
+}
+
+int mpmae_activity_pool(const uint8_t* in, uint8_t* out, int Mout, int S, int k, mpmae_stream_t s) {
+  hipLaunchKernelGGL(activity_pool_kernel, dim3(grid1d(Mout)), dim3(256), 0, S_(s), in, out, Mout, S, k);
+  RET();
+}
+
+int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_elems, mpmae_stream_t s) {
+  dim3 g(grid1d(max_elems, 256, 64), ndesc);
+  if (dt == 0) hipLaunchKernelGGL(prep_kernel<float>, g, dim3(256), 0, S_(s), table);
+  else hipLaunchKernelGGL(prep_kernel<bf16_t>, g, dim3(256), 0, S_(s), table);
+  RET();
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
+  dim3 g(cdiv(a.M, GBM), cdiv(a.N, GBN)), b(256);
+#define GEMM_CASE(P, E)                                                            \
+  if (pro == P && epi == E) {                                                      \
+    hipLaunchKernelGGL((gemm_kernel<T, P, E>), g, b, 0, st, a);                    \
+    return (int)hipGetLastError();                                                 \
+  }
+  GEMM_CASE(PRO_NONE, EPI_STORE)
+  GEMM_CASE(PRO_NONE, EPI_SCATTER_ROWS)
+  GEMM_CASE(PRO_NONE, EPI_DZ_STATS)
+  GEMM_CASE(PRO_NONE, EPI_DOWN_DGRAD)
+  GEMM_CASE(PRO_LN_AFFINE, EPI_GELU_SUMSQ)
+  GEMM_CASE(PRO_LN_AFFINE, EPI_STORE)
+  GEMM_CASE(PRO_GRN, EPI_RESID)
+  GEMM_CASE(PRO_GRN_BWD, EPI_STORE)
+  GEMM_CASE(PRO_DOWN_GATHER, EPI_STORE)
+  GEMM_CASE(PRO_ROW_GATHER, EPI_STORE)
+  GEMM_CASE(PRO_IM2COL3, EPI_STORE)
+#undef GEMM_CASE
+  return (int)hipErrorInvalidValue;
+}
+
+int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t s) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
+  if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
+    return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
+  return dt == 0 ? launch_gemm<float>(pro, epi, *args, S_(s)) : launch_gemm<bf16_t>(pro, epi, *args, S_(s));
+}
+
+template <typename T>
+static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStream_t st) {
+  dim3 g(cdiv(a.Nn, WBN), cdiv(a.Kk, WBK), splits), b(256);
+#define WG_CASE(P, Q)                                                              \
+  if (ppro == P && qpro == Q) {                                                    \
+    hipLaunchKernelGGL((wgrad_kernel<T, P, Q>), g, b, 0, st, a);                   \
+    return (int)hipGetLastError();                                                 \
+  }
+  WG_CASE(PRO_NONE, PRO_NONE)
+  WG_CASE(PRO_NONE, PRO_GRN)
+  WG_CASE(PRO_NONE, PRO_LN_AFFINE)
+  WG_CASE(PRO_GRN_BWD, PRO_LN_AFFINE)
+  WG_CASE(PRO_NONE, PRO_DOWN_GATHER)
+  WG_CASE(PRO_ROW_GATHER, PRO_NONE)
+  WG_CASE(PRO_NONE, PRO_IM2COL3)
+#undef WG_CASE
+  return (int)hipErrorInvalidValue;
+}
+
+int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits, mpmae_stream_t s) {
+  if (!args || splits < 1) return (int)hipErrorInvalidValue;
+  WgradP a = *args;
+  int rps = cdiv(a.M, splits);
+  rps = cdiv(rps, WBM) * WBM;
+  a.rows_per_split = rps;
+  splits = cdiv(a.M, rps);
+  return dt == 0 ? launch_wgrad<float>(ppro, qpro, a, splits, S_(s)) : launch_wgrad<bf16_t>(ppro, qpro, a, splits, S_(s));
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename T>
+static void launch_ln_fwd(const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta,
+                          int act, float eps, int M, int C, const uint8_t* rowmask, hipStream_t st) {
+  const int blocks = grid1d((long long)M * 64, 256, 8192);
+  hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
+                     act, eps, M, C, rowmask);
+}
+
+int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
+                 float eps, int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
+  if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if (dt == 0) launch_ln_fwd<float>(x, xhat, rstd, y, gamma, beta, act, eps, M, C, rowmask, S_(s));
+  else launch_ln_fwd<bf16_t>(x, xhat, rstd, y, gamma, beta, act, eps, M, C, rowmask, S_(s));
+  RET();
+}
+
+int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
+                 const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
+                 int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
+  if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  const int blocks = grid1d((long long)M * 64, 256, 1024);
+  if (dt == 0)
+    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
+                       (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, dgamma, dbeta, M, C, rowmask);
+  else
+    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dy, dy_div, dy_scale,
+                       (const bf16_t*)xhat, rstd, gamma, beta, act, (bf16_t*)dx, accumulate, dgamma, dbeta, M, C, rowmask);
+  RET();
+}
+
+int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx, float* Ainv,
+                           float* scale, mpmae_stream_t s) {
+  hipLaunchKernelGGL(grn_fwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), G2, gamma, eps, H, Gx, Ainv, scale);
+  RET();
+}
+
+int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv, const float* gamma,
+                           int G, int H, float* coef, float* dgamma, float* dbeta, mpmae_stream_t s) {
+  hipLaunchKernelGGL(grn_bwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), S0, S1, Gx, Ainv, gamma, H, coef, dgamma, dbeta);
+  RET();
+}
+
+// ------------------------------------------------------------------------------------------
+static size_t dw_lds_bytes(int CC, bool wgrad) {
+  size_t b = (size_t)DW_HP * CC * sizeof(float) + (DW_HP + 4) * sizeof(int);
+  if (wgrad) b += (size_t)50 * CC * sizeof(float);
+  return b;
+}
+
+int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
+  if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  const size_t lds = dw_lds_bytes(a->CC, false);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
+  if (dt == 0) {
+    (void)hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), *a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+  }
+  RET();
+}
+
+int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
+  if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  const size_t lds = dw_lds_bytes(a->CC, true);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
+  dim3 g(nblocks, cdiv(a->C, a->CC));
+  if (dt == 0) {
+    (void)hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), *a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+  }
+  RET();
+}
+
+int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const float* b, int Mout, int C, int S, int k,
+                       const uint8_t* act_in, const uint8_t* act_out, mpmae_stream_t s) {
+  if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)Mout * C);
+  if (dt == 0) hipLaunchKernelGGL(dwstride_fwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)in, (float*)out, w, b, Mout, C, S, k, act_in, act_out);
+  else hipLaunchKernelGGL(dwstride_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)in, (bf16_t*)out, w, b, Mout, C, S, k, act_in, act_out);
+  RET();
+}
+
+int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w, float* dw, float* db,
+                       int Mout, int C, int S, int k, const uint8_t* act_in, mpmae_stream_t s) {
+  if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
+  const int g = 1024;
+  if (dt == 0) hipLaunchKernelGGL(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, dw, db, Mout, C, S, k, act_in);
+  else hipLaunchKernelGGL(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, dw, db, Mout, C, S, k, act_in);
+  RET();
+}
+
+int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D, mpmae_stream_t s) {
+  const int g = grid1d((long long)rows * D);
+  if (dt == 0) hipLaunchKernelGGL(fill_mask_token_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)xdec, token, inv, rows, D);
+  else hipLaunchKernelGGL(fill_mask_token_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)xdec, token, inv, rows, D);
+  RET();
+}
+
+int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, mpmae_stream_t s) {
+  dim3 g(cdiv(D, 256), 64);
+  if (dt == 0) hipLaunchKernelGGL(mask_token_bwd_kernel<float>, g, dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
+  else hipLaunchKernelGGL(mask_token_bwd_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
+  RET();
+}
+
+int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mpmae_stream_t s) {
+  const int g = grid1d((long long)N * C);
+  if (dt == 0) hipLaunchKernelGGL(pool_rows_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)x, (float*)pooled, N, L, C);
+  else hipLaunchKernelGGL(pool_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)x, (bf16_t*)pooled, N, L, C);
+  RET();
+}
+
+// ------------------------------------------------------------------------------------------
+int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
+  dim3 g(npatches), b(256);
+  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else hipLaunchKernelGGL((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else hipLaunchKernelGGL((loss_pix_cont_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  RET();
+}
+
+int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* a, int npatches, mpmae_stream_t s) {
+  if (a->K > 16) return (int)hipErrorInvalidValue;
+  dim3 g(npatches), b(256);
+  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else hipLaunchKernelGGL((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else hipLaunchKernelGGL((loss_pix_cat_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  RET();
+}
+
+int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* a, mpmae_stream_t s) {
+  dim3 g(a->N), b(256);
+  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_img_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else hipLaunchKernelGGL((loss_img_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) hipLaunchKernelGGL((loss_img_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else hipLaunchKernelGGL((loss_img_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  RET();
+}
+
+int mpmae_loss_finalize(const float* acc, const float* log_vars, int T, float loss_scale, float* losses, float* weighted,
+                        float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
+  if (T > 64) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, log_vars, T, loss_scale, losses, weighted,
+                     total, coef, dlog_vars);
+  RET();
+}
+
+int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
+                float wd, size_t n, const uint8_t* decay, mpmae_stream_t s) {
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d((long long)n, 256, 4096)), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2,
+                     eps, wd, n, decay);
+  RET();
+}
+
+int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t s) {
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d((long long)n, 256, 1024)), dim3(256), 0, S_(s), x, n, out);
+  RET();
+}
+

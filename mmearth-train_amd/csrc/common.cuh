@@ -1,0 +1,94 @@
+// Common device helpers for the MP-MAE HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mpmae_hip.h"
+
+#define MPMAE_CHECK_LAUNCH() ((int)hipGetLastError())
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; all arithmetic is done in fp32 registers
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---------------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-nearest-even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// 8-wide contiguous load / store (p must be 8-element aligned for the vector path)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float (&o)[8]);
+template <> __device__ __forceinline__ void ld8<float>(const float* p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+template <> __device__ __forceinline__ void ld8<bf16_t>(const bf16_t* p, float (&o)[8]) {
+  const uint4 a = *reinterpret_cast<const uint4*>(p);
+  o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+  o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+  o[4] = __uint_as_float(a.z << 16); o[5] = __uint_as_float(a.z & 0xffff0000u);
+  o[6] = __uint_as_float(a.w << 16); o[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float (&v)[8]);
+template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v)[8]) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+  uint4 a;
+  a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
+  a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
+  a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = a;
+}
+
+// ---------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_f(float x) {            // exact (erf) GELU
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------
+// sparse row geometry: rows of a stage are (n, slot k, intra-patch point q = iy*S + ix)
+//   row = (n*keep + k)*S*S + q ; slot k <-> patch index vis[n*keep + k] on the grid x grid grid
+//   inv[n*L + patch] = slot or -1.  inv == nullptr means "all patches visible, slot = patch".
+// ---------------------------------------------------------------------------------
+typedef MpmaeGeom Geom;
+
+__device__ __forceinline__ int geom_row_of(const Geom& g, int n, int gy, int gx) {
+  // (gy, gx) in stage-point coordinates on the dense (grid*S)^2 map; returns row or -1
+  const int ext = g.grid * g.S;
+  if (gy < 0 || gx < 0 || gy >= ext || gx >= ext) return -1;
+  const int py = gy / g.S, px = gx / g.S;
+  const int patch = py * g.grid + px;
+  const int slot = g.inv ? g.inv[n * g.grid * g.grid + patch] : patch;
+  if (slot < 0) return -1;
+  return (n * g.keep + slot) * g.S * g.S + (gy - py * g.S) * g.S + (gx - px * g.S);
+}

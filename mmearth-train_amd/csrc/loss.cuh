@@ -1,0 +1,227 @@
+// Per-modality reconstruction losses + uncertainty weighting, forward and backward, with no
+// host synchronisation (reference: models/fcmae.py:267-412, custom_loss.py:19-30).
+// Predictions are channels-last rows: pixel heads [N*L, ld] (modality slice at column `coff`,
+// column j = (ph*p+pw)*C + c), image heads [N, ld].
+#pragma once
+#include "common.cuh"
+
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ float nan_to_num0(float t) { return (isnan(t) || isinf(t)) ? 0.f : t; }
+
+typedef MpmaePixContArgs PixContP;
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, n = b / q.L, l = b - n * q.L;
+  const int py = l / q.grid, px = l - py * q.grid;
+  const int p = q.p, C = q.C, J = p * p * C;
+  const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+  const bool masked = q.mask[b] != 0.f;
+  if constexpr (BWD) {
+    T* dp = reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff;
+    const float pl = q.patch_l[b];
+    const bool counted = masked && pl != 0.f && !isnan(pl);
+    if (!counted) {
+      for (int j = threadIdx.x; j < J; j += blockDim.x) stf<T>(dp + j, 0.f);
+      return;
+    }
+    const float k = q.coef[0] * q.mask[b] * 2.f / q.patch_cnt[b];
+    const float mean = q.patch_mean[b], rstd = q.patch_rstd[b];
+    for (int i = threadIdx.x; i < J; i += blockDim.x) {
+      const int c = i / (p * p), r = i - c * p * p, ph = r / p, pw = r - ph * p;
+      float t = nan_to_num0(q.target[((size_t)(n * C + c) * q.H + py * p + ph) * q.H + px * p + pw]);
+      t = (t - mean) * rstd;
+      const int j = (ph * p + pw) * C + c;
+      const float d = ldf<T>(pred + j) - t;
+      stf<T>(dp + j, isnan(d * d) ? 0.f : k * d);
+    }
+    return;
+  } else {
+    if (!masked) {
+      if (threadIdx.x == 0) { q.patch_l[b] = 0.f; q.patch_cnt[b] = 0.f; q.patch_mean[b] = 0.f; q.patch_rstd[b] = 1.f; }
+      return;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (q.norm_pix) {
+      float s = 0.f;
+      for (int i = threadIdx.x; i < J; i += blockDim.x) {
+        const int c = i / (p * p), r = i - c * p * p, ph = r / p, pw = r - ph * p;
+        s += nan_to_num0(q.target[((size_t)(n * C + c) * q.H + py * p + ph) * q.H + px * p + pw]);
+      }
+      mean = block_sum256(s, sh) / J;
+      float v = 0.f;
+      for (int i = threadIdx.x; i < J; i += blockDim.x) {
+        const int c = i / (p * p), r = i - c * p * p, ph = r / p, pw = r - ph * p;
+        const float d = nan_to_num0(q.target[((size_t)(n * C + c) * q.H + py * p + ph) * q.H + px * p + pw]) - mean;
+        v += d * d;
+      }
+      const float var = block_sum256(v, sh) / (J - 1);          // unbiased (torch .var default)
+      rstd = 1.f / sqrtf(var + 1.0e-6f);
+    }
+    float se = 0.f, cnt = 0.f;
+    for (int i = threadIdx.x; i < J; i += blockDim.x) {
+      const int c = i / (p * p), r = i - c * p * p, ph = r / p, pw = r - ph * p;
+      float t = nan_to_num0(q.target[((size_t)(n * C + c) * q.H + py * p + ph) * q.H + px * p + pw]);
+      t = (t - mean) * rstd;
+      const float d = ldf<T>(pred + (ph * p + pw) * C + c) - t;
+      const float e = d * d;
+      if (!isnan(e)) { se += e; cnt += 1.f; }
+    }
+    se = block_sum256(se, sh);
+    cnt = block_sum256(cnt, sh);
+    if (threadIdx.x == 0) {
+      const float lp = se / cnt;                                  // 0/0 -> NaN -> dropped below
+      const float qv = lp * q.mask[b];
+      const bool counted = !isnan(qv) && qv != 0.f;
+      q.patch_l[b] = counted ? lp : 0.f;
+      q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
+      if (counted) { atomicAdd(q.acc, qv); atomicAdd(q.acc + 1, 1.f); }
+    }
+  }
+}
+
+typedef MpmaePixCatArgs PixCatP;
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
+  __shared__ float sh[4];
+  const int b = blockIdx.x, n = b / q.L, l = b - n * q.L;
+  const int py = l / q.grid, px = l - py * q.grid;
+  const int p = q.p, K = q.K, PP = p * p;
+  const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+  const bool masked = q.mask[b] == 1.f;
+  T* dp = BWD ? reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff : nullptr;
+  if (!masked) {
+    if constexpr (BWD) for (int j = threadIdx.x; j < PP * K; j += blockDim.x) stf<T>(dp + j, 0.f);
+    return;
+  }
+  float se = 0.f, cnt = 0.f;
+  const float k = BWD ? q.coef[0] : 0.f;
+  for (int pix = threadIdx.x; pix < PP; pix += blockDim.x) {
+    const int ph = pix / p, pw = pix - ph * p;
+    const long long t = q.target[((size_t)n * q.H + py * p + ph) * q.H + px * p + pw];
+    float z[16];
+    float mx = -INFINITY;
+    for (int c = 0; c < K; ++c) { z[c] = ldf<T>(pred + pix * K + c); mx = fmaxf(mx, z[c]); }
+    float s = 0.f;
+    for (int c = 0; c < K; ++c) s += __expf(z[c] - mx);
+    const float lse = mx + __logf(s);
+    if (t != -1) {
+      if constexpr (BWD) {
+        for (int c = 0; c < K; ++c) stf<T>(dp + pix * K + c, k * (__expf(z[c] - lse) - (c == (int)t ? 1.f : 0.f)));
+      } else {
+        se += lse - z[(int)t];
+        cnt += 1.f;
+      }
+    } else if constexpr (BWD) {
+      for (int c = 0; c < K; ++c) stf<T>(dp + pix * K + c, 0.f);
+    }
+  }
+  if constexpr (!BWD) {
+    se = block_sum256(se, sh);
+    cnt = block_sum256(cnt, sh);
+    if (threadIdx.x == 0 && cnt > 0.f) { atomicAdd(q.acc, se); atomicAdd(q.acc + 1, cnt); }
+  }
+}
+
+typedef MpmaeImgArgs ImgP;
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
+  __shared__ float sh[4];
+  __shared__ int shi[4];
+  const int n = blockIdx.x, K = q.K;
+  const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)n * q.ld + q.coff;
+  T* dp = BWD ? reinterpret_cast<T*>(q.dpred) + (size_t)n * q.ld + q.coff : nullptr;
+  if (q.kind == 1) {
+    const float* tg = reinterpret_cast<const float*>(q.target) + (size_t)n * K;
+    float se = 0.f, cnt = 0.f;
+    const float k = BWD ? q.coef[0] : 0.f;
+    for (int c = threadIdx.x; c < K; c += blockDim.x) {
+      const float t = tg[c];
+      const float d = ldf<T>(pred + c) - t;
+      if (!isnan(t)) {
+        if constexpr (BWD) stf<T>(dp + c, 2.f * k * d); else { se += d * d; cnt += 1.f; }
+      } else if constexpr (BWD) stf<T>(dp + c, 0.f);
+    }
+    if constexpr (!BWD) {
+      se = block_sum256(se, sh); cnt = block_sum256(cnt, sh);
+      if (threadIdx.x == 0 && cnt > 0.f) { atomicAdd(q.acc, se); atomicAdd(q.acc + 1, cnt); }
+    }
+    return;
+  }
+  // cross entropy against argmax of the one-hot row (first maximum)
+  const long long* oh = reinterpret_cast<const long long*>(q.target) + (size_t)n * K;
+  long long bestv = LLONG_MIN; int besti = 0x7fffffff;
+  float mx = -INFINITY;
+  for (int c = threadIdx.x; c < K; c += blockDim.x) {
+    const long long v = oh[c];
+    if (v > bestv) { bestv = v; besti = c; }
+    mx = fmaxf(mx, ldf<T>(pred + c));
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long ov = __shfl_xor(bestv, o, 64); const int oi = __shfl_xor(besti, o, 64);
+    if (ov > bestv || (ov == bestv && oi < besti)) { bestv = ov; besti = oi; }
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  }
+  __shared__ long long shv[4];
+  if ((threadIdx.x & 63) == 0) { shv[threadIdx.x >> 6] = bestv; shi[threadIdx.x >> 6] = besti; sh[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (shv[w] > bestv || (shv[w] == bestv && shi[w] < besti)) { bestv = shv[w]; besti = shi[w]; }
+    mx = fmaxf(mx, sh[w]);
+  }
+  float s = 0.f;
+  for (int c = threadIdx.x; c < K; c += blockDim.x) s += __expf(ldf<T>(pred + c) - mx);
+  s = block_sum256(s, sh);
+  const float lse = mx + __logf(s);
+  if constexpr (BWD) {
+    const float k = q.coef[0];
+    for (int c = threadIdx.x; c < K; c += blockDim.x)
+      stf<T>(dp + c, k * (__expf(ldf<T>(pred + c) - lse) - (c == besti ? 1.f : 0.f)));
+  } else if (threadIdx.x == 0) {
+    atomicAdd(q.acc, lse - ldf<T>(pred + besti));
+    atomicAdd(q.acc + 1, 1.f);
+  }
+}
+
+// L_i = sum_i / count_i ; uncertainty: w_i = (exp(-s_i) L_i + s_i) [L_i != 0] (custom_loss.py:19-30)
+__global__ void loss_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ log_vars, int Tn,
+                                     float loss_scale, float* __restrict__ losses, float* __restrict__ weighted,
+                                     float* __restrict__ total, float* __restrict__ coef, float* __restrict__ dlog_vars) {
+  __shared__ float w[64];
+  const int i = threadIdx.x;
+  float wi = 0.f;
+  if (i < Tn) {
+    const float Li = acc[2 * i] / acc[2 * i + 1];
+    losses[i] = Li;
+    float dLi = 1.f;
+    if (log_vars) {
+      const float s = log_vars[i], e = __expf(-s);
+      const float nz = (Li != 0.f) ? 1.f : 0.f;
+      wi = (e * Li + s) * nz;
+      dLi = e * nz;
+      if (dlog_vars) dlog_vars[i] += loss_scale * (1.f - e * Li) * nz;
+      weighted[i] = wi;
+    } else {
+      wi = Li;
+      weighted[i] = Li;
+    }
+    coef[i] = loss_scale * dLi / acc[2 * i + 1];
+  }
+  w[i] = wi;
+  __syncthreads();
+  if (i == 0) {
+    float t = 0.f;
+    for (int j = 0; j < Tn; ++j) t += w[j];
+    total[0] = t;
+  }
+}

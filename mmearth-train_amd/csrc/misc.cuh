@@ -1,0 +1,115 @@
+// Mask generation, activity maps, weight staging, optimizer (gfx950).
+#pragma once
+#include "common.cuh"
+
+// ---------------------------------------------------------------------------------
+// Random mask from explicit noise (reference: models/fcmae.py:214-231):
+//   mask[n,l] = 1 iff rank(noise[n,l]) >= len_keep  (rank by (value, index): a stable argsort)
+// also emits the visible-patch table vis[n, slot] (ascending patch index) and inv[n, patch].
+// One block per sample.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_gen_kernel(const float* __restrict__ noise, int L, int keep,
+                                                       float* __restrict__ mask, int* __restrict__ vis,
+                                                       int* __restrict__ inv) {
+  extern __shared__ float sh[];            // noise row [L], then flags [L]
+  int* flag = reinterpret_cast<int*>(sh + L);
+  const int n = blockIdx.x;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) sh[l] = noise[(size_t)n * L + l];
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    const float v = sh[l];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) rank += (sh[j] < v) || (sh[j] == v && j < l);
+    const int masked = rank >= keep;
+    flag[l] = !masked;
+    mask[(size_t)n * L + l] = masked ? 1.f : 0.f;
+  }
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    if (flag[l]) {
+      int slot = 0;
+      for (int j = 0; j < l; ++j) slot += flag[j];
+      vis[(size_t)n * keep + slot] = l;
+      inv[(size_t)n * L + l] = slot;
+    } else {
+      inv[(size_t)n * L + l] = -1;
+    }
+  }
+}
+
+// act0[row] = (sum_c |img[n,c,y,x]| != 0) for every pixel of every visible patch (ME to_sparse)
+__global__ __launch_bounds__(256) void activity_kernel(const float* __restrict__ img, const int* __restrict__ vis,
+                                                       uint8_t* __restrict__ act, int N, int Cin, int H, int keep,
+                                                       int grid, int S) {
+  const int total = N * keep * S * S;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < total; m += gridDim.x * blockDim.x) {
+    const int P = S * S, nk = m / P, q = m - nk * P, n = nk / keep;
+    const int patch = vis[nk], py = patch / grid, px = patch - py * grid;
+    const int y = py * S + q / S, x = px * S + q % S;
+    float s = 0.f;
+    for (int c = 0; c < Cin; ++c) s += fabsf(img[((size_t)(n * Cin + c) * H + y) * H + x]);
+    act[m] = (s != 0.f) ? 1 : 0;      // NaN != 0 is true: NaN pixels are active, as in the reference
+  }
+}
+
+// act_out[m'] = OR over the k x k children (stride-k pooling of the activity map)
+__global__ __launch_bounds__(256) void activity_pool_kernel(const uint8_t* __restrict__ act_in, uint8_t* __restrict__ act_out,
+                                                            int Mout, int S, int k) {
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < Mout; m += gridDim.x * blockDim.x) {
+    const int P = S * S, nk = m / P, q = m - nk * P, iy = q / S, ix = q - iy * S;
+    int a = 0;
+    for (int kh = 0; kh < k; ++kh)
+      for (int kw = 0; kw < k; ++kw) a |= act_in[nk * (k * k * P) + (k * iy + kh) * (k * S) + (k * ix + kw)];
+    act_out[m] = a ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Weight staging: dst[r*dst_ld + c] = T(src[r*sr + c*sc]) for a table of 2-D views
+// (casts fp32 master weights to the compute type in the [N][K] layouts the GEMMs read).
+// ---------------------------------------------------------------------------------
+typedef MpmaePrepDesc PrepDesc;
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_kernel(const PrepDesc* __restrict__ table) {
+  const PrepDesc d = table[blockIdx.y];
+  const size_t total = (size_t)d.rows * d.cols;
+  T* dst = reinterpret_cast<T*>(d.dst);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = i / d.cols, c = i - (size_t)r * d.cols;
+    stf<T>(dst + (size_t)r * d.dst_ld + c, d.src[(size_t)r * d.sr + (size_t)c * d.sc]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// AdamW over the flat fp32 parameter buffer (reference: main_pretrain.py:312-320, betas
+// (0.9, 0.95), timm weight-decay grouping: decay[i] != 0 marks decayed elements).
+// hp = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale}
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ hp, float beta1, float beta2,
+                                                    float eps, float wd, size_t n,
+                                                    const uint8_t* __restrict__ decay) {
+  const float lr = hp[0], ibc1 = hp[1], isbc2 = hp[2], gs = hp[3];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gs;
+    float pi = p[i];
+    if (decay[i]) pi *= (1.f - lr * wd);
+    const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) * isbc2 + eps;
+    p[i] = pi - lr * ibc1 * mi / denom;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}

@@ -1,0 +1,289 @@
+// Row-wise kernels: LayerNorm fwd/bwd, GRN statistics finalisation, strided depthwise stem,
+// mask-token fill, global-average pooling. Rows are [M, C] channels-last in storage type T.
+#pragma once
+#include "common.cuh"
+
+constexpr int LN_MAXPER = 16;   // supports C <= 1024 with one wave per row
+
+// ---------------------------------------------------------------------------------
+// LayerNorm forward: xhat = (x - mean) * rstd (biased variance, eps inside the sqrt);
+//   optional y = act(xhat*gamma + beta), act in {0: identity, 1: GELU}
+//   rows with rowmask[m] == 0 produce zeros (inactive sparse sites).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ xhat,
+                                                     float* __restrict__ rstd_out, T* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int act, float eps, int M, int C,
+                                                     const uint8_t* __restrict__ rowmask) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int m = wave_global; m < M; m += nwaves) {
+    const bool live = !rowmask || rowmask[m];
+    float v[LN_MAXPER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+      const int c = lane + i * 64;
+      v[i] = (c < C) ? ldf<T>(x + (size_t)m * C + c) : 0.f;
+      s += v[i];
+    }
+    const float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+      const int c = lane + i * 64;
+      const float d = (c < C) ? v[i] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / C + eps);
+    if (lane == 0 && rstd_out) rstd_out[m] = live ? rstd : 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+      const int c = lane + i * 64;
+      if (c < C) {
+        float xh = live ? (v[i] - mean) * rstd : 0.f;
+        if (xhat) {
+          stf<T>(xhat + (size_t)m * C + c, xh);
+          if (sizeof(T) == 2) xh = bf2f(f2bf(xh));      // consumers (and bwd) see the rounded value
+        }
+        if (y) {
+          float u = xh * gamma[c] + beta[c];
+          if (act == 1) u = gelu_f(u);
+          stf<T>(y + (size_t)m * C + c, live ? u : 0.f);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// LayerNorm backward. dy is the gradient w.r.t. y = act(xhat*gamma + beta).
+//   dy row index = m / dy_div, scaled by dy_scale (broadcast of a pooled gradient).
+//   dx (+)= rstd * (dxh - mean(dxh) - xhat*mean(dxh*xhat)),  dxh = dy'*gamma
+//   dgamma += sum_m dy'*xhat ; dbeta += sum_m dy'
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int dy_div, float dy_scale,
+                                                     const T* __restrict__ xhat, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     int act, T* __restrict__ dx, int accumulate,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int M, int C, const uint8_t* __restrict__ rowmask) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  float ag[LN_MAXPER], ab[LN_MAXPER];
+#pragma unroll
+  for (int i = 0; i < LN_MAXPER; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int m = wave_global; m < M; m += nwaves) {
+    const bool live = !rowmask || rowmask[m];
+    float g[LN_MAXPER], xh[LN_MAXPER];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+      const int c = lane + i * 64;
+      g[i] = 0.f; xh[i] = 0.f;
+      if (c < C && live) {
+        xh[i] = ldf<T>(xhat + (size_t)m * C + c);
+        float d = ldf<T>(dy + (size_t)(m / dy_div) * C + c) * dy_scale;
+        const float ga = gamma[c];
+        if (act == 1) d *= gelu_grad_f(xh[i] * ga + beta[c]);
+        ag[i] += d * xh[i];
+        ab[i] += d;
+        g[i] = d * ga;
+        s1 += g[i];
+        s2 += g[i] * xh[i];
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    const float rs = live ? rstd[m] : 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXPER; ++i) {
+      const int c = lane + i * 64;
+      if (c < C) {
+        float v = rs * (g[i] - s1 - xh[i] * s2);
+        if (!live) v = 0.f;
+        T* o = dx + (size_t)m * C + c;
+        if (accumulate) v += ldf<T>(o);
+        stf<T>(o, v);
+      }
+    }
+  }
+  // reduce dgamma / dbeta over the block's 4 waves, then one atomic per channel per block
+#pragma unroll
+  for (int i = 0; i < LN_MAXPER; ++i) {
+    if (i * 64 < C) {
+      red[0][wave][lane] = ag[i];
+      red[1][wave][lane] = ab[i];
+      __syncthreads();
+      if (wave == 0) {
+        const int c = lane + i * 64;
+        if (c < C) {
+          const float a = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
+          const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
+          if (dgamma) atomicAdd(dgamma + c, a);
+          if (dbeta) atomicAdd(dbeta + c, b);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// GRN statistics finalisation. One block per group g.
+//   fwd: Gx = sqrt(G2[g,:]); A = mean_j Gx; Nx = Gx/(A+eps); scale[g,j] = 1 + gamma[j]*Nx[g,j]
+//   bwd: dgamma[j] += Nx*S1 ; dbeta[j] += S0 ; dNx = gamma*S1
+//        dGx = dNx/(A+eps) - (1/H) * sum_k dNx[k]*Gx[k] / (A+eps)^2 ; coef = dGx/Gx (0 if Gx == 0)
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const float* __restrict__ G2, const float* __restrict__ gamma,
+                                                               float eps, int H, float* __restrict__ Gx,
+                                                               float* __restrict__ Ainv, float* __restrict__ scale) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const float v = sqrtf(G2[(size_t)g * H + j]);
+    Gx[(size_t)g * H + j] = v;
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float A = (red[0] + red[1] + red[2] + red[3]) / H;
+  const float ainv = 1.f / (A + eps);
+  if (threadIdx.x == 0) Ainv[g] = ainv;
+  for (int j = threadIdx.x; j < H; j += 256)
+    scale[(size_t)g * H + j] = 1.f + gamma[j] * (Gx[(size_t)g * H + j] * ainv);
+}
+
+__global__ __launch_bounds__(256) void grn_bwd_finalize_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
+                                                               const float* __restrict__ Gx, const float* __restrict__ Ainv,
+                                                               const float* __restrict__ gamma, int H,
+                                                               float* __restrict__ coef, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ float red[4];
+  const int g = blockIdx.x;
+  const float ainv = Ainv[g];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const size_t i = (size_t)g * H + j;
+    s += gamma[j] * S1[i] * Gx[i];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float T2 = (red[0] + red[1] + red[2] + red[3]) * ainv * ainv / H;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const size_t i = (size_t)g * H + j;
+    const float gx = Gx[i];
+    const float dNx = gamma[j] * S1[i];
+    const float dGx = dNx * ainv - T2;
+    coef[i] = (gx > 0.f) ? dGx / gx : 0.f;
+    atomicAdd(dgamma + j, gx * ainv * S1[i]);
+    atomicAdd(dbeta + j, S0[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Strided depthwise stem conv (kernel = stride = k in {1,2}); ME kernel index = kw*k + kh.
+//   out[m', c] = sum_{kh,kw} in[child(m', kh, kw), c] * w[(kw*k+kh)*C + c] + b[c]
+// input rows are patches of (k*S)^2 points, output rows patches of S^2 points.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwstride_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                           const float* __restrict__ w, const float* __restrict__ b,
+                                                           int Mout, int C, int S, int k,
+                                                           const uint8_t* __restrict__ act_in,
+                                                           const uint8_t* __restrict__ act_out) {
+  const size_t total = (size_t)Mout * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int m = idx / C, c = idx - (size_t)m * C;
+    const int P = S * S, nk = m / P, q = m - nk * P, iy = q / S, ix = q - iy * S;
+    float acc = b[c];
+    for (int kw = 0; kw < k; ++kw)
+      for (int kh = 0; kh < k; ++kh) {
+        const int src = nk * (k * k * P) + (k * iy + kh) * (k * S) + (k * ix + kw);
+        if (!act_in || act_in[src]) acc += ldf<T>(in + (size_t)src * C + c) * w[(kw * k + kh) * C + c];
+      }
+    if (act_out && !act_out[m]) acc = 0.f;
+    stf<T>(out + idx, acc);
+  }
+}
+
+// backward: din[src,c] = dout[m',c]*w[tap,c] ; dw[tap,c] += sum dout*in ; db[c] += sum dout
+template <typename T>
+__global__ __launch_bounds__(256) void dwstride_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ in,
+                                                           T* __restrict__ din, const float* __restrict__ w,
+                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           int Mout, int C, int S, int k,
+                                                           const uint8_t* __restrict__ act_in) {
+  // thread <-> channel (threadIdx.x % C-chunk), rows strided: keeps per-thread channel fixed so the
+  // dw/db partial sums live in registers.
+  const int cpb = (C < 256) ? C : 256;            // channels handled per block pass
+  const int rows_par = 256 / cpb > 0 ? 256 / cpb : 1;
+  const int tc = threadIdx.x % cpb, tr = threadIdx.x / cpb;
+  for (int c0 = 0; c0 < C; c0 += cpb) {
+    const int c = c0 + tc;
+    float adw[4] = {0.f, 0.f, 0.f, 0.f}, adb = 0.f;
+    if (c < C && tr < rows_par) {
+      for (int m = blockIdx.x * rows_par + tr; m < Mout; m += gridDim.x * rows_par) {
+        const int P = S * S, nk = m / P, q = m - nk * P, iy = q / S, ix = q - iy * S;
+        const float g = ldf<T>(dout + (size_t)m * C + c);
+        adb += g;
+        for (int kw = 0; kw < k; ++kw)
+          for (int kh = 0; kh < k; ++kh) {
+            const int tap = kw * k + kh;
+            const int src = nk * (k * k * P) + (k * iy + kh) * (k * S) + (k * ix + kw);
+            const bool live = !act_in || act_in[src];
+            stf<T>(din + (size_t)src * C + c, live ? g * w[tap * C + c] : 0.f);
+            if (live) adw[tap] += g * ldf<T>(in + (size_t)src * C + c);
+          }
+      }
+      for (int t = 0; t < k * k; ++t) atomicAdd(dw + t * C + c, adw[t]);
+      atomicAdd(db + c, adb);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// decoder input: rows of masked patches take the mask token (fcmae.py:253-255); rows of
+// visible patches were written by the proj GEMM (EPI_SCATTER_ROWS).
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void fill_mask_token_kernel(T* __restrict__ xdec, const float* __restrict__ token,
+                                                              const int* __restrict__ inv, int rows, int D) {
+  const size_t total = (size_t)rows * D;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = idx / D, c = idx - (size_t)r * D;
+    if (inv[r] < 0) stf<T>(xdec + idx, token[c]);
+  }
+}
+
+// d(mask_token)[c] += sum over masked rows of dxdec[r, c]
+template <typename T>
+__global__ __launch_bounds__(256) void mask_token_bwd_kernel(const T* __restrict__ dxdec, const int* __restrict__ inv,
+                                                             float* __restrict__ dtoken, int rows, int D) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y)
+    if (inv[r] < 0) a += ldf<T>(dxdec + (size_t)r * D + c);
+  atomicAdd(dtoken + c, a);
+}
+
+// pooled[n, c] = mean over L rows ; bwd handled by ln_bwd's dy_div/dy_scale broadcast
+template <typename T>
+__global__ __launch_bounds__(256) void pool_rows_kernel(const T* __restrict__ x, T* __restrict__ pooled, int N, int L, int C) {
+  const size_t total = (size_t)N * C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int n = idx / C, c = idx - (size_t)n * C;
+    float a = 0.f;
+    for (int l = 0; l < L; ++l) a += ldf<T>(x + ((size_t)n * L + l) * C + c);
+    stf<T>(pooled + idx, a / L);
+  }
+}

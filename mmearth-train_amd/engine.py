@@ -1,0 +1,740 @@
+"""MP-MAE pretraining step on MI355X: forward + losses + backward + AdamW as an explicit
+launch sequence of libmpmae_hip.so kernels (no autograd, no MinkowskiEngine, no CPU fallback).
+
+The engine owns (through torch, which is only the allocator / stream / collective provider):
+  * one flat fp32 parameter buffer, one flat fp32 gradient buffer, AdamW moments;
+  * a compute-type (fp32 or bf16) arena of staged weights in the [N][K] layouts the GEMMs read;
+  * all activation workspaces of the step for a fixed per-GPU batch size N;
+  * pre-built ctypes argument records, so a step is a flat loop of C-ABI calls that can be
+    captured into a HIP graph.
+
+Reference call path reproduced (paths relative to /root/reference):
+  FCMAE.forward            models/fcmae.py:414-456
+  SparseConvNeXtV2.forward models/convnextv2_sparse.py:191-220 (+ Block :47-56)
+  forward_decoder          models/fcmae.py:249-265 (shared decoder Block evaluated once)
+  forward_loss             models/fcmae.py:267-412, custom_loss.py:19-30
+  backward / optimizer     engine_pretrain.py:87-94, main_pretrain.py:312-320
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import EPI, PRO
+from .config import ModelCfg
+from .synth import state_dict_spec
+
+F32, BF16 = 0, 1
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
+                 track_activity: bool = True, mask_ratio=None):
+        if cfg.decoder_depth != 1:
+            raise NotImplementedError("decoder_depth != 1")
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.N = N = int(batch_size)
+        self.dt = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}[dtype]
+        self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
+        self.device = torch.device(device)
+        self.track_activity = track_activity
+        self.L = cfg.num_patches
+        self.grid = cfg.grid
+        self.keep = cfg.len_keep(mask_ratio)
+        self.p = cfg.patch_size
+        self.S = [8, 4, 2, 1]
+        self.M = [N * self.keep * s * s for s in self.S]
+        self.Mfull = N * self.keep * self.p * self.p
+        self.D = cfg.decoder_embed_dim
+        self._keepalive = []
+        self._build_params()
+        self._alloc()
+        self._build_prep()
+        self.fwd_ops, self.bwd_ops = [], []
+        self._build_forward()
+        self._build_backward()
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ params
+    def _build_params(self):
+        spec = state_dict_spec(self.cfg)
+        total = sum(math.prod(s) for _, s, _ in spec)
+        dev = self.device
+        self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.mflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.vflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.decay_mask = torch.zeros(total, dtype=torch.uint8, device=dev)
+        self.params, self.grads, self.offsets = OrderedDict(), OrderedDict(), OrderedDict()
+        off = 0
+        for key, shape, _ in spec:
+            n = math.prod(shape)
+            self.params[key] = self.pflat[off:off + n].view(shape)
+            self.grads[key] = self.gflat[off:off + n].view(shape)
+            self.offsets[key] = (off, n)
+            # timm param_groups_weight_decay: ndim <= 1 or name endswith ".bias" -> no decay
+            if len(shape) > 1 and not key.endswith(".bias"):
+                self.decay_mask[off:off + n] = 1
+            off += n
+        self.n_params = total
+        self.hp = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.hp_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        self.gnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def load_state_dict(self, sd):
+        """sd: reference-layout state dict (aliases of the shared decoder block are accepted)."""
+        first = self.cfg.out_mods[0].name
+        for key, t in self.params.items():
+            src = sd[key] if key in sd else None
+            if src is None and key.startswith(f"decoder_dict.{first}.0."):
+                raise KeyError(key)
+            if src is None:
+                raise KeyError(key)
+            t.copy_(src.to(torch.float32).reshape(t.shape))
+
+    def state_dict(self):
+        """Reference-layout state dict (shared decoder block replicated under every modality)."""
+        first = self.cfg.out_mods[0].name
+        pre = f"decoder_dict.{first}.0."
+        out = OrderedDict()
+        for k, v in self.params.items():
+            if not k.startswith(pre):
+                out[k] = v
+        for m in self.cfg.out_mods:
+            for k, v in self.params.items():
+                if k.startswith(pre):
+                    out[f"decoder_dict.{m.name}.0." + k[len(pre):]] = v
+        return out
+
+    # ------------------------------------------------------------------ buffers
+    def _t(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=dtype or self.tdtype, device=self.device)
+
+    def _alloc(self):
+        cfg, N, L, D = self.cfg, self.N, self.L, self.D
+        dims, dev = cfg.dims, self.device
+        f32 = torch.float32
+        S = cfg.img_size
+        # static inputs
+        self.inp = OrderedDict()
+        self.inp["sentinel2"] = torch.zeros(N, cfg.in_chans, S, S, dtype=f32, device=dev)
+        for om in cfg.out_mods:
+            if om.name == "sentinel2":
+                continue
+            if om.kind == "pix_cont":
+                self.inp[om.name] = torch.zeros(N, om.chans, S, S, dtype=f32, device=dev)
+            elif om.kind == "pix_cat":
+                self.inp[om.name] = torch.zeros(N, 1, S, S, dtype=torch.int64, device=dev)
+            elif om.kind == "img_cat":
+                self.inp[om.name] = torch.zeros(N, om.chans, dtype=torch.int64, device=dev)
+            else:
+                self.inp[om.name] = torch.zeros(N, om.chans, dtype=f32, device=dev)
+        self.noise = torch.zeros(N, L, dtype=f32, device=dev)
+        self.mask = torch.zeros(N, L, dtype=f32, device=dev)
+        self.vis = torch.zeros(N * self.keep, dtype=torch.int32, device=dev)
+        self.inv = torch.zeros(N * L, dtype=torch.int32, device=dev)
+        # activity maps
+        if self.track_activity:
+            self.act_full = torch.ones(self.Mfull, dtype=torch.uint8, device=dev)
+            self.act = [self.act_full if self.p == 8 else torch.ones(self.M[0], dtype=torch.uint8, device=dev)]
+            for i in range(1, 4):
+                self.act.append(torch.ones(self.M[i], dtype=torch.uint8, device=dev))
+        else:
+            self.act_full = None
+            self.act = [None] * 4
+        C0 = dims[0]
+        # stem
+        self.c1 = self._t(self.Mfull, C0)
+        self.c1hat = self._t(self.Mfull, C0)
+        self.rstd1 = self._t(self.Mfull, dtype=f32)
+        self.a1 = self._t(self.Mfull, C0)
+        self.s0 = self._t(self.M[0], C0)
+        self.s0hat = self._t(self.M[0], C0)
+        self.rstd2 = self._t(self.M[0], dtype=f32)
+        self.x0 = self._t(self.M[0], C0)
+        # statistics arena (zeroed once per step): GRN stats fwd/bwd, loss accumulators
+        self._stat_sizes = []
+        self.blocks = []           # encoder blocks then the decoder block
+        for i in range(4):
+            for j in range(cfg.depths[i]):
+                self.blocks.append(self._alloc_block(f"encoder.stages.{i}.{j}", self.M[i], dims[i], 1, i, sparse=True))
+        self.dec = self._alloc_block(f"decoder_dict.{cfg.out_mods[0].name}.0", N * L, D, N, None, sparse=False)
+        self.down = []
+        for i in range(3):
+            self.down.append(dict(xhat=self._t(self.M[i], dims[i]), rstd=self._t(self.M[i], dtype=f32),
+                                  out=self._t(self.M[i + 1], dims[i + 1])))
+        self.xdec = self._t(N * L, D)
+        # heads
+        self.Wpix = sum(m.head_out for m in cfg.pix_mods)
+        self.Wimg = sum(m.head_out for m in cfg.img_mods)
+        self.ldimg = max(8, _rup(self.Wimg, 8))
+        self.pred_pix = self._t(N * L, max(self.Wpix, 8))
+        self.dpred_pix = self._t(N * L, max(self.Wpix, 8))
+        self.pred_img = torch.zeros(N, self.ldimg, dtype=self.tdtype, device=dev)
+        self.dpred_img = torch.zeros(N, self.ldimg, dtype=self.tdtype, device=dev)
+        self.yhat = self._t(N * L, D)
+        self.rstd_y = self._t(N * L, dtype=f32)
+        self.yln = self._t(N * L, D)
+        self.pooled = self._t(N, D)
+        self.dpooled = self._t(N, D)
+        T = len(cfg.out_mods)
+        self.n_stats = sum(self._stat_sizes) + 2 * T
+        self.stats = torch.zeros(self.n_stats, dtype=f32, device=dev)
+        off = 0
+        for blk in self.blocks + [self.dec]:
+            G, H = blk["G"], blk["H"]
+            for nm in ("G2", "S0", "S1"):
+                blk[nm] = self.stats[off:off + G * H]
+                off += G * H
+        self.loss_acc = self.stats[off:off + 2 * T]
+        self.losses = torch.zeros(T, dtype=f32, device=dev)
+        self.weighted = torch.zeros(T, dtype=f32, device=dev)
+        self.total = torch.zeros(1, dtype=f32, device=dev)
+        self.coef = torch.zeros(T, dtype=f32, device=dev)
+        npc = max(1, len([m for m in cfg.out_mods if m.kind == "pix_cont"]))
+        self.patch_buf = torch.zeros(npc, 4, N * L, dtype=f32, device=dev)
+        # backward scratch
+        maxMH = max(b["M"] * b["H"] for b in self.blocks + [self.dec])
+        maxMC = max(max(b["M"] * b["C"] for b in self.blocks + [self.dec]), self.Mfull * C0)
+        self.scr_dz = self._t(maxMH)
+        self.scr_dxn = self._t(maxMC)
+        self.scr_dd = self._t(maxMC)
+        self.scr_dxA = self._t(maxMC)
+        self.scr_dxB = self._t(maxMC)
+        self.dy = self._t(N * L, D)
+
+    def _alloc_block(self, prefix, M, Cc, G, stage, sparse):
+        H = 4 * Cc
+        f32 = torch.float32
+        blk = dict(prefix=prefix, M=M, C=Cc, H=H, G=G, stage=stage, sparse=sparse,
+                   d=self._t(M, Cc), dhat=self._t(M, Cc), rstd=self._t(M, dtype=f32),
+                   h=self._t(M, H), out=self._t(M, Cc),
+                   Gx=self._t(G * H, dtype=f32), Ainv=self._t(G, dtype=f32),
+                   scale=self._t(G * H, dtype=f32), coef=self._t(G * H, dtype=f32))
+        self._stat_sizes.append(3 * G * H)
+        return blk
+
+    # ------------------------------------------------------------------ weight staging
+    def _build_prep(self):
+        """Arena of compute-type weight copies in [N][K] layout + the device descriptor table."""
+        descs = []
+        self.w = {}
+        chunks = []
+
+        def add(name, src, rows, cols, sr, sc, ld=None, dst=None, coloff=0):
+            """dst[r, coloff + c] = src.flat[r*sr + c*sc]; a new [rows][ld] matrix unless dst is given."""
+            if dst is None:
+                dst = dict(rows=rows, ld=ld or _rup(cols, 8), off=None)
+                chunks.append((name, dst))
+                self.w[name] = dst
+            descs.append((src, None, dst, rows, cols, sr, sc, coloff))
+            return dst
+
+        P = self.params
+        cfg, dims, D = self.cfg, self.cfg.dims, self.D
+        C0 = dims[0]
+        k = P["encoder.initial_conv.0.kernel"]
+        add("stem.Wt", k, C0, 9 * cfg.in_chans, 1, C0)
+
+        def block_weights(prefix, Cc, sparse):
+            H = 4 * Cc
+            w1 = P[prefix + (".pwconv1.linear.weight" if sparse else ".pwconv1.weight")]
+            w2 = P[prefix + (".pwconv2.linear.weight" if sparse else ".pwconv2.weight")]
+            add(prefix + ".W1", w1, H, Cc, Cc, 1)
+            add(prefix + ".W2", w2, Cc, H, H, 1)
+            add(prefix + ".W1T", w1, Cc, H, 1, Cc)
+            add(prefix + ".W2T", w2, H, Cc, 1, H)
+
+        for blk in self.blocks:
+            block_weights(blk["prefix"], blk["C"], True)
+        for i in range(3):
+            kk = P[f"encoder.downsample_layers.{i}.1.kernel"]      # (4, C, C')
+            Ci, Co = dims[i], dims[i + 1]
+            add(f"down{i}.Wt", kk, Co, 4 * Ci, 1, Co)            # [C'][4C]
+            add(f"down{i}.W", kk, 4 * Ci, Co, Co, 1)             # [4C][C']
+        add("proj.W", P["proj.weight"], D, dims[3], dims[3], 1)
+        add("proj.WT", P["proj.weight"], dims[3], D, 1, dims[3])
+        block_weights(self.dec["prefix"], D, False)
+        pixT = imgT = None
+        coff_p = coff_i = 0
+        for om in cfg.out_mods:
+            wsrc = P[f"pred_dict.{om.name}.weight"]
+            add(f"head.{om.name}.W", wsrc, om.head_out, D, D, 1)
+            if om.kind.startswith("pix"):
+                if pixT is None:
+                    pixT = add("head.pixT", wsrc, D, om.head_out, 1, D, ld=_rup(self.Wpix, 8))
+                else:
+                    add("head.pixT", wsrc, D, om.head_out, 1, D, dst=pixT, coloff=coff_p)
+                coff_p += om.head_out
+            else:
+                if imgT is None:
+                    imgT = add("head.imgT", wsrc, D, om.head_out, 1, D, ld=self.ldimg)
+                else:
+                    add("head.imgT", wsrc, D, om.head_out, 1, D, dst=imgT, coloff=coff_i)
+                coff_i += om.head_out
+        # lay the arena out
+        total = 0
+        for _, dst in chunks:
+            dst["off"] = total
+            total += _rup(dst["rows"] * dst["ld"], 64)
+        self.warena = torch.zeros(total, dtype=self.tdtype, device=self.device)
+        esz = self.warena.element_size()
+        for _, dst in chunks:
+            dst["t"] = self.warena[dst["off"]:dst["off"] + dst["rows"] * dst["ld"]]
+        table = (_lib.PrepDesc * len(descs))()
+        mx = 0
+        for i, (src, _, dst, rows, cols, sr, sc, coloff) in enumerate(descs):
+            table[i].src = src.data_ptr()
+            table[i].dst = self.warena.data_ptr() + (dst["off"] + coloff) * esz
+            table[i].rows, table[i].cols, table[i].sr, table[i].sc = rows, cols, sr, sc
+            table[i].dst_ld = dst["ld"]
+            mx = max(mx, rows * cols)
+        raw = bytes(table)
+        self.prep_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.prep_n, self.prep_max = len(descs), mx
+
+    # ------------------------------------------------------------------ op helpers
+    def _op(self, lst, name, fn, *args):
+        lst.append((name, fn, args))
+
+    def _gemm(self, lst, name, pro, epi, **kw):
+        a = _lib.GemmArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        if not kw.get("rpg"):
+            a.rpg = max(int(a.M), 1)
+        self._keepalive.append(a)
+        self._op(lst, name, self.lib.mpmae_gemm, self.dt, PRO[pro], EPI[epi], C.byref(a))
+
+    def _wgrad(self, lst, name, ppro, qpro, **kw):
+        a = _lib.WgradArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        if not kw.get("rpg"):
+            a.rpg = max(int(a.M), 1)
+        tiles = ((a.Nn + 63) // 64) * ((a.Kk + 63) // 64)
+        splits = max(1, min((1024 + tiles - 1) // tiles, (a.M + 255) // 256))
+        self._keepalive.append(a)
+        self._op(lst, name, self.lib.mpmae_wgrad, self.dt, PRO[ppro], PRO[qpro], C.byref(a), splits)
+
+    def _geom(self, stage):
+        g = _lib.Geom()
+        if stage is None:      # dense decoder grid
+            g.vis, g.inv, g.N, g.keep, g.grid, g.S = 0, 0, self.N, self.L, self.grid, 1
+        else:
+            g.vis, g.inv = self.vis.data_ptr(), self.inv.data_ptr()
+            g.N, g.keep, g.grid, g.S = self.N, self.keep, self.grid, self.S[stage]
+        return g
+
+    def _dw_tiling(self, stage, Cc):
+        S = 1 if stage is None else self.S[stage]
+        TP = {8: 1, 4: 2, 2: 4, 1: 7}[S]
+        if TP * S > 8:
+            TP = 8 // S
+        tiles_side = (self.grid + TP - 1) // TP
+        CC = Cc if Cc <= 96 else 64
+        return TP, tiles_side, CC
+
+    def _dw_weight(self, blk):
+        P, G = self.params, self.grads
+        pre = blk["prefix"]
+        Cc = blk["C"]
+        if blk["sparse"]:   # ME kernel (49, C), index (kw*7+kh)*C + c
+            return P[pre + ".dwconv.kernel"], G[pre + ".dwconv.kernel"], P[pre + ".dwconv.bias"], G[pre + ".dwconv.bias"], (Cc, 7 * Cc, 1)
+        return P[pre + ".dwconv.weight"], G[pre + ".dwconv.weight"], P[pre + ".dwconv.bias"], G[pre + ".dwconv.bias"], (7, 1, 49)
+
+    def _dwconv(self, lst, name, blk, x, out, add, flip, with_bias):
+        w, _, b, _, (skh, skw, sc) = self._dw_weight(blk)
+        TP, ts, CC = self._dw_tiling(blk["stage"], blk["C"])
+        a = _lib.DwArgs()
+        a.x, a.out, a.add = x.data_ptr(), out.data_ptr(), (add.data_ptr() if add is not None else 0)
+        a.w, a.bias = w.data_ptr(), (b.data_ptr() if with_bias else 0)
+        a.s_kh, a.s_kw, a.s_c, a.flip = skh, skw, sc, flip
+        a.g = self._geom(blk["stage"])
+        a.C, a.CC, a.TP, a.tiles_side = blk["C"], CC, TP, ts
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        a.act = act.data_ptr() if act is not None else 0
+        self._keepalive.append(a)
+        self._op(lst, name, self.lib.mpmae_dwconv7_fwd, self.dt, C.byref(a))
+
+    def _block_names(self, blk):
+        pre, sp = blk["prefix"], blk["sparse"]
+        return dict(
+            ln_w=pre + (".norm.ln.weight" if sp else ".norm.weight"),
+            ln_b=pre + (".norm.ln.bias" if sp else ".norm.bias"),
+            w1=pre + (".pwconv1.linear.weight" if sp else ".pwconv1.weight"),
+            b1=pre + (".pwconv1.linear.bias" if sp else ".pwconv1.bias"),
+            w2=pre + (".pwconv2.linear.weight" if sp else ".pwconv2.weight"),
+            b2=pre + (".pwconv2.linear.bias" if sp else ".pwconv2.bias"),
+            gg=pre + ".grn.gamma", gb=pre + ".grn.beta")
+
+    # ------------------------------------------------------------------ forward program
+    def _block_fwd(self, lst, blk, x):
+        P, lib, dt = self.params, self.lib, self.dt
+        nm = self._block_names(blk)
+        M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        rpg = M if blk["sparse"] else self.L
+        eps = 1e-6 if blk["sparse"] else 1e-4
+        tag = blk["prefix"]
+        blk["x"] = x
+        self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
+        self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]), None,
+                 None, None, 0, 1e-6, M, Cc, _p(act))
+        self._gemm(lst, tag + ":pw1", "LN_AFFINE", "GELU_SUMSQ", A=blk["dhat"], B=self.w[tag + ".W1"]["t"],
+                   bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
+                   p0=P[nm["ln_w"]], p1=P[nm["ln_b"]], rpg=rpg, s0=blk["G2"], act=act)
+        self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
+                 _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
+        self._gemm(lst, tag + ":pw2", "GRN", "RESID", A=blk["h"], B=self.w[tag + ".W2"]["t"], bias=P[nm["b2"]],
+                   C=blk["out"], R=x, M=M, N=Cc, K=H, lda=H, ldb=self.w[tag + ".W2"]["ld"], ldc=Cc, ldr=Cc,
+                   p0=blk["scale"], p1=P[nm["gb"]], rpg=rpg, act=act)
+        return blk["out"]
+
+    def _build_forward(self):
+        cfg, P, lib, dt, N, L, D = self.cfg, self.params, self.lib, self.dt, self.N, self.L, self.D
+        f = self.fwd_ops
+        dims = cfg.dims
+        C0, p, k = dims[0], self.p, cfg.stem_k
+        self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max)
+        self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv))
+        img = self.inp["sentinel2"]
+        if self.track_activity:
+            self._op(f, "act0", lib.mpmae_activity, _p(img), _p(self.vis), _p(self.act_full), N, cfg.in_chans,
+                     cfg.img_size, self.keep, self.grid, p)
+            if k > 1:
+                self._op(f, "actpool_stem", lib.mpmae_activity_pool, _p(self.act_full), _p(self.act[0]), self.M[0], 8, k)
+            for i in range(1, 4):
+                self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2)
+        wt = self.w["stem.Wt"]
+        self._gemm(f, "stem:conv", "IM2COL3", "STORE", A=img, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
+                   C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
+                   vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
+                   grid=self.grid, H=cfg.img_size)
+        self._op(f, "stem:ln1", lib.mpmae_ln_fwd, dt, _p(self.c1), _p(self.c1hat), _p(self.rstd1), _p(self.a1),
+                 _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, 1e-6,
+                 self.Mfull, C0, _p(self.act_full))
+        self._op(f, "stem:dw", lib.mpmae_dwstride_fwd, dt, _p(self.a1), _p(self.s0), _p(P["encoder.stem.0.kernel"]),
+                 _p(P["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full), _p(self.act[0]))
+        self._op(f, "stem:ln2", lib.mpmae_ln_fwd, dt, _p(self.s0), _p(self.s0hat), _p(self.rstd2), _p(self.x0),
+                 _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, 1e-6, self.M[0], C0,
+                 _p(self.act[0]))
+        x = self.x0
+        bi = 0
+        for i in range(4):
+            if i > 0:
+                dn = self.down[i - 1]
+                pre = f"encoder.downsample_layers.{i - 1}"
+                dn["x"] = x
+                self._op(f, pre + ":ln", lib.mpmae_ln_fwd, dt, _p(x), _p(dn["xhat"]), _p(dn["rstd"]), None, None, None,
+                         0, 1e-6, self.M[i - 1], dims[i - 1], _p(self.act[i - 1]))
+                wd = self.w[f"down{i - 1}.Wt"]
+                self._gemm(f, pre + ":conv", "DOWN_GATHER", "STORE", A=dn["xhat"], B=wd["t"], bias=P[pre + ".1.bias"],
+                           C=dn["out"], M=self.M[i], N=dims[i], K=4 * dims[i - 1], lda=dims[i - 1], ldb=wd["ld"],
+                           ldc=dims[i], p0=P[pre + ".0.ln.weight"], p1=P[pre + ".0.ln.bias"], S=self.S[i],
+                           Cseg=dims[i - 1], act=self.act[i], act_src=self.act[i - 1])
+                x = dn["out"]
+            for j in range(cfg.depths[i]):
+                x = self._block_fwd(f, self.blocks[bi], x)
+                bi += 1
+        self.enc_out = x
+        wp = self.w["proj.W"]
+        self._gemm(f, "proj", "NONE", "SCATTER_ROWS", A=x, B=wp["t"], bias=P["proj.bias"], C=self.xdec, M=self.M[3],
+                   N=D, K=dims[3], lda=dims[3], ldb=wp["ld"], ldc=D, vis=self.vis, keep=self.keep, L=L)
+        self._op(f, "mask_token", lib.mpmae_fill_mask_token, dt, _p(self.xdec), _p(P["mask_token"]), _p(self.inv), N * L, D)
+        y = self._block_fwd(f, self.dec, self.xdec)
+        self.dec_out = y
+        # heads
+        coff = 0
+        self.head_cols = {}
+        for om in cfg.pix_mods:
+            wh = self.w[f"head.{om.name}.W"]
+            cview = self.pred_pix.view(-1)[coff:]
+            self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=y, B=wh["t"], bias=P[f"pred_dict.{om.name}.bias"],
+                       C=cview, M=N * L, N=om.head_out, K=D, lda=D, ldb=wh["ld"], ldc=self.pred_pix.shape[1])
+            self.head_cols[om.name] = coff
+            coff += om.head_out
+        if cfg.img_mods:
+            self._op(f, "head:ln", lib.mpmae_ln_fwd, dt, _p(y), _p(self.yhat), _p(self.rstd_y), _p(self.yln),
+                     _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, 1e-6, N * L, D, None)
+            self._op(f, "head:pool", lib.mpmae_pool_rows, dt, _p(self.yln), _p(self.pooled), N, L, D)
+            coff = 0
+            for om in cfg.img_mods:
+                wh = self.w[f"head.{om.name}.W"]
+                cview = self.pred_img.view(-1)[coff:]
+                self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=self.pooled, B=wh["t"],
+                           bias=P[f"pred_dict.{om.name}.bias"], C=cview, M=N, N=om.head_out, K=D, lda=D,
+                           ldb=wh["ld"], ldc=self.ldimg)
+                self.head_cols[om.name] = coff
+                coff += om.head_out
+        # losses
+        self.loss_args = {}
+        ipc = 0
+        for t, om in enumerate(cfg.out_mods):
+            acc = self.loss_acc[2 * t:2 * t + 2]
+            coef = self.coef[t:t + 1]
+            tgt = self.inp[om.name]
+            if om.kind == "pix_cont":
+                a = _lib.PixContArgs()
+                a.pred, a.dpred = self.pred_pix.data_ptr(), self.dpred_pix.data_ptr()
+                a.ld, a.coff = self.pred_pix.shape[1], self.head_cols[om.name]
+                a.target, a.mask = tgt.data_ptr(), self.mask.data_ptr()
+                a.C, a.p, a.grid, a.H, a.L = om.chans, self.p, self.grid, cfg.img_size, L
+                a.norm_pix = 1 if (cfg.norm_pix_loss and om.name == "sentinel2") else 0
+                a.acc = acc.data_ptr()
+                pb = self.patch_buf[ipc]
+                ipc += 1
+                a.patch_l, a.patch_cnt, a.patch_mean, a.patch_rstd = (pb[i].data_ptr() for i in range(4))
+                a.coef = coef.data_ptr()
+                self._keepalive.append(a)
+                self.loss_args[om.name] = a
+                self._op(f, f"loss:{om.name}", lib.mpmae_loss_pix_cont, dt, 0, C.byref(a), N * L)
+            elif om.kind == "pix_cat":
+                a = _lib.PixCatArgs()
+                a.pred, a.dpred = self.pred_pix.data_ptr(), self.dpred_pix.data_ptr()
+                a.ld, a.coff = self.pred_pix.shape[1], self.head_cols[om.name]
+                a.target, a.mask = tgt.data_ptr(), self.mask.data_ptr()
+                a.K, a.p, a.grid, a.H, a.L = om.chans, self.p, self.grid, cfg.img_size, L
+                a.acc, a.coef = acc.data_ptr(), coef.data_ptr()
+                self._keepalive.append(a)
+                self.loss_args[om.name] = a
+                self._op(f, f"loss:{om.name}", lib.mpmae_loss_pix_cat, dt, 0, C.byref(a), N * L)
+            else:
+                a = _lib.ImgArgs()
+                a.pred, a.dpred = self.pred_img.data_ptr(), self.dpred_img.data_ptr()
+                a.ld, a.coff = self.ldimg, self.head_cols[om.name]
+                a.target = tgt.data_ptr()
+                a.K, a.N, a.kind = om.chans, N, (0 if om.kind == "img_cat" else 1)
+                a.acc, a.coef = acc.data_ptr(), coef.data_ptr()
+                self._keepalive.append(a)
+                self.loss_args[om.name] = a
+                self._op(f, f"loss:{om.name}", lib.mpmae_loss_img, dt, 0, C.byref(a))
+        self.loss_scale = 1.0
+        lv = P.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
+        glv = self.grads.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
+        self._fin_args = (_p(self.loss_acc), _p(lv), len(cfg.out_mods), _p(self.losses), _p(self.weighted),
+                          _p(self.total), _p(self.coef), _p(glv))
+
+    # ------------------------------------------------------------------ backward program
+    def _block_bwd(self, lst, blk, dout, dx):
+        """dout: gradient w.r.t. the block output [M,C]; writes the gradient w.r.t. its input into dx."""
+        P, Gd, lib, dt = self.params, self.grads, self.lib, self.dt
+        nm = self._block_names(blk)
+        M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        rpg = M if blk["sparse"] else self.L
+        tag = blk["prefix"]
+        dz = self.scr_dz[:M * H]
+        dxn = self.scr_dxn[:M * Cc]
+        dd = self.scr_dd[:M * Cc]
+        w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
+        self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H, K=Cc,
+                   lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
+        self._wgrad(lst, tag + ":pw2.wgrad", "NONE", "GRN", P=dout, Q=blk["h"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
+                    dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]], qp0=blk["scale"], qp1=P[nm["gb"]], rpg=rpg)
+        self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
+                 _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
+        self._gemm(lst, tag + ":pw1.dgrad", "GRN_BWD", "STORE", A=dz, A2=blk["h"], B=w1t["t"], C=dxn, M=M, N=Cc, K=H,
+                   lda=H, ldb=w1t["ld"], ldc=Cc, p0=blk["scale"], p1=blk["coef"], rpg=rpg)
+        self._wgrad(lst, tag + ":pw1.wgrad", "GRN_BWD", "LN_AFFINE", P=dz, P2=blk["h"], Q=blk["dhat"], M=M, Nn=H,
+                    Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]], pp0=blk["scale"],
+                    pp1=blk["coef"], qp0=P[nm["ln_w"]], qp1=P[nm["ln_b"]], rpg=rpg)
+        self._op(lst, tag + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+                 _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
+                 _p(act))
+        # depthwise conv: weight grad, then data grad (+ residual)
+        w, gw, b, gb, (skh, skw, sc) = self._dw_weight(blk)
+        TP, ts, CC = self._dw_tiling(blk["stage"], Cc)
+        a = _lib.DwWgArgs()
+        a.x, a.dd, a.dw, a.db = blk["x"].data_ptr(), dd.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        a.s_kh, a.s_kw, a.s_c = skh, skw, sc
+        a.g = self._geom(blk["stage"])
+        a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
+        a.ntiles_total = self.N * ts * ts
+        a.act = act.data_ptr() if act is not None else 0
+        self._keepalive.append(a)
+        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024)
+        self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
+
+    def _build_backward(self):
+        cfg, P, Gd, lib, dt, N, L, D = self.cfg, self.params, self.grads, self.lib, self.dt, self.N, self.L, self.D
+        b = self.bwd_ops
+        dims = cfg.dims
+        y = self.dec_out
+        # loss gradients w.r.t. predictions
+        for om in cfg.out_mods:
+            a = self.loss_args[om.name]
+            if om.kind == "pix_cont":
+                self._op(b, f"dloss:{om.name}", lib.mpmae_loss_pix_cont, dt, 1, C.byref(a), N * L)
+            elif om.kind == "pix_cat":
+                self._op(b, f"dloss:{om.name}", lib.mpmae_loss_pix_cat, dt, 1, C.byref(a), N * L)
+            else:
+                self._op(b, f"dloss:{om.name}", lib.mpmae_loss_img, dt, 1, C.byref(a))
+        ldp = self.pred_pix.shape[1]
+        for om in cfg.pix_mods:
+            pv = self.dpred_pix.view(-1)[self.head_cols[om.name]:]
+            self._wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", P=pv, Q=y, M=N * L, Nn=om.head_out, Kk=D, ldp=ldp,
+                        ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1, db=Gd[f"pred_dict.{om.name}.bias"])
+        have_pix = bool(cfg.pix_mods)
+        if have_pix:
+            wt = self.w["head.pixT"]
+            self._gemm(b, "head:pix.dgrad", "NONE", "STORE", A=self.dpred_pix, B=wt["t"], C=self.dy, M=N * L, N=D,
+                       K=self.Wpix, lda=ldp, ldb=wt["ld"], ldc=D)
+        if cfg.img_mods:
+            for om in cfg.img_mods:
+                pv = self.dpred_img.view(-1)[self.head_cols[om.name]:]
+                self._wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", P=pv, Q=self.pooled, M=N, Nn=om.head_out, Kk=D,
+                            ldp=self.ldimg, ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1,
+                            db=Gd[f"pred_dict.{om.name}.bias"])
+            wt = self.w["head.imgT"]
+            self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
+                       K=self.Wimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
+            self._op(b, "head:ln.bwd", lib.mpmae_ln_bwd, dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
+                     _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, _p(self.dy), 1 if have_pix else 0,
+                     _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
+        # decoder block
+        dxdec = self.scr_dxA[:N * L * D]
+        self._block_bwd(b, self.dec, self.dy, dxdec)
+        self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D)
+        self._wgrad(b, "proj.wgrad", "ROW_GATHER", "NONE", P=dxdec, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
+                    ldq=dims[3], dW=Gd["proj.weight"], sn=dims[3], sk=1, db=Gd["proj.bias"], vis=self.vis,
+                    keep=self.keep, L=L)
+        wpt = self.w["proj.WT"]
+        cur = self.scr_dxB[:self.M[3] * dims[3]]
+        self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
+                   ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
+        other = self.scr_dxA
+        bi = len(self.blocks) - 1
+        for i in range(3, -1, -1):
+            for j in range(cfg.depths[i] - 1, -1, -1):
+                blk = self.blocks[bi]
+                nxt = other[:blk["M"] * blk["C"]]
+                self._block_bwd(b, blk, cur, nxt)
+                other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
+                cur = nxt
+                bi -= 1
+            if i > 0:
+                dn = self.down[i - 1]
+                pre = f"encoder.downsample_layers.{i - 1}"
+                Ci, Co = dims[i - 1], dims[i]
+                self._wgrad(b, pre + ":wgrad", "NONE", "DOWN_GATHER", P=cur, Q=dn["xhat"], M=self.M[i], Nn=Co, Kk=4 * Ci,
+                            ldp=Co, ldq=Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"],
+                            qp0=P[pre + ".0.ln.weight"], qp1=P[pre + ".0.ln.bias"], S=self.S[i], Cseg=Ci,
+                            act_src=self.act[i - 1])
+                wd = self.w[f"down{i - 1}.W"]
+                dxn = self.scr_dxn[:self.M[i - 1] * Ci]
+                self._gemm(b, pre + ":dgrad", "NONE", "DOWN_DGRAD", A=cur, B=wd["t"], C=dxn, M=self.M[i], N=4 * Ci, K=Co,
+                           lda=Co, ldb=wd["ld"], ldc=Ci, S=self.S[i], Cseg=Ci, act_src=self.act[i - 1])
+                nxt = other[:self.M[i - 1] * Ci]
+                self._op(b, pre + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
+                         _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
+                         _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
+                other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
+                cur = nxt
+        # stem
+        C0, k = dims[0], cfg.stem_k
+        ds = self.scr_dd[:self.M[0] * C0]
+        self._op(b, "stem:ln2.bwd", lib.mpmae_ln_bwd, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
+                 _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, _p(ds), 0,
+                 _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
+        da1 = self.scr_dxn[:self.Mfull * C0]
+        self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
+                 _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full))
+        dc1 = other[:self.Mfull * C0]
+        self._op(b, "stem:ln1.bwd", lib.mpmae_ln_bwd, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
+                 _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
+                 _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
+                 _p(self.act_full))
+        self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,
+                    Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,
+                    db=Gd["encoder.initial_conv.0.bias"], vis=self.vis, inv=self.inv, keep=self.keep, L=L, S=self.p,
+                    Cseg=cfg.in_chans, grid=self.grid, H=cfg.img_size)
+
+    # ------------------------------------------------------------------ execution
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _run(self, ops, stream):
+        for name, fn, args in ops:
+            err = fn(*args, stream)
+            if err != 0:
+                raise _lib.HipLibraryError(f"{name}: hipError {err}")
+
+    def set_inputs(self, imgs_dict, noise):
+        """Copy a (cropped) batch and the mask noise into the engine's static device buffers."""
+        for k, dst in self.inp.items():
+            dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
+        self.noise.copy_(noise, non_blocking=True)
+
+    def forward(self, loss_scale: float = 1.0):
+        st = self._stream()
+        self.stats.zero_()
+        self._run(self.fwd_ops, st)
+        err = self.lib.mpmae_loss_finalize(self._fin_args[0], self._fin_args[1], self._fin_args[2], float(loss_scale),
+                                           *self._fin_args[3:7], None, st)
+        _lib.check(err, "loss_finalize")
+        self._loss_scale = float(loss_scale)
+
+    def backward(self, zero_grad: bool = True):
+        st = self._stream()
+        if zero_grad:
+            self.gflat.zero_()
+        # d(total)/d(log_vars) and the per-modality coefficients (second finalize pass adds dlog_vars)
+        err = self.lib.mpmae_loss_finalize(self._fin_args[0], self._fin_args[1], self._fin_args[2], self._loss_scale,
+                                           *self._fin_args[3:7], self._fin_args[7], st)
+        _lib.check(err, "loss_finalize(bwd)")
+        self._run(self.bwd_ops, st)
+
+    def optimizer_step(self, lr: float, weight_decay: float = 0.05, beta1: float = 0.9, beta2: float = 0.95,
+                       eps: float = 1e-8, grad_scale: float = 1.0):
+        self.step_count += 1
+        t = self.step_count
+        self.hp_host[0] = lr
+        self.hp_host[1] = 1.0 / (1.0 - beta1 ** t)
+        self.hp_host[2] = 1.0 / math.sqrt(1.0 - beta2 ** t)
+        self.hp_host[3] = grad_scale
+        self.hp.copy_(self.hp_host, non_blocking=True)
+        err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
+                                   beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), self._stream())
+        _lib.check(err, "adamw")
+
+    def grad_norm(self):
+        self.gnorm2.zero_()
+        _lib.check(self.lib.mpmae_sumsq(_p(self.gflat), self.n_params, _p(self.gnorm2), self._stream()), "sumsq")
+        return self.gnorm2.sqrt()
+
+    # ------------------------------------------------------------------ results (reference shapes)
+    def preds(self):
+        """dict modality -> prediction in the reference's shapes ([N, p*p*C, h, w] / [N, K])."""
+        N, L, g = self.N, self.L, self.grid
+        out = OrderedDict()
+        for om in self.cfg.out_mods:
+            c = self.head_cols[om.name]
+            if om.kind.startswith("pix"):
+                v = self.pred_pix[:, c:c + om.head_out].reshape(N, L, om.head_out)
+                out[om.name] = v.permute(0, 2, 1).reshape(N, om.head_out, g, g)
+            else:
+                out[om.name] = self.pred_img[:, c:c + om.head_out]
+        return out
+
+    def dense_map(self, rows, Cc, stage):
+        """Scatter compacted stage rows [M, C] to the reference's dense [N, C, G, G] map (tests)."""
+        N, keep, S, g = self.N, self.keep, self.S[stage], self.grid
+        x = rows.float().reshape(N, keep, S, S, Cc)
+        out = torch.zeros(N, g, S, g, S, Cc, device=rows.device)
+        vis = self.vis.view(N, keep).long()
+        py, px = vis // g, vis % g
+        n_idx = torch.arange(N, device=rows.device)[:, None].expand(N, keep)
+        out[n_idx, py, :, px, :, :] = x.permute(0, 1, 2, 3, 4)
+        return out.reshape(N, g * S, g * S, Cc).permute(0, 3, 1, 2)
