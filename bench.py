@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""Benchmark of the MP-MAE pretraining micro-step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = FCMAE forward + 12 losses + backward + gradient all-reduce (N > 1) + AdamW on one
+synthetic batch (256 tiles of 12x56x56 per GPU, all_mod atto, bf16 activations / fp32 master
+weights), inputs resident in HBM. Rank 0 prints ONE JSON line: whole-job images/sec, plus
+  "roofline":     achieved vs peak HBM GB/s of the dominant kernel, timed live with HIP events
+                  on the launch stream (algorithmic bytes per launch / average launch duration);
+  "cpu_baseline": the CPU oracle (oracle/mpmae_ref.py, the parity checker) timed on the host
+                  cores on a bounded sample of the same workload. It is a reported baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mmearth_train_amd import MODALITIES as M  # noqa: E402
+from mmearth_train_amd.config import make_cfg  # noqa: E402
+from mmearth_train_amd.engine import Engine  # noqa: E402
+from mmearth_train_amd.synth import make_inputs, make_state_dict  # noqa: E402
+from mmearth_train_amd import dist as mdist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+STEP_ROOFLINE_US = {            # sum over layers of max(t_MFMA, t_HBM) at bs256
+    ("convnextv2_atto", 56, "all_mod"): 764.0,
+    ("convnextv2_atto", 56, "pix_mod"): 759.0,
+    ("convnextv2_tiny", 112, "all_mod"): 2699.0,
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch size")
+    ap.add_argument("--model", default="convnextv2_atto")
+    ap.add_argument("--img", type=int, default=56)
+    ap.add_argument("--patch", type=int, default=8)
+    ap.add_argument("--subset", default="all_mod")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--profile-names", action="store_true", help="per-launch (by op name) time table to stderr")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel-kind time table to stderr")
+    return ap.parse_args()
+
+
+def per_kernel_times(eng, reps=3, by_name=False):
+    """Eager pass with HIP events (torch.cuda.Event on the launch stream) around every launch."""
+    stream = torch.cuda.current_stream()
+    acc = {}
+    fa = eng._fin_args
+    for _ in range(reps):
+        eng.stats.zero_()
+        eng.gflat.zero_()
+        evs = []
+        st = eng._stream()
+        for phase, ops in (("fwd", eng.fwd_ops), ("bwd", eng.bwd_ops)):
+            if phase == "bwd":   # loss finalisation between the two programs (untimed, 1 tiny block)
+                assert eng.lib.mpmae_loss_finalize(fa[0], fa[1], fa[2], 1.0, *fa[3:7], fa[7], st) == 0
+            for name, fn, args, meta in ops:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                err = fn(*args, st)
+                e1.record(stream)
+                assert err == 0, (name, err)
+                evs.append((dict(meta, name=name), e0, e1))
+        torch.cuda.synchronize()
+        for meta, e0, e1 in evs:
+            d = acc.setdefault(meta["kind"] if not by_name else meta["name"], dict(ms=0.0, n=0, bytes=0, flops=0))
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+            d["bytes"] += meta["bytes"]
+            d["flops"] += meta["flops"]
+    return acc
+
+
+def cpu_baseline(cfg, batch, steps):
+    """Oracle (CPU restatement, kind 'port') forward+backward+AdamW on the host cores."""
+    from oracle import mpmae_ref as O
+    ncores = min(os.cpu_count(), 16)       # more threads only add contention on these small ops
+    torch.set_num_threads(ncores)
+    sd = make_state_dict(cfg, seed=0)
+    inputs, noise = make_inputs(cfg, batch, seed=1000)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    mom = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in sd.items()}
+
+    def one(t):
+        for p in params.values():
+            p.grad = None
+        out = O.forward(params, inputs, noise, cfg)
+        out[0].backward()
+        with torch.no_grad():
+            for k, p in params.items():
+                if p.grad is None:
+                    continue
+                new, m, v = O.adamw_step(p, p.grad, mom[k][0], mom[k][1], t, 1e-4)
+                p.copy_(new)
+                mom[k] = (m, v)
+
+    one(1)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i + 2)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=round(batch / dt, 2), unit="images/sec", cores=ncores, kind="port",
+                sample=f"{cfg.name} {cfg.img_size}/{cfg.patch_size} {len(cfg.out_mods)}-modality step, "
+                       f"batch {batch}, 1 warm-up + {steps} timed fp32 steps of oracle/mpmae_ref.py "
+                       f"(fwd+bwd+AdamW), {dt * 1e3:.0f} ms/step")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        mdist.init(backend="nccl", local_rank=local_rank)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
+    eng = Engine(cfg, a.batch, dtype=a.dtype, device=dev)
+    eng.load_state_dict(make_state_dict(cfg, seed=0))
+    inputs, noise = make_inputs(cfg, a.batch, seed=1000 + rank)
+    eng.set_inputs(inputs, noise)
+    torch.cuda.synchronize()
+    trainer = mdist.StepRunner(eng, world_size=world, use_graph=not a.no_graph, lr=1e-4)
+
+    for _ in range(a.warmup):
+        trainer.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        mdist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    elapsed = mdist.max_over_ranks(elapsed) if world > 1 else elapsed
+    loss = float(eng.total.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = a.batch * world * a.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # --- roofline of the dominant kernel: live per-launch HIP-event timing ---
+        acc = per_kernel_times(eng)
+        tot = sum(d["ms"] for d in acc.values())
+        dom_kind, dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = dom["ms"] / dom["n"]
+        avg_bytes = dom["bytes"] / dom["n"]
+        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        if a.profile_ops:
+            for k, d in sorted(acc.items(), key=lambda kv: -kv[1]["ms"]):
+                gbs = d["bytes"] / max(d["ms"], 1e-9) / 1e6
+                tfs = d["flops"] / max(d["ms"], 1e-9) / 1e9
+                print(f"{k:36s} {d['ms'] / 3:9.3f} ms/step {d['n'] // 3:4d} launches "
+                      f"{gbs:8.0f} GB/s {tfs:8.1f} TFLOP/s  {100 * d['ms'] / tot:5.1f}%", file=sys.stderr)
+        if a.profile_names:
+            byn = per_kernel_times(eng, by_name=True)
+            for k, d in sorted(byn.items(), key=lambda kv: -kv[1]["ms"])[:70]:
+                gbs = d["bytes"] / max(d["ms"], 1e-9) / 1e6
+                tfs = d["flops"] / max(d["ms"], 1e-9) / 1e9
+                print(f"{k:58s} {d['ms'] / 3 * 1e3:9.1f} us {gbs:8.0f} GB/s {tfs:8.1f} TF/s", file=sys.stderr)
+        key = (a.model, a.img, a.subset)
+        step_roof = STEP_ROOFLINE_US.get(key)
+        roof = dict(bound="hbm", kernel=dom_kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    kernel_avg_us=round(avg_ms * 1e3, 2), kernel_launches_per_step=dom["n"] // 3,
+                    kernel_share_of_step=round(dom["ms"] / tot, 3))
+        if step_roof and a.batch == 256:
+            roof["step_roofline_us"] = step_roof
+            roof["step_frac"] = round(step_roof / (ms_per_step * 1e3), 4)
+        out = dict(metric="pretrain images/sec (12x56x56 S2, bs256/GPU)" if a.img == 56 else "pretrain images/sec",
+                   value=round(value, 1), unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(ms_per_step, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype="bf16" if a.dtype == "bf16" else "f32", data="synthetic",
+                   config=dict(workload=f"{a.subset} {a.model.replace('convnextv2_', '')} {a.img}x{a.img} patch{a.patch} "
+                                        f"mask0.6 uncertainty loss, fwd+loss+bwd+allreduce+AdamW",
+                               per_gpu_batch=a.batch, global_batch=a.batch * world,
+                               parallelism=f"dp{world}", graph=trainer.graph_mode, final_loss=round(loss, 4)),
+                   roofline=roof)
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_batch, a.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        mdist.barrier()
+        mdist.shutdown()
+
+
+if __name__ == "__main__":
+    main()

@@ -161,10 +161,10 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
   if (dt == 0) {
-    (void)hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
     hipLaunchKernelGGL(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), *a);
   } else {
-    (void)hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
     hipLaunchKernelGGL(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
   }
   RET();
@@ -177,10 +177,10 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
   if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
   dim3 g(nblocks, cdiv(a->C, a->CC));
   if (dt == 0) {
-    (void)hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
     hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), *a);
   } else {
-    (void)hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
     hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
   }
   RET();

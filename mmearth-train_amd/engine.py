@@ -305,8 +305,10 @@ class Engine:
         self.prep_n, self.prep_max = len(descs), mx
 
     # ------------------------------------------------------------------ op helpers
-    def _op(self, lst, name, fn, *args):
-        lst.append((name, fn, args))
+    def _op(self, lst, name, fn, *args, kind=None, nbytes=0, flops=0):
+        """Append one C-ABI launch; `kind` names the kernel, nbytes/flops are its ALGORITHMIC
+        traffic (operands read once + results written once) and work, for the roofline report."""
+        lst.append((name, fn, args, dict(kind=kind or fn.__name__, bytes=int(nbytes), flops=int(flops))))
 
     def _gemm(self, lst, name, pro, epi, **kw):
         a = _lib.GemmArgs()
@@ -315,7 +317,14 @@ class Engine:
         if not kw.get("rpg"):
             a.rpg = max(int(a.M), 1)
         self._keepalive.append(a)
-        self._op(lst, name, self.lib.mpmae_gemm, self.dt, PRO[pro], EPI[epi], C.byref(a))
+        esz = 4 if self.dt == F32 else 2
+        M_, N_, K_ = int(a.M), int(a.N), int(a.K)
+        a_bytes = M_ * K_ * esz * (2 if pro == "GRN_BWD" else 1)
+        if pro == "IM2COL3":
+            a_bytes = M_ * int(a.Cseg) * 4           # each visible pixel's channels read once
+        c_bytes = M_ * N_ * esz * (2 if epi in ("RESID", "DZ_STATS") else 1)
+        self._op(lst, name, self.lib.mpmae_gemm, self.dt, PRO[pro], EPI[epi], C.byref(a),
+                 kind=f"gemm<{pro},{epi}>", nbytes=a_bytes + c_bytes + N_ * K_ * esz, flops=2 * M_ * N_ * K_)
 
     def _wgrad(self, lst, name, ppro, qpro, **kw):
         a = _lib.WgradArgs()
@@ -326,7 +335,12 @@ class Engine:
         tiles = ((a.Nn + 63) // 64) * ((a.Kk + 63) // 64)
         splits = max(1, min((1024 + tiles - 1) // tiles, (a.M + 255) // 256))
         self._keepalive.append(a)
-        self._op(lst, name, self.lib.mpmae_wgrad, self.dt, PRO[ppro], PRO[qpro], C.byref(a), splits)
+        esz = 4 if self.dt == F32 else 2
+        M_, N_, K_ = int(a.M), int(a.Nn), int(a.Kk)
+        p_bytes = M_ * N_ * esz * (2 if ppro == "GRN_BWD" else 1)
+        q_bytes = M_ * int(a.Cseg) * 4 if qpro == "IM2COL3" else M_ * K_ * esz
+        self._op(lst, name, self.lib.mpmae_wgrad, self.dt, PRO[ppro], PRO[qpro], C.byref(a), splits,
+                 kind=f"wgrad<{ppro},{qpro}>", nbytes=p_bytes + q_bytes + N_ * K_ * 4, flops=2 * M_ * N_ * K_)
 
     def _geom(self, stage):
         g = _lib.Geom()
@@ -366,7 +380,10 @@ class Engine:
         act = self.act[blk["stage"]] if blk["sparse"] else None
         a.act = act.data_ptr() if act is not None else 0
         self._keepalive.append(a)
-        self._op(lst, name, self.lib.mpmae_dwconv7_fwd, self.dt, C.byref(a))
+        esz = 4 if self.dt == F32 else 2
+        mc = blk["M"] * blk["C"]
+        self._op(lst, name, self.lib.mpmae_dwconv7_fwd, self.dt, C.byref(a), kind="dwconv7",
+                 nbytes=mc * esz * (3 if add is not None else 2), flops=2 * 49 * mc)
 
     def _block_names(self, blk):
         pre, sp = blk["prefix"], blk["sparse"]
@@ -564,7 +581,8 @@ class Engine:
         a.ntiles_total = self.N * ts * ts
         a.act = act.data_ptr() if act is not None else 0
         self._keepalive.append(a)
-        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024)
+        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024, kind="dwconv7_wgrad",
+                 nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
         self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
 
     def _build_backward(self):
@@ -666,7 +684,7 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _run(self, ops, stream):
-        for name, fn, args in ops:
+        for name, fn, args, _ in ops:
             err = fn(*args, stream)
             if err != 0:
                 raise _lib.HipLibraryError(f"{name}: hipError {err}")
@@ -699,11 +717,18 @@ class Engine:
     def optimizer_step(self, lr: float, weight_decay: float = 0.05, beta1: float = 0.9, beta2: float = 0.95,
                        eps: float = 1e-8, grad_scale: float = 1.0):
         self.step_count += 1
-        t = self.step_count
+        self.set_hyper(lr, self.step_count, beta1, beta2, grad_scale)
+        self.launch_adamw(weight_decay, beta1, beta2, eps)
+
+    def set_hyper(self, lr, t, beta1=0.9, beta2=0.95, grad_scale=1.0):
+        """Fill the pinned hyper-parameter record {lr, 1/(1-b1^t), 1/sqrt(1-b2^t), grad_scale};
+        launch_adamw's (graph-capturable) H2D copy picks it up."""
         self.hp_host[0] = lr
         self.hp_host[1] = 1.0 / (1.0 - beta1 ** t)
         self.hp_host[2] = 1.0 / math.sqrt(1.0 - beta2 ** t)
         self.hp_host[3] = grad_scale
+
+    def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8):
         self.hp.copy_(self.hp_host, non_blocking=True)
         err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                    beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), self._stream())
