@@ -164,6 +164,16 @@ int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G
 int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv,
                            const float* gamma, int G, int H, float* coef, float* dgamma,
                            float* dbeta, mpmae_stream_t stream);
+/* element-wise GRN application z = gelu(h)*(1+gamma*Nx) + beta and its backward
+ * dh = (dz*(1+gamma*Nx) + coef*gelu(h)) * gelu'(h) (in place over dz), and the column statistics
+ * they need (mode 0: s0 += sum gelu(h)^2; mode 1: s0 += sum dz, s1 += sum dz*gelu(h)), per group
+ * of rpg rows (sparse_norm_layers.py:24-33; norm_layers.py:41-44 and their autograd). */
+int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const float* beta, int M,
+                    int H, int rpg, const uint8_t* act, mpmae_stream_t stream);
+int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, const float* coef,
+                        int M, int H, int rpg, mpmae_stream_t stream);
+int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M,
+                   int H, int rpg, mpmae_stream_t stream);
 /* MinkowskiDepthwiseConvolution 7x7 (convnextv2_sparse.py:37-39) / dense depthwise 7x7 pad 3
  * (convnextv2.py:27-29): forward, data gradient (flip = 1, add = upstream residual gradient),
  * weight + bias gradient. `args` are HOST pointers. */

@@ -109,6 +109,9 @@ SYMBOLS = {
     "mpmae_grn_fwd_finalize": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_grn_bwd_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p],
+    "mpmae_grn_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
+    "mpmae_grn_bwd_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_dwconv7_fwd": [c_int, P(DwArgs), c_void_p],
     "mpmae_dwconv7_wgrad": [c_int, P(DwWgArgs), c_int, c_void_p],
     "mpmae_dwstride_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

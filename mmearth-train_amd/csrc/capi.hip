@@ -5,6 +5,13 @@
 #include "dwconv.cuh"
 #include "misc.cuh"
 #include "loss.cuh"
+#include "gemm_fast.cuh"
+#include "dwconv2.cuh"
+
+static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
+static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
+static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a);
+static int launch_wgrad_fast(WgradP a, hipStream_t st);
 
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 #define RET() return (int)hipGetLastError()
@@ -55,6 +62,7 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
     return (int)hipGetLastError();                                                 \
   }
   GEMM_CASE(PRO_NONE, EPI_STORE)
+  GEMM_CASE(PRO_NONE, EPI_RESID)
   GEMM_CASE(PRO_NONE, EPI_SCATTER_ROWS)
   GEMM_CASE(PRO_NONE, EPI_DZ_STATS)
   GEMM_CASE(PRO_NONE, EPI_DOWN_DGRAD)
@@ -73,6 +81,7 @@ int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
+  if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
   return dt == 0 ? launch_gemm<float>(pro, epi, *args, S_(s)) : launch_gemm<bf16_t>(pro, epi, *args, S_(s));
 }
 
@@ -97,6 +106,7 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
 
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits, mpmae_stream_t s) {
   if (!args || splits < 1) return (int)hipErrorInvalidValue;
+  if (wgrad_fast_ok(dt, ppro, qpro, *args)) return launch_wgrad_fast(*args, S_(s));
   WgradP a = *args;
   int rps = cdiv(a.M, splits);
   rps = cdiv(rps, WBM) * WBM;
@@ -155,8 +165,30 @@ static size_t dw_lds_bytes(int CC, bool wgrad) {
   return b;
 }
 
+template <typename T>
+static void launch_dw_v2(const MpmaeDwArgs& a, hipStream_t st) {
+  const bool c40 = (a.C % 40 == 0);
+  const int cc = c40 ? 40 : 32;
+  dim3 g(a.g.N * a.tiles_side * a.tiles_side, cdiv(a.C, cc));
+  if (c40) hipLaunchKernelGGL((dwconv7_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
+  else hipLaunchKernelGGL((dwconv7_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
+}
+
+template <typename T>
+static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
+  const bool c40 = (a.C % 40 == 0);
+  const int cc = c40 ? 40 : 32;
+  dim3 g(nblocks, cdiv(a.C, cc));
+  if (c40) hipLaunchKernelGGL((dwconv7_wgrad_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
+  else hipLaunchKernelGGL((dwconv7_wgrad_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
+}
+
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if ((a->C & 7) == 0) {
+    if (dt == 0) launch_dw_v2<float>(*a, S_(s)); else launch_dw_v2<bf16_t>(*a, S_(s));
+    RET();
+  }
   const size_t lds = dw_lds_bytes(a->CC, false);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
@@ -172,6 +204,11 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if ((a->C & 7) == 0) {
+    if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
+    if (dt == 0) launch_dwwg_v2<float>(*a, nblocks, S_(s)); else launch_dwwg_v2<bf16_t>(*a, nblocks, S_(s));
+    RET();
+  }
   const size_t lds = dw_lds_bytes(a->CC, true);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
@@ -274,3 +311,82 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t s) {
   RET();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// fast bf16 paths (compute-shaped layers) and the element-wise GRN kernels
+// ------------------------------------------------------------------------------------------
+static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
+  if (dt != 1 || pro != PRO_NONE) return false;
+  if (epi != EPI_STORE && epi != EPI_RESID) return false;
+  if ((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) return false;
+  if (epi == EPI_RESID && (a.ldr & 7)) return false;
+  return true;
+}
+
+static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
+  if (epi != EPI_RESID) a.R = nullptr;
+  const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
+  if (w64 < w128) {
+    constexpr int BN = 64;
+    const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
+    dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<BN>, g, dim3(256), lds, st, a);
+  } else {
+    constexpr int BN = 128;
+    const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
+    static bool once = false;
+    if (!once) {
+      if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return (int)hipGetLastError();
+      once = true;
+    }
+    dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel<BN>, g, dim3(256), lds, st, a);
+  }
+  return (int)hipGetLastError();
+}
+
+static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
+  return dt == 1 && ppro == PRO_NONE && qpro == PRO_NONE && !((a.ldp | a.ldq | a.Nn | a.Kk) & 1);
+}
+
+static int launch_wgrad_fast(WgradP a, hipStream_t st) {
+  const int tiles = cdiv(a.Nn, 128) * cdiv(a.Kk, 128);
+  int splits = cdiv(1024, tiles);
+  const int maxs = cdiv(a.M, 64);
+  if (splits > maxs) splits = maxs;
+  if (splits < 1) splits = 1;
+  int rps = cdiv(cdiv(a.M, splits), TBM) * TBM;
+  a.rows_per_split = rps;
+  splits = cdiv(a.M, rps);
+  dim3 g(cdiv(a.Nn, 128), cdiv(a.Kk, 128), splits);
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const float* beta, int M, int H, int rpg,
+                    const uint8_t* act, mpmae_stream_t s) {
+  if (H & 7) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)M * H / 8, 256, 8192);
+  if (dt == 0) hipLaunchKernelGGL(grn_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)h, (float*)z, scale, beta, M, H, rpg, act);
+  else hipLaunchKernelGGL(grn_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)h, (bf16_t*)z, scale, beta, M, H, rpg, act);
+  RET();
+}
+
+int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, const float* coef, int M, int H, int rpg,
+                        mpmae_stream_t s) {
+  if (H & 7) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)M * H / 8, 256, 8192);
+  if (dt == 0) hipLaunchKernelGGL(grn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)dz, (const float*)h, scale, coef, M, H, rpg);
+  else hipLaunchKernelGGL(grn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)dz, (const bf16_t*)h, scale, coef, M, H, rpg);
+  RET();
+}
+
+int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M, int H, int rpg,
+                   mpmae_stream_t s) {
+  const int rpb = (rpg < M) ? rpg : 256;
+  dim3 g(cdiv(H, 64), cdiv(M, rpb));
+  if (dt == 0) hipLaunchKernelGGL(colstats_kernel<float>, g, dim3(256), 0, S_(s), (const float*)h, (const float*)dz, mode, s0, s1, M, H, rpg, rpb);
+  else hipLaunchKernelGGL(colstats_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)h, (const bf16_t*)dz, mode, s0, s1, M, H, rpg, rpb);
+  RET();
+}

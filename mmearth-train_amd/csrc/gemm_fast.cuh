@@ -1,0 +1,335 @@
+// bf16 MFMA GEMMs for the compute-shaped layers (decoder block, stages 2-3, heads, proj).
+//
+//   gemm_nt_bf16 :  C[M,N] = A[M,K] * B[N,K]^T + bias  (+ R)      128 x BN x 64 tiles, 4 waves
+//   gemm_tn_bf16 :  dW[n,k] += sum_m P[m,n] * Q[m,k]  (+ db)       128 x 128 output tiles, split-M
+//
+// Design (MI355X_MICROARCH / cdna_hip_programming guides): 64-wide waves each own a 64x64 (or
+// 64x32) register tile of 16x16x32 bf16 MFMAs; operands are staged global -> registers -> LDS with
+// 16-byte accesses, LDS rows padded to 144 B so every ds_read_b128 fragment read is
+// conflict-free; the next K-slab's global loads are in flight while the current slab's MFMAs
+// run (one barrier per slab, two LDS buffers); the epilogue goes back through LDS so that global
+// stores are 16 B per lane along rows. The TN (weight-gradient) form transposes while loading:
+// lanes read 4-byte pairs along the contiguous n/k axis for 8 consecutive m and repack them into
+// m-contiguous 16-byte LDS rows.
+#pragma once
+#include "gemm.cuh"
+
+constexpr int FBM = 128, FBK = 64, FLD = FBK + 8;   // LDS row = 72 bf16 = 144 B
+
+__device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nrows, int ld, int k, int K) {
+  // 8 bf16 at (row, k..k+7); zero beyond the matrix. K % 8 == 0 is required by the dispatcher.
+  if (row < nrows && k < K) return *reinterpret_cast<const uint4*>(base + (size_t)row * ld + k);
+  return make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
+  constexpr int NJ = BN / 32;                 // 16-wide N tiles per wave (wave tile 64 x BN/2)
+  constexpr int BCH = BN * 8 / 256;           // 16-byte chunks of the B tile per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][128][72]
+  bf16_t* Bs = As + 2 * FBM * FLD;                                  // [2][BN][72]
+  float* stage = reinterpret_cast<float*>(smem_raw);                // [128][68] fp32 (epilogue)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * FBM, n0 = blockIdx.y * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[BCH];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      ra[i] = ldg16_guard(A, m0 + (c >> 3), p.M, p.lda, k0 + (c & 7) * 8, p.K);
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int c = tid + 256 * i;
+      rb[i] = ldg16_guard(B, n0 + (c >> 3), p.N, p.ldb, k0 + (c & 7) * 8, p.K);
+    }
+  };
+  auto lstore = [&](int buf) {
+    bf16_t* a = As + buf * FBM * FLD;
+    bf16_t* b = Bs + buf * BN * FLD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      *reinterpret_cast<uint4*>(a + (c >> 3) * FLD + (c & 7) * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BCH; ++i) {
+      const int c = tid + 256 * i;
+      *reinterpret_cast<uint4*>(b + (c >> 3) * FLD + (c & 7) * 8) = rb[i];
+    }
+  };
+
+  const int nk = (p.K + FBK - 1) / FBK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) gload((kt + 1) * FBK);
+    const bf16_t* a = As + (kt & 1) * FBM * FLD + (wm * 64 + lr) * FLD + lg * 8;
+    const bf16_t* b = Bs + (kt & 1) * BN * FLD + (wn * (BN / 2) + lr) * FLD + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < FBK; ks += 32) {
+      bf16x8_t af[4], bfr[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * FLD + ks));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * FLD + ks));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) lstore((kt + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> LDS (fp32, 64 columns at a time) -> 16-byte global stores ----
+  constexpr int SLD = 68;
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+  const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
+  constexpr int HALVES = BN / 64;
+#pragma unroll
+  for (int half = 0; half < HALVES; ++half) {
+    const bool mine = (HALVES == 1) || (wn == half);
+    if (mine) {
+      const int cbase = (HALVES == 1) ? wn * 32 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            stage[(wm * 64 + i * 16 + lg * 4 + r) * SLD + cbase + j * 16 + lr] = acc[i][j][r];
+    }
+    __syncthreads();
+    {
+      const int row = tid >> 1, cseg = (tid & 1) * 32;
+      const int grow = m0 + row;
+      const bool live = !p.act || (grow < p.M && p.act[grow]);
+      if (grow < p.M) {
+#pragma unroll
+        for (int v8 = 0; v8 < 4; ++v8) {
+          const int col = n0 + half * 64 + cseg + v8 * 8;
+          if (col < p.N) {              // N % 8 == 0 guaranteed by the dispatcher
+            float v[8];
+            const float4 s0 = *reinterpret_cast<const float4*>(stage + row * SLD + cseg + v8 * 8);
+            const float4 s1 = *reinterpret_cast<const float4*>(stage + row * SLD + cseg + v8 * 8 + 4);
+            v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+            if (p.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += p.bias[col + e];
+            }
+            if (R) {
+              float rr[8];
+              ld8<bf16_t>(R + (size_t)grow * p.ldr + col, rr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += rr[e];
+            }
+            if (!live) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            }
+            st8<bf16_t>(C + (size_t)grow * p.ldc + col, v);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =====================================================================================
+// TN form (weight gradients): dW[n*sn + k*sk] += sum_m P[m,n]*Q[m,k]; db[n] += sum_m P[m,n]
+// =====================================================================================
+constexpr int TBM = 32, TLD = TBM + 8;     // reduction slab of 32 rows; LDS row = 40 bf16 = 80 B
+
+__device__ __forceinline__ void tn_load_pack(const bf16_t* X, int ld, int ncols, int mbase, int mend, int col,
+                                             uint4& lo, uint4& hi) {
+  // reads the 2-column pair (col, col+1) for 8 consecutive rows; returns the two m-contiguous
+  // 8-element vectors (column col -> lo, column col+1 -> hi)
+  uint32_t w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = mbase + i;
+    w[i] = (m < mend && col < ncols) ? *reinterpret_cast<const uint32_t*>(X + (size_t)m * ld + col) : 0u;
+  }
+  lo.x = __byte_perm(w[0], w[1], 0x5410); hi.x = __byte_perm(w[0], w[1], 0x7632);
+  lo.y = __byte_perm(w[2], w[3], 0x5410); hi.y = __byte_perm(w[2], w[3], 0x7632);
+  lo.z = __byte_perm(w[4], w[5], 0x5410); hi.z = __byte_perm(w[4], w[5], 0x7632);
+  lo.w = __byte_perm(w[6], w[7], 0x5410); hi.w = __byte_perm(w[6], w[7], 0x7632);
+}
+
+__device__ __forceinline__ float bf16x8_sum(const uint4& v) {
+  return __uint_as_float(v.x << 16) + __uint_as_float(v.x & 0xffff0000u) + __uint_as_float(v.y << 16) +
+         __uint_as_float(v.y & 0xffff0000u) + __uint_as_float(v.z << 16) + __uint_as_float(v.z & 0xffff0000u) +
+         __uint_as_float(v.w << 16) + __uint_as_float(v.w & 0xffff0000u);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const WgradP w) {
+  __shared__ __attribute__((aligned(16))) bf16_t Pt[2][128 * TLD];
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[2][128 * TLD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+  const int mbeg = blockIdx.z * w.rows_per_split;
+  const int mend = min(w.M, mbeg + w.rows_per_split);
+  const bf16_t* P = reinterpret_cast<const bf16_t*>(w.P);
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(w.Q);
+  const bool do_db = (w.db != nullptr) && (blockIdx.y == 0);
+
+  // loader mapping: column pair cp = tid % 64 (columns 2cp, 2cp+1), row octet ro = tid / 64 (rows 8ro..8ro+7)
+  const int cp = (tid & 63) * 2, ro = (tid >> 6) * 8;
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float db0 = 0.f, db1 = 0.f;
+  uint4 plo, phi, qlo, qhi;
+
+  auto gload = [&](int mb) {
+    tn_load_pack(P, w.ldp, w.Nn, mb + ro, mend, n0 + cp, plo, phi);
+    tn_load_pack(Q, w.ldq, w.Kk, mb + ro, mend, k0 + cp, qlo, qhi);
+  };
+  auto lstore = [&](int buf) {
+    *reinterpret_cast<uint4*>(&Pt[buf][cp * TLD + ro]) = plo;
+    *reinterpret_cast<uint4*>(&Pt[buf][(cp + 1) * TLD + ro]) = phi;
+    *reinterpret_cast<uint4*>(&Qt[buf][cp * TLD + ro]) = qlo;
+    *reinterpret_cast<uint4*>(&Qt[buf][(cp + 1) * TLD + ro]) = qhi;
+    if (do_db) { db0 += bf16x8_sum(plo); db1 += bf16x8_sum(phi); }
+  };
+
+  const int nsl = (mend - mbeg + TBM - 1) / TBM;
+  if (nsl > 0) {
+    gload(mbeg);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsl; ++s) {
+    if (s + 1 < nsl) gload(mbeg + (s + 1) * TBM);
+    const bf16_t* a = &Pt[s & 1][(wn * 64 + lr) * TLD + lg * 8];
+    const bf16_t* b = &Qt[s & 1][(wk * 64 + lr) * TLD + lg * 8];
+    bf16x8_t af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * TLD));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * TLD));
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (s + 1 < nsl) lstore((s + 1) & 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + lg * 4 + r;
+        const int k = k0 + wk * 64 + j * 16 + lr;
+        if (n < w.Nn && k < w.Kk) {
+          const float v = acc[i][j][r];
+          if (v != 0.f) atomicAdd(w.dW + (size_t)n * w.sn + (size_t)k * w.sk, v);
+        }
+      }
+  if (do_db) {
+    // the 4 row-octet groups hold partial sums for the same column pair: reduce through LDS
+    float* red = reinterpret_cast<float*>(&Pt[0][0]);
+    red[(tid >> 6) * 128 + cp] = db0;
+    red[(tid >> 6) * 128 + cp + 1] = db1;
+    __syncthreads();
+    if (tid < 128 && n0 + tid < w.Nn) {
+      const float v = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
+      if (v != 0.f) atomicAdd(w.db + n0 + tid, v);
+    }
+  }
+}
+
+// =====================================================================================
+// Element-wise GRN application and its backward over [M, H] rows (materialised operands of
+// the compute-shaped GEMMs), and column statistics.
+// =====================================================================================
+// z = gelu(h) * scale[g, j] + beta[j]   (inactive rows -> 0)
+template <typename T>
+__global__ __launch_bounds__(256) void grn_apply_kernel(const T* __restrict__ h, T* __restrict__ z,
+                                                        const float* __restrict__ scale, const float* __restrict__ beta,
+                                                        int M, int H, int rpg, const uint8_t* __restrict__ act) {
+  const size_t nvec = (size_t)M * H / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / H, j = e - (size_t)m * H;
+    float v[8];
+    ld8<T>(h + e, v);
+    const bool live = !act || act[m];
+    const float* sc = scale + (size_t)(m / rpg) * H + j;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = live ? gelu_f(v[q]) * sc[q] + beta[j + q] : 0.f;
+    st8<T>(z + e, v);
+  }
+}
+
+// dh = (dz*scale[g,j] + coef[g,j]*gelu(h)) * gelu'(h), written over dz
+template <typename T>
+__global__ __launch_bounds__(256) void grn_bwd_apply_kernel(T* __restrict__ dz, const T* __restrict__ h,
+                                                            const float* __restrict__ scale, const float* __restrict__ coef,
+                                                            int M, int H, int rpg) {
+  const size_t nvec = (size_t)M * H / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / H, j = e - (size_t)m * H;
+    float d[8], hv[8];
+    ld8<T>(dz + e, d);
+    ld8<T>(h + e, hv);
+    const size_t gi = (size_t)(m / rpg) * H + j;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = (d[q] * scale[gi + q] + coef[gi + q] * gelu_f(hv[q])) * gelu_grad_f(hv[q]);
+    st8<T>(dz + e, d);
+  }
+}
+
+// column statistics over row groups: mode 0: s0[g,j] += sum gelu(h)^2
+//                                   mode 1: s0[g,j] += sum dz ; s1[g,j] += sum dz*gelu(h)
+// grid = (ceil(H/64), row chunks); block 256 = 64 columns x 4 row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ h, const T* __restrict__ dz, int mode,
+                                                       float* __restrict__ s0, float* __restrict__ s1, int M, int H,
+                                                       int rpg, int rows_per_block) {
+  __shared__ float red[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int mb = blockIdx.y * rows_per_block, me = min(M, mb + rows_per_block);
+  int g = mb / rpg;            // rows_per_block never straddles a group boundary when rpg < M
+  float a0 = 0.f, a1 = 0.f;
+  if (c < H) {
+    for (int m = mb + rl; m < me; m += 4) {
+      const float gv = gelu_f(ldf<T>(h + (size_t)m * H + c));
+      if (mode == 0) a0 += gv * gv;
+      else { const float d = ldf<T>(dz + (size_t)m * H + c); a0 += d; a1 += d * gv; }
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = a0;
+  red[1][rl][threadIdx.x & 63] = a1;
+  __syncthreads();
+  if (rl == 0 && c < H) {
+    const int l = threadIdx.x & 63;
+    atomicAdd(s0 + (size_t)g * H + c, red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
+    if (mode == 1) atomicAdd(s1 + (size_t)g * H + c, red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+  }
+}

@@ -39,7 +39,7 @@ def _rup(x, m):
 
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
-                 track_activity: bool = True, mask_ratio=None):
+                 track_activity: bool = True, mask_ratio=None, block_mode=None):
         if cfg.decoder_depth != 1:
             raise NotImplementedError("decoder_depth != 1")
         self.lib = _lib.load()
@@ -49,6 +49,7 @@ class Engine:
         self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
         self.device = torch.device(device)
         self.track_activity = track_activity
+        self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.L = cfg.num_patches
         self.grid = cfg.grid
         self.keep = cfg.len_keep(mask_ratio)
@@ -397,7 +398,103 @@ class Engine:
             gg=pre + ".grn.gamma", gb=pre + ".grn.beta")
 
     # ------------------------------------------------------------------ forward program
+    # ---- block programs -------------------------------------------------------------------
+    # "fused": LN-affine / GELU / GRN are applied in the GEMM prologues (fewest bytes; used for the
+    #          bandwidth-bound stages with small C).
+    # "mat"  : xn, z = GRN(GELU(h)) and dh are materialised by row-wise kernels so that every GEMM is
+    #          a plain NT / TN product on the fast bf16 MFMA kernels (compute-shaped layers).
+    def _block_mode(self, blk):
+        if self.block_mode_override:
+            return self.block_mode_override
+        return "mat" if (self.dt == BF16 and blk["C"] >= 128) else "fused"
+
     def _block_fwd(self, lst, blk, x):
+        blk["mode"] = self._block_mode(blk)
+        return (self._block_fwd_mat if blk["mode"] == "mat" else self._block_fwd_fused)(lst, blk, x)
+
+    def _block_bwd(self, lst, blk, dout, dx):
+        return (self._block_bwd_mat if blk["mode"] == "mat" else self._block_bwd_fused)(lst, blk, dout, dx)
+
+    def _block_fwd_mat(self, lst, blk, x):
+        P, lib, dt = self.params, self.lib, self.dt
+        nm = self._block_names(blk)
+        M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        rpg = M if blk["sparse"] else self.L
+        eps = 1e-6 if blk["sparse"] else 1e-4
+        tag = blk["prefix"]
+        esz = 4 if dt == F32 else 2
+        blk["x"] = x
+        if "xn" not in blk:
+            blk["xn"] = self._t(M, Cc)
+            blk["z"] = self._t(M, H)
+        self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
+        self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]), _p(blk["xn"]),
+                 _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, 1e-6, M, Cc, _p(act), kind="ln_fwd", nbytes=3 * M * Cc * esz)
+        self._gemm(lst, tag + ":pw1", "NONE", "STORE", A=blk["xn"], B=self.w[tag + ".W1"]["t"], bias=P[nm["b1"]],
+                   C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
+        self._op(lst, tag + ":grn.stats", lib.mpmae_colstats, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H, rpg,
+                 kind="colstats", nbytes=M * H * esz)
+        self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
+                 _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
+        self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
+                 _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
+        self._gemm(lst, tag + ":pw2", "NONE", "RESID", A=blk["z"], B=self.w[tag + ".W2"]["t"], bias=P[nm["b2"]],
+                   C=blk["out"], R=x, M=M, N=Cc, K=H, lda=H, ldb=self.w[tag + ".W2"]["ld"], ldc=Cc, ldr=Cc, act=act)
+        return blk["out"]
+
+    def _block_bwd_mat(self, lst, blk, dout, dx):
+        P, Gd, lib, dt = self.params, self.grads, self.lib, self.dt
+        nm = self._block_names(blk)
+        M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        rpg = M if blk["sparse"] else self.L
+        tag = blk["prefix"]
+        esz = 4 if dt == F32 else 2
+        dz = self.scr_dz[:M * H]
+        dxn = self.scr_dxn[:M * Cc]
+        dd = self.scr_dd[:M * Cc]
+        w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
+        self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
+                   ldb=w2t["ld"], ldc=H)
+        self._wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
+                    dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
+        self._op(lst, tag + ":grn.bstats", lib.mpmae_colstats, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]), _p(blk["S1"]),
+                 M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
+        self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
+                 _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
+        self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
+                 _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
+        self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
+                   ldb=w1t["ld"], ldc=Cc)
+        self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
+                    dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
+        self._op(lst, tag + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+                 _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
+                 _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
+        self._dw_bwd(lst, blk, dd, dout, dx)
+
+    def _dw_bwd(self, lst, blk, dd, dout, dx):
+        """depthwise conv backward: weight/bias gradient, then data gradient (+ residual dout)."""
+        lib, dt = self.lib, self.dt
+        M, Cc = blk["M"], blk["C"]
+        act = self.act[blk["stage"]] if blk["sparse"] else None
+        tag = blk["prefix"]
+        w, gw, b, gb, (skh, skw, sc) = self._dw_weight(blk)
+        TP, ts, CC = self._dw_tiling(blk["stage"], Cc)
+        a = _lib.DwWgArgs()
+        a.x, a.dd, a.dw, a.db = blk["x"].data_ptr(), dd.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        a.s_kh, a.s_kw, a.s_c = skh, skw, sc
+        a.g = self._geom(blk["stage"])
+        a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
+        a.ntiles_total = self.N * ts * ts
+        a.act = act.data_ptr() if act is not None else 0
+        self._keepalive.append(a)
+        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024, kind="dwconv7_wgrad",
+                 nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
+        self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
+
+    def _block_fwd_fused(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
         nm = self._block_names(blk)
         M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
@@ -544,7 +641,7 @@ class Engine:
                           _p(self.total), _p(self.coef), _p(glv))
 
     # ------------------------------------------------------------------ backward program
-    def _block_bwd(self, lst, blk, dout, dx):
+    def _block_bwd_fused(self, lst, blk, dout, dx):
         """dout: gradient w.r.t. the block output [M,C]; writes the gradient w.r.t. its input into dx."""
         P, Gd, lib, dt = self.params, self.grads, self.lib, self.dt
         nm = self._block_names(blk)
@@ -570,20 +667,7 @@ class Engine:
         self._op(lst, tag + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                  _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                  _p(act))
-        # depthwise conv: weight grad, then data grad (+ residual)
-        w, gw, b, gb, (skh, skw, sc) = self._dw_weight(blk)
-        TP, ts, CC = self._dw_tiling(blk["stage"], Cc)
-        a = _lib.DwWgArgs()
-        a.x, a.dd, a.dw, a.db = blk["x"].data_ptr(), dd.data_ptr(), gw.data_ptr(), gb.data_ptr()
-        a.s_kh, a.s_kw, a.s_c = skh, skw, sc
-        a.g = self._geom(blk["stage"])
-        a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
-        a.ntiles_total = self.N * ts * ts
-        a.act = act.data_ptr() if act is not None else 0
-        self._keepalive.append(a)
-        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024, kind="dwconv7_wgrad",
-                 nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
-        self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
+        self._dw_bwd(lst, blk, dd, dout, dx)
 
     def _build_backward(self):
         cfg, P, Gd, lib, dt, N, L, D = self.cfg, self.params, self.grads, self.lib, self.dt, self.N, self.L, self.D

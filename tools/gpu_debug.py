@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--case", default="allmod_atto_56")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--block-mode", default=None)
     a = ap.parse_args()
     c = CASES[a.case]
     cfg = case_cfg(c)
@@ -31,7 +32,7 @@ def main():
     loss, pred, mask, loss_dict, log_vars, weighted = O.forward(p, inputs, noise, cfg, taps=taps)
     loss.backward()
 
-    eng = Engine(cfg, c["N"], dtype=a.dtype)
+    eng = Engine(cfg, c["N"], dtype=a.dtype, block_mode=a.block_mode)
     eng.load_state_dict(sd)
     eng.set_inputs(inputs, noise)
     eng.forward()
