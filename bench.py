@@ -62,7 +62,6 @@ def per_kernel_times(eng, reps=3, by_name=False):
     """Eager pass with HIP events (torch.cuda.Event on the launch stream) around every launch."""
     stream = torch.cuda.current_stream()
     acc = {}
-    fa = eng._fin_args
     for _ in range(reps):
         eng.stats.zero_()
         eng.gflat.zero_()
@@ -70,7 +69,7 @@ def per_kernel_times(eng, reps=3, by_name=False):
         st = eng._stream()
         for phase, ops in (("fwd", eng.fwd_ops), ("bwd", eng.bwd_ops)):
             if phase == "bwd":   # loss finalisation between the two programs (untimed, 1 tiny block)
-                assert eng.lib.mpmae_loss_finalize(fa[0], fa[1], fa[2], 1.0, *fa[3:7], fa[7], st) == 0
+                eng.finalize_loss(st, True, 1.0)
             for name, fn, args, meta in ops:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)

@@ -11,6 +11,10 @@
  * optimizer step (main_pretrain.py:312-320). Each entry point below names the reference
  * operation(s) it stands in for.
  *
+ * Reductions. Large reductions (weight gradients, column statistics, LayerNorm parameter
+ * gradients) are two-stage: per-block partial slabs in caller-provided scratch `ws`, then an
+ * in-library second-stage kernel; global float atomics are avoided (they serialise on MI355X).
+ *
  * Conventions
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
  *   - `dt` selects the activation storage type: 0 = fp32 (exact-f32 MFMA, parity mode),
@@ -61,6 +65,7 @@ typedef struct MpmaeGemmArgs {
   const int* vis; const int* inv; const uint8_t* act; const uint8_t* act_src;
   int keep, L, S, Cseg, grid;
   int H;
+  float* ws; size_t ws_floats;       /* scratch for per-block statistic slabs (stats epilogues) */
 } MpmaeGemmArgs;
 
 /* dW[n*sn + k*sk] += sum_m proP(P)[m,n]*proQ(Q)[m,k] ; db[n] += sum_m proP(P)[m,n] */
@@ -72,6 +77,7 @@ typedef struct MpmaeWgradArgs {
   int rpg; int rows_per_split;
   const int* vis; const int* inv; const uint8_t* act_src;
   int keep, L, S, Cseg, grid, H;
+  float* ws; size_t ws_floats;       /* scratch for the per-split partial slabs */
 } MpmaeWgradArgs;
 
 typedef struct MpmaeDwArgs {
@@ -90,6 +96,7 @@ typedef struct MpmaeDwWgArgs {
   MpmaeGeom g;
   int C, CC, TP, tiles_side, ntiles_total;
   const uint8_t* act;
+  float* ws; size_t ws_floats;       /* scratch for the per-block partial slabs */
 } MpmaeDwWgArgs;
 
 typedef struct MpmaePrepDesc {
@@ -156,7 +163,7 @@ int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const 
 int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat,
                  const float* rstd, const float* gamma, const float* beta, int act, void* dx,
                  int accumulate, float* dgamma, float* dbeta, int M, int C, const uint8_t* rowmask,
-                 mpmae_stream_t stream);
+                 float* ws, size_t ws_floats, mpmae_stream_t stream);
 /* MinkowskiGRN (batch-global, eps 1e-6; sparse_norm_layers.py:24-33) and GRN (per-sample,
  * eps 1e-4; norm_layers.py:41-44): statistics finalisation for G groups of H channels. */
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx,
@@ -173,7 +180,7 @@ int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const fl
 int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, const float* coef,
                         int M, int H, int rpg, mpmae_stream_t stream);
 int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M,
-                   int H, int rpg, mpmae_stream_t stream);
+                   int H, int rpg, float* ws, size_t ws_floats, mpmae_stream_t stream);
 /* MinkowskiDepthwiseConvolution 7x7 (convnextv2_sparse.py:37-39) / dense depthwise 7x7 pad 3
  * (convnextv2.py:27-29): forward, data gradient (flip = 1, add = upstream residual gradient),
  * weight + bias gradient. `args` are HOST pointers. */
@@ -200,7 +207,9 @@ int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* args, int npatc
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* args, int npatches,
                        mpmae_stream_t stream);
 int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* args, mpmae_stream_t stream);
-int mpmae_loss_finalize(const float* acc, const float* log_vars, int T, float loss_scale,
+/* acc: per-sample partial {sum, count} pairs laid out [T][N][2] (written by the loss kernels:
+ * args->acc points at modality t's [N][2] block). */
+int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale,
                         float* losses, float* weighted, float* total, float* coef,
                         float* dlog_vars, mpmae_stream_t stream);
 

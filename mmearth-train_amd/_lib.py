@@ -27,7 +27,8 @@ class GemmArgs(C.Structure):
                 ("s0", c_void_p), ("s1", c_void_p),
                 ("vis", c_void_p), ("inv", c_void_p), ("act", c_void_p), ("act_src", c_void_p),
                 ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
-                ("H", c_int)]
+                ("H", c_int),
+                ("ws", c_void_p), ("ws_floats", c_size_t)]
 
 
 class WgradArgs(C.Structure):
@@ -38,7 +39,8 @@ class WgradArgs(C.Structure):
                 ("rpg", c_int), ("rows_per_split", c_int),
                 ("vis", c_void_p), ("inv", c_void_p), ("act_src", c_void_p),
                 ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
-                ("H", c_int)]
+                ("H", c_int),
+                ("ws", c_void_p), ("ws_floats", c_size_t)]
 
 
 class DwArgs(C.Structure):
@@ -56,7 +58,8 @@ class DwWgArgs(C.Structure):
                 ("g", Geom),
                 ("C", c_int), ("CC", c_int), ("TP", c_int), ("tiles_side", c_int),
                 ("ntiles_total", c_int),
-                ("act", c_void_p)]
+                ("act", c_void_p),
+                ("ws", c_void_p), ("ws_floats", c_size_t)]
 
 
 class PrepDesc(C.Structure):
@@ -105,13 +108,14 @@ SYMBOLS = {
     "mpmae_ln_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                      c_int, c_int, c_void_p, c_void_p],
     "mpmae_ln_bwd": [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+                     c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
     "mpmae_grn_fwd_finalize": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_grn_bwd_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p],
     "mpmae_grn_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "mpmae_grn_bwd_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
+                       c_void_p],
     "mpmae_dwconv7_fwd": [c_int, P(DwArgs), c_void_p],
     "mpmae_dwconv7_wgrad": [c_int, P(DwWgArgs), c_int, c_void_p],
     "mpmae_dwstride_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -124,7 +128,7 @@ SYMBOLS = {
     "mpmae_loss_pix_cont": [c_int, c_int, P(PixContArgs), c_int, c_void_p],
     "mpmae_loss_pix_cat": [c_int, c_int, P(PixCatArgs), c_int, c_void_p],
     "mpmae_loss_img": [c_int, c_int, P(ImgArgs), c_void_p],
-    "mpmae_loss_finalize": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+    "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p],

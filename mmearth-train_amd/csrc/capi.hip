@@ -7,6 +7,7 @@
 #include "loss.cuh"
 #include "gemm_fast.cuh"
 #include "dwconv2.cuh"
+#include "dwconv3.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -22,6 +23,18 @@ static inline int grid1d(long long total, int per_block = 256, int cap = 16384) 
   if (g < 1) g = 1;
   if (g > cap) g = cap;
   return (int)g;
+}
+
+// second stage of the two-stage reductions (see reduce_partials_kernel in misc.cuh)
+static void launch_reduce(int mode, const float* part, int P, int W, float* out, float* out2, int a, int b, int c, int d,
+                          hipStream_t st) {
+  int R = P / 32;
+  if (R < 1) R = 1;
+  if (R > 16) R = 16;
+  dim3 g(cdiv(W, 256), R);
+  if (mode == 0) hipLaunchKernelGGL(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else if (mode == 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else hipLaunchKernelGGL(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
 }
 
 // C linkage comes from the declarations in include/mpmae_hip.h
@@ -82,7 +95,21 @@ int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
   if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
-  return dt == 0 ? launch_gemm<float>(pro, epi, *args, S_(s)) : launch_gemm<bf16_t>(pro, epi, *args, S_(s));
+  const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);
+  const bool single = stats && args->rpg >= args->M;
+  const int mblocks = cdiv(args->M, GBM);
+  if (single) {
+    const size_t need = (size_t)mblocks * args->N * (epi == EPI_DZ_STATS ? 2 : 1);
+    if (!args->ws || args->ws_floats < need) return (int)hipErrorInvalidValue;
+  }
+  int err = dt == 0 ? launch_gemm<float>(pro, epi, *args, S_(s)) : launch_gemm<bf16_t>(pro, epi, *args, S_(s));
+  if (err == 0 && single) {
+    launch_reduce(0, args->ws, mblocks, args->N, args->s0, nullptr, 0, 0, 0, 0, S_(s));
+    if (epi == EPI_DZ_STATS)
+      launch_reduce(0, args->ws + (size_t)mblocks * args->N, mblocks, args->N, args->s1, nullptr, 0, 0, 0, 0, S_(s));
+    err = (int)hipGetLastError();
+  }
+  return err;
 }
 
 template <typename T>
@@ -108,11 +135,19 @@ int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int spli
   if (!args || splits < 1) return (int)hipErrorInvalidValue;
   if (wgrad_fast_ok(dt, ppro, qpro, *args)) return launch_wgrad_fast(*args, S_(s));
   WgradP a = *args;
+  const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
+  if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
+  const int maxs = (int)(a.ws_floats / per);
+  if (splits > maxs) splits = maxs;
   int rps = cdiv(a.M, splits);
   rps = cdiv(rps, WBM) * WBM;
   a.rows_per_split = rps;
   splits = cdiv(a.M, rps);
-  return dt == 0 ? launch_wgrad<float>(ppro, qpro, a, splits, S_(s)) : launch_wgrad<bf16_t>(ppro, qpro, a, splits, S_(s));
+  int err = dt == 0 ? launch_wgrad<float>(ppro, qpro, a, splits, S_(s)) : launch_wgrad<bf16_t>(ppro, qpro, a, splits, S_(s));
+  if (err) return err;
+  launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, S_(s));
+  if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, S_(s));
+  return (int)hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -134,15 +169,25 @@ int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const 
 
 int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
                  const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
-                 int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
+                 int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, mpmae_stream_t s) {
   if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
-  const int blocks = grid1d((long long)M * 64, 256, 1024);
+  int blocks = grid1d((long long)M * 64, 256, 1024);
+  if (!ws || ws_floats < (size_t)2 * C) return (int)hipErrorInvalidValue;
+  if ((size_t)blocks * 2 * C > ws_floats) blocks = (int)(ws_floats / ((size_t)2 * C));
   if (dt == 0)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
-                       (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, dgamma, dbeta, M, C, rowmask);
+                       (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);
   else
     hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dy, dy_div, dy_scale,
-                       (const bf16_t*)xhat, rstd, gamma, beta, act, (bf16_t*)dx, accumulate, dgamma, dbeta, M, C, rowmask);
+                       (const bf16_t*)xhat, rstd, gamma, beta, act, (bf16_t*)dx, accumulate, ws, M, C, rowmask);
+  // slabs are [block][2][C]: e = n*C + k with n = 0 -> dgamma[k], n = 1 -> dbeta[k] (MODE 1, b = dbeta - dgamma)
+  if (dgamma && dbeta) {
+    const long long delta = dbeta - dgamma;
+    if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+    launch_reduce(1, ws, blocks, 2 * C, dgamma, nullptr, C, (int)delta, 1, 0, S_(s));
+  } else if (dgamma || dbeta) {
+    return (int)hipErrorInvalidValue;     // both or neither
+  }
   RET();
 }
 
@@ -185,6 +230,12 @@ static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
+    dim3 g(a->g.N * a->tiles_side * a->tiles_side, a->C / 8);
+    if (dt == 0) hipLaunchKernelGGL(dwconv7_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
+    else hipLaunchKernelGGL(dwconv7_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
+    RET();
+  }
   if ((a->C & 7) == 0) {
     if (dt == 0) launch_dw_v2<float>(*a, S_(s)); else launch_dw_v2<bf16_t>(*a, S_(s));
     RET();
@@ -204,9 +255,24 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
-  if ((a->C & 7) == 0) {
+  if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
+    const size_t per = (size_t)50 * a->C;
+    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
     if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
+    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
+    dim3 g(nblocks, a->C / 8);
+    if (dt == 0) hipLaunchKernelGGL(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
+    else hipLaunchKernelGGL(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
+    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
+    RET();
+  }
+  if ((a->C & 7) == 0) {
+    const size_t per = (size_t)50 * a->C;
+    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
+    if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
+    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
     if (dt == 0) launch_dwwg_v2<float>(*a, nblocks, S_(s)); else launch_dwwg_v2<bf16_t>(*a, nblocks, S_(s));
+    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }
   const size_t lds = dw_lds_bytes(a->CC, true);
@@ -235,7 +301,7 @@ int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const 
 int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w, float* dw, float* db,
                        int Mout, int C, int S, int k, const uint8_t* act_in, mpmae_stream_t s) {
   if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
-  const int g = 1024;
+  const int g = 128;     // few blocks: each ends with C*(k*k+1) float atomics
   if (dt == 0) hipLaunchKernelGGL(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, dw, db, Mout, C, S, k, act_in);
   else hipLaunchKernelGGL(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, dw, db, Mout, C, S, k, act_in);
   RET();
@@ -264,7 +330,7 @@ int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mp
 
 // ------------------------------------------------------------------------------------------
 int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
-  dim3 g(npatches), b(256);
+  dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
   if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
                  else hipLaunchKernelGGL((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
   else { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
@@ -274,7 +340,7 @@ int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches
 
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* a, int npatches, mpmae_stream_t s) {
   if (a->K > 16) return (int)hipErrorInvalidValue;
-  dim3 g(npatches), b(256);
+  dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
   if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
                  else hipLaunchKernelGGL((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
   else { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
@@ -291,10 +357,10 @@ int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* a, mpmae_stream_t s) {
   RET();
 }
 
-int mpmae_loss_finalize(const float* acc, const float* log_vars, int T, float loss_scale, float* losses, float* weighted,
-                        float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
+int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
+                        float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
   if (T > 64) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, log_vars, T, loss_scale, losses, weighted,
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
                      total, coef, dlog_vars);
   RET();
 }
@@ -351,16 +417,21 @@ static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
 }
 
 static int launch_wgrad_fast(WgradP a, hipStream_t st) {
+  const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
+  if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
   const int tiles = cdiv(a.Nn, 128) * cdiv(a.Kk, 128);
-  int splits = cdiv(1024, tiles);
-  const int maxs = cdiv(a.M, 64);
+  int splits = cdiv(768, tiles);                 // ~3 workgroups per CU
+  const int maxs = cdiv(a.M, 256);               // at least 8 reduction slabs per workgroup
   if (splits > maxs) splits = maxs;
+  if (splits > (int)(a.ws_floats / per)) splits = (int)(a.ws_floats / per);
   if (splits < 1) splits = 1;
   int rps = cdiv(cdiv(a.M, splits), TBM) * TBM;
   a.rows_per_split = rps;
   splits = cdiv(a.M, rps);
   dim3 g(cdiv(a.Nn, 128), cdiv(a.Kk, 128), splits);
   hipLaunchKernelGGL(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
+  launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
+  if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
   return (int)hipGetLastError();
 }
 
@@ -383,10 +454,21 @@ int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, con
 }
 
 int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M, int H, int rpg,
-                   mpmae_stream_t s) {
-  const int rpb = (rpg < M) ? rpg : 256;
-  dim3 g(cdiv(H, 64), cdiv(M, rpb));
-  if (dt == 0) hipLaunchKernelGGL(colstats_kernel<float>, g, dim3(256), 0, S_(s), (const float*)h, (const float*)dz, mode, s0, s1, M, H, rpg, rpb);
-  else hipLaunchKernelGGL(colstats_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)h, (const bf16_t*)dz, mode, s0, s1, M, H, rpg, rpb);
+                   float* ws, size_t ws_floats, mpmae_stream_t s) {
+  const bool single = rpg >= M;
+  int rpb = single ? 256 : rpg;
+  if (single) {
+    const size_t per = (size_t)H * (mode == 1 ? 2 : 1);
+    if (!ws || ws_floats < per) return (int)hipErrorInvalidValue;
+    while ((size_t)cdiv(M, rpb) * per > ws_floats) rpb *= 2;
+  } else if (M % rpg != 0) return (int)hipErrorInvalidValue;
+  const int rblocks = cdiv(M, rpb);
+  dim3 g(cdiv(H, 64), rblocks);
+  if (dt == 0) hipLaunchKernelGGL(colstats_kernel<float>, g, dim3(256), 0, S_(s), (const float*)h, (const float*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
+  else hipLaunchKernelGGL(colstats_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)h, (const bf16_t*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
+  if (single) {
+    launch_reduce(0, ws, rblocks, H, s0, nullptr, 0, 0, 0, 0, S_(s));
+    if (mode == 1) launch_reduce(0, ws + (size_t)rblocks * H, rblocks, H, s1, nullptr, 0, 0, 0, 0, S_(s));
+  }
   RET();
 }

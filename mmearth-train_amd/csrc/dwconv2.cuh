@@ -163,15 +163,10 @@ __global__ __launch_bounds__(8 * CC) void dwconv7_wgrad_v2_kernel(const DwWgP q)
     atomicAdd(&red[49 * CC + tc], adb);
   }
   __syncthreads();
+  // slab ws[blockIdx.x][50][C]: taps 0..48 then the bias row; reduced by mpmae_dwconv7_wgrad
+  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
   for (int i = threadIdx.x; i < 50 * CC; i += 8 * CC) {
     const int k = i / CC, cc = i - k * CC;
-    if (c0 + cc >= C) continue;
-    const float v = red[i];
-    if (k < 49) {
-      const int kh = k / 7, kw = k - kh * 7;
-      atomicAdd(q.dw + kh * q.s_kh + kw * q.s_kw + (c0 + cc) * q.s_c, v);
-    } else if (q.db) {
-      atomicAdd(q.db + c0 + cc, v);
-    }
+    if (c0 + cc < C) slab[k * C + c0 + cc] = red[i];
   }
 }

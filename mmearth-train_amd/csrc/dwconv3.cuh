@@ -1,0 +1,196 @@
+// Wave-granular submanifold depthwise 7x7 (forward / data gradient / weight gradient), v3.
+//
+// rocprof showed the block-granular kernels (dwconv.cuh, dwconv2.cuh) latency-bound: every
+// workgroup walks a chain of dependent global round trips (visibility table -> halo rows ->
+// compute) behind workgroup barriers, with 2 workgroups resident per CU. Here the unit of work
+// is ONE 64-lane wave: an 8x8 tile of stage points x 8 channels. A wave keeps its 14x14x8 halo
+// (raw storage type) and its 49x8 weights in ~5 KB of LDS, needs no cross-wave barrier, and uses
+// <= 64 VGPRs, so 24-32 independent waves per CU overlap each other's memory latency.
+//   lane = ox*8 + c8 : column ox of the tile, channel c8 of the chunk; 8 outputs (oy) per lane.
+// Inactive sites hold zeros in every row tensor (all producers write zeros there), so the halo
+// gather does not consult the activity map; only the outputs are masked.
+#pragma once
+#include "dwconv.cuh"
+
+constexpr int W64_MAXL = 256;   // patches per sample supported by the LDS copy of the inverse table
+
+template <typename T>
+__device__ __forceinline__ void w64_setup(const Geom& g, int n, int ty0, int tx0, int* invs, int* rowtab) {
+  const int lane = threadIdx.x;
+  const int L = g.grid * g.grid;
+  if (g.inv) { for (int i = lane; i < L; i += 64) invs[i] = g.inv[n * L + i]; }
+  else { for (int i = lane; i < L; i += 64) invs[i] = i; }
+  __syncthreads();
+  const int ext = g.grid * g.S, P = g.S * g.S;
+  for (int i = lane; i < DW_HP; i += 64) {
+    const int hy = i / DW_HALO, hx = i - hy * DW_HALO;
+    const int gy = ty0 - 3 + hy, gx = tx0 - 3 + hx;
+    int r = -1;
+    if (gy >= 0 && gx >= 0 && gy < ext && gx < ext) {
+      const int py = gy / g.S, px = gx / g.S;
+      const int slot = invs[py * g.grid + px];
+      if (slot >= 0) r = (n * g.keep + slot) * P + (gy - py * g.S) * g.S + (gx - px * g.S);
+    }
+    rowtab[i] = r;
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int* rowtab, T* tile, int C, int c0) {
+  // 8 channels of one halo point = one 16-byte (bf16) / 32-byte (fp32) vector per lane
+  for (int i = threadIdx.x; i < DW_HP; i += 64) {
+    const int r = rowtab[i];
+    if (sizeof(T) == 2) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (r >= 0) v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + c0);
+      *reinterpret_cast<uint4*>(tile + i * 8) = v;
+    } else {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+      if (r >= 0) {
+        a = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
+        b = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0 + 4);
+      }
+      *reinterpret_cast<float4*>(tile + i * 8) = a;
+      *reinterpret_cast<float4*>(tile + i * 8 + 4) = b;
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64, 8) void dwconv7_w64_kernel(const DwP p) {
+  __shared__ __attribute__((aligned(16))) T tile[DW_HP * 8];
+  __shared__ float wl[49 * 8];
+  __shared__ int rowtab[DW_HP];
+  __shared__ int invs[W64_MAXL];
+  const int lane = threadIdx.x;
+  const int tps = p.tiles_side * p.tiles_side;
+  const int n = blockIdx.x / tps, t = blockIdx.x - n * tps;
+  const int tyi = t / p.tiles_side, txi = t - tyi * p.tiles_side;
+  const int TS = p.TP * p.g.S;
+  const int ty0 = tyi * TS, tx0 = txi * TS;
+  const int c0 = blockIdx.y * 8;
+  const int C = p.C;
+
+  w64_setup<T>(p.g, n, ty0, tx0, invs, rowtab);
+  {
+    const int oy = lane >> 3, oxx = lane & 7;
+    const int valid = (oy < TS && oxx < TS && rowtab[(oy + 3) * DW_HALO + oxx + 3] >= 0);
+    if (!__any(valid)) return;
+  }
+  w64_load_tile<T>(reinterpret_cast<const T*>(p.x), rowtab, tile, C, c0);
+  for (int i = lane; i < 49 * 8; i += 64) {
+    int k = i >> 3;
+    const int c = i & 7;
+    int kh = k / 7, kw = k - kh * 7;
+    if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
+    wl[i] = p.w[kh * p.s_kh + kw * p.s_kw + (c0 + c) * p.s_c];
+  }
+  __syncthreads();
+
+  const int ox = lane >> 3, c8 = lane & 7;
+  const int c = c0 + c8;
+  float acc[8];
+  const float b = p.bias ? p.bias[c] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = b;
+#pragma unroll 1                        // rolled: one kx-slab of LDS reads live at a time (54 VGPRs, 8 waves/SIMD);
+  for (int kx = 0; kx < 7; ++kx) {      // fully unrolled, hipcc hoists all 98 reads first (156 VGPRs, 3 waves/SIMD)
+    float w7[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) w7[ky] = wl[(ky * 7 + kx) * 8 + c8];
+#pragma unroll
+    for (int y = 0; y < DW_HALO; ++y) {
+      const float v = ldf<T>(tile + (y * DW_HALO + ox + kx) * 8 + c8);
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        const int ky = y - o;
+        if (ky >= 0 && ky < 7) acc[o] += w7[ky] * v;
+      }
+    }
+  }
+  if (ox >= TS) return;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* add = reinterpret_cast<const T*>(p.add);
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (o < TS) {
+      const int r = rowtab[(o + 3) * DW_HALO + ox + 3];
+      if (r >= 0) {
+        float v = acc[o];
+        if (add) v += ldf<T>(add + (size_t)r * C + c);
+        if (p.act && !p.act[r]) v = 0.f;
+        stf<T>(out + (size_t)r * C + c, v);
+      }
+    }
+  }
+}
+
+// weight / bias gradient, persistent waves: blockIdx.x strides over tiles, blockIdx.y = channel
+// chunk; result slab ws[blockIdx.x][50][C] (taps 0..48, then the bias row).
+template <typename T>
+__global__ __launch_bounds__(64, 5) void dwconv7_wgrad_w64_kernel(const DwWgP q) {
+  __shared__ __attribute__((aligned(16))) T tile[DW_HP * 8];
+  __shared__ int rowtab[DW_HP];
+  __shared__ int invs[W64_MAXL];
+  const int lane = threadIdx.x;
+  const int ox = lane >> 3, c8 = lane & 7;
+  const int C = q.C;
+  const int c0 = blockIdx.y * 8;
+  const int c = c0 + c8;
+  const int TS = q.TP * q.g.S;
+  const int tps = q.tiles_side * q.tiles_side;
+  const T* dd = reinterpret_cast<const T*>(q.dd);
+
+  float adw[49], adb = 0.f;
+#pragma unroll
+  for (int k = 0; k < 49; ++k) adw[k] = 0.f;
+
+  for (int tile_id = blockIdx.x; tile_id < q.ntiles_total; tile_id += gridDim.x) {
+    const int n = tile_id / tps, t = tile_id - n * tps;
+    const int tyi = t / q.tiles_side, txi = t - tyi * q.tiles_side;
+    const int ty0 = tyi * TS, tx0 = txi * TS;
+    __syncthreads();
+    w64_setup<T>(q.g, n, ty0, tx0, invs, rowtab);
+    {
+      const int oy = lane >> 3, oxx = lane & 7;
+      const int valid = (oy < TS && oxx < TS && rowtab[(oy + 3) * DW_HALO + oxx + 3] >= 0);
+      if (!__any(valid)) continue;
+    }
+    w64_load_tile<T>(reinterpret_cast<const T*>(q.x), rowtab, tile, C, c0);
+    float g[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      const int r = (o < TS && ox < TS) ? rowtab[(o + 3) * DW_HALO + ox + 3] : -1;
+      g[o] = (r >= 0) ? ldf<T>(dd + (size_t)r * C + c) : 0.f;
+      adb += g[o];
+    }
+    __syncthreads();
+    int toff = 0;                        // LDS offset made data-dependent on the previous kx-slab's FMAs, so that
+#pragma unroll                           // hipcc cannot hoist all 98 LDS reads above the FMAs (static indices needed
+    for (int kx = 0; kx < 7; ++kx) {     // for the 49 register accumulators forbid rolling this loop)
+      if (kx > 0)
+        asm volatile("" : "+v"(toff) : "v"(adw[kx - 1]), "v"(adw[7 + kx - 1]), "v"(adw[14 + kx - 1]),
+                     "v"(adw[21 + kx - 1]), "v"(adw[28 + kx - 1]), "v"(adw[35 + kx - 1]), "v"(adw[42 + kx - 1]));
+#pragma unroll
+      for (int y = 0; y < DW_HALO; ++y) {
+        const float v = ldf<T>(tile + toff + (y * DW_HALO + ox + kx) * 8 + c8);
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const int ky = y - o;
+          if (ky >= 0 && ky < 7) adw[ky * 7 + kx] += g[o] * v;
+        }
+      }
+    }
+  }
+  // reduce over the 8 columns (lane bits 3..5), lanes 0..7 write the slab
+  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
+#pragma unroll
+  for (int k = 0; k < 49; ++k) {
+    float v = adw[k];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (ox == 0) slab[k * C + c] = v;
+  }
+  adb += __shfl_xor(adb, 8, 64); adb += __shfl_xor(adb, 16, 64); adb += __shfl_xor(adb, 32, 64);
+  if (ox == 0) slab[49 * C + c] = adb;
+}

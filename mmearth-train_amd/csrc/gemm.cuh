@@ -273,17 +273,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
   }
   if constexpr (STATS) {
     __syncthreads();
-    const int ng = grouped ? GMAXG : 1;
-    for (int i = tid; i < ng * GBN; i += 256) {
-      const int gl = i / GBN, c = i - gl * GBN;
-      const int col = n0 + c;
-      const int g = grouped ? (g0 + gl) : 0;
-      if (col < p.N && (!grouped || (size_t)g * p.rpg < (size_t)p.M)) {
-        const float a = sacc[0][gl][c];
-        if (a != 0.f) atomicAdd(p.s0 + (size_t)g * p.N + col, a);
-        if constexpr (EPI == EPI_DZ_STATS) {
-          const float b = sacc[1][gl][c];
-          if (b != 0.f) atomicAdd(p.s1 + (size_t)g * p.N + col, b);
+    if (!grouped) {
+      // single statistics group: this block's column partials go to its own slab row
+      // ws[blockIdx.x][N] (second stat: + gridDim.x*N); mpmae_gemm reduces the slabs afterwards.
+      for (int c = tid; c < GBN; c += 256) {
+        const int col = n0 + c;
+        if (col < p.N) {
+          p.ws[(size_t)blockIdx.x * p.N + col] = sacc[0][0][c];
+          if constexpr (EPI == EPI_DZ_STATS) p.ws[((size_t)gridDim.x + blockIdx.x) * p.N + col] = sacc[1][0][c];
+        }
+      }
+    } else {
+      for (int i = tid; i < GMAXG * GBN; i += 256) {
+        const int gl = i / GBN, c = i - gl * GBN;
+        const int col = n0 + c;
+        const int g = g0 + gl;
+        if (col < p.N && (size_t)g * p.rpg < (size_t)p.M) {
+          const float a = sacc[0][gl][c];
+          if (a != 0.f) atomicAdd(p.s0 + (size_t)g * p.N + col, a);
+          if constexpr (EPI == EPI_DZ_STATS) {
+            const float b = sacc[1][gl][c];
+            if (b != 0.f) atomicAdd(p.s1 + (size_t)g * p.N + col, b);
+          }
         }
       }
     }
@@ -358,7 +369,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP w) {
     mma_slab<T, 2, 2>(Pt, Qt, LDT, LDT, wn * 32, wk * 32, acc);
   }
 
+  // partial results of this M-split go to its own slab ws[z][Nn*Kk] (+ bias slab); mpmae_wgrad
+  // runs the second-stage reduction into dW / db afterwards (no global atomics).
   const int lr = lane & 15, lg = lane >> 4;
+  float* slab = w.ws + (size_t)blockIdx.z * w.Nn * w.Kk;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -367,10 +381,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP w) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 32 + i * 16 + lg * 4 + r;
         const int k = k0 + wk * 32 + j * 16 + lr;
-        if (n < w.Nn && k < w.Kk) {
-          const float v = acc[i][j][r];
-          if (v != 0.f) atomicAdd(w.dW + (size_t)n * w.sn + (size_t)k * w.sk, v);
-        }
+        if (n < w.Nn && k < w.Kk) slab[(size_t)n * w.Kk + k] = acc[i][j][r];
       }
   if (do_db) {
     if (tid < WBN) dbs[tid] = 0.f;
@@ -378,6 +389,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradP w) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) atomicAdd(&dbs[lc + i], dbacc[i]);
     __syncthreads();
-    if (tid < WBN && n0 + tid < w.Nn && dbs[tid] != 0.f) atomicAdd(w.db + n0 + tid, dbs[tid]);
+    float* dslab = w.ws + (size_t)gridDim.z * w.Nn * w.Kk + (size_t)blockIdx.z * w.Nn;
+    if (tid < WBN && n0 + tid < w.Nn) dslab[n0 + tid] = dbs[tid];
   }
 }

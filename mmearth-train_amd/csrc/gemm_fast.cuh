@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const WgradP w) {
     if (s + 1 < nsl) lstore((s + 1) & 1);
     __syncthreads();
   }
+  float* slab = w.ws + (size_t)blockIdx.z * w.Nn * w.Kk;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -245,10 +246,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const WgradP w) {
       for (int r = 0; r < 4; ++r) {
         const int n = n0 + wn * 64 + i * 16 + lg * 4 + r;
         const int k = k0 + wk * 64 + j * 16 + lr;
-        if (n < w.Nn && k < w.Kk) {
-          const float v = acc[i][j][r];
-          if (v != 0.f) atomicAdd(w.dW + (size_t)n * w.sn + (size_t)k * w.sk, v);
-        }
+        if (n < w.Nn && k < w.Kk) slab[(size_t)n * w.Kk + k] = acc[i][j][r];
       }
   if (do_db) {
     // the 4 row-octet groups hold partial sums for the same column pair: reduce through LDS
@@ -256,10 +254,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const WgradP w) {
     red[(tid >> 6) * 128 + cp] = db0;
     red[(tid >> 6) * 128 + cp + 1] = db1;
     __syncthreads();
-    if (tid < 128 && n0 + tid < w.Nn) {
-      const float v = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
-      if (v != 0.f) atomicAdd(w.db + n0 + tid, v);
-    }
+    float* dslab = w.ws + (size_t)gridDim.z * w.Nn * w.Kk + (size_t)blockIdx.z * w.Nn;
+    if (tid < 128 && n0 + tid < w.Nn) dslab[n0 + tid] = red[tid] + red[128 + tid] + red[256 + tid] + red[384 + tid];
   }
 }
 
@@ -311,7 +307,7 @@ __global__ __launch_bounds__(256) void grn_bwd_apply_kernel(T* __restrict__ dz, 
 template <typename T>
 __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ h, const T* __restrict__ dz, int mode,
                                                        float* __restrict__ s0, float* __restrict__ s1, int M, int H,
-                                                       int rpg, int rows_per_block) {
+                                                       int rpg, int rows_per_block, float* __restrict__ ws) {
   __shared__ float red[2][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int mb = blockIdx.y * rows_per_block, me = min(M, mb + rows_per_block);
@@ -329,7 +325,14 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ h, 
   __syncthreads();
   if (rl == 0 && c < H) {
     const int l = threadIdx.x & 63;
-    atomicAdd(s0 + (size_t)g * H + c, red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l]);
-    if (mode == 1) atomicAdd(s1 + (size_t)g * H + c, red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l]);
+    const float r0 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+    const float r1 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+    if (rpg < M) {                 // one block per (group, column chunk): sole writer
+      s0[(size_t)g * H + c] += r0;
+      if (mode == 1) s1[(size_t)g * H + c] += r1;
+    } else {                       // single group: slab row per row-block, reduced afterwards
+      ws[(size_t)blockIdx.y * H + c] = r0;
+      if (mode == 1) ws[((size_t)gridDim.y + blockIdx.y) * H + c] = r1;
+    }
   }
 }

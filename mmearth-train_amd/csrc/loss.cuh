@@ -17,10 +17,12 @@ __device__ __forceinline__ float nan_to_num0(float t) { return (isnan(t) || isin
 
 typedef MpmaePixContArgs PixContP;
 
+// Forward: one block per SAMPLE looping over its L patches, per-sample partial {sum, count}
+// written to acc[2n], acc[2n+1] (no atomics; loss_finalize sums over samples).
+// Backward: one block per patch.
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x, n = b / q.L, l = b - n * q.L;
+__device__ __forceinline__ void loss_pix_cont_patch(const PixContP& q, int b, float* sh, float& acc_s, float& acc_c) {
+  const int n = b / q.L, l = b - n * q.L;
   const int py = l / q.grid, px = l - py * q.grid;
   const int p = q.p, C = q.C, J = p * p * C;
   const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
@@ -83,17 +85,32 @@ __global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
       const bool counted = !isnan(qv) && qv != 0.f;
       q.patch_l[b] = counted ? lp : 0.f;
       q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
-      if (counted) { atomicAdd(q.acc, qv); atomicAdd(q.acc + 1, 1.f); }
+      if (counted) { acc_s += qv; acc_c += 1.f; }
     }
+  }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
+  __shared__ float sh[4];
+  float as = 0.f, ac = 0.f;
+  if constexpr (BWD) {
+    loss_pix_cont_patch<T, true>(q, blockIdx.x, sh, as, ac);
+  } else {
+    const int n = blockIdx.x;
+    for (int l = 0; l < q.L; ++l) {
+      loss_pix_cont_patch<T, false>(q, n * q.L + l, sh, as, ac);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) { q.acc[2 * n] = as; q.acc[2 * n + 1] = ac; }
   }
 }
 
 typedef MpmaePixCatArgs PixCatP;
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
-  __shared__ float sh[4];
-  const int b = blockIdx.x, n = b / q.L, l = b - n * q.L;
+__device__ __forceinline__ void loss_pix_cat_patch(const PixCatP& q, int b, float& se, float& cnt) {
+  const int n = b / q.L, l = b - n * q.L;
   const int py = l / q.grid, px = l - py * q.grid;
   const int p = q.p, K = q.K, PP = p * p;
   const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
@@ -103,7 +120,6 @@ __global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
     if constexpr (BWD) for (int j = threadIdx.x; j < PP * K; j += blockDim.x) stf<T>(dp + j, 0.f);
     return;
   }
-  float se = 0.f, cnt = 0.f;
   const float k = BWD ? q.coef[0] : 0.f;
   for (int pix = threadIdx.x; pix < PP; pix += blockDim.x) {
     const int ph = pix / p, pw = pix - ph * p;
@@ -125,10 +141,35 @@ __global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
       for (int c = 0; c < K; ++c) stf<T>(dp + pix * K + c, 0.f);
     }
   }
-  if constexpr (!BWD) {
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
+  __shared__ float sh[4];
+  float se = 0.f, cnt = 0.f;
+  if constexpr (BWD) {
+    loss_pix_cat_patch<T, true>(q, blockIdx.x, se, cnt);
+  } else {
+    const int n = blockIdx.x;
+    const int p = q.p, K = q.K, PP = p * p;
+    for (int idx = threadIdx.x; idx < q.L * PP; idx += blockDim.x) {      // all pixels of all patches
+      const int l = idx / PP, pix = idx - l * PP;
+      const int b = n * q.L + l;
+      if (q.mask[b] != 1.f) continue;
+      const int py = l / q.grid, px = l - py * q.grid, ph = pix / p, pw = pix - ph * p;
+      const long long t = q.target[((size_t)n * q.H + py * p + ph) * q.H + px * p + pw];
+      if (t == -1) continue;
+      const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff + pix * K;
+      float z[16], mx = -INFINITY;
+      for (int c = 0; c < K; ++c) { z[c] = ldf<T>(pred + c); mx = fmaxf(mx, z[c]); }
+      float sm = 0.f;
+      for (int c = 0; c < K; ++c) sm += __expf(z[c] - mx);
+      se += mx + __logf(sm) - z[(int)t];
+      cnt += 1.f;
+    }
     se = block_sum256(se, sh);
     cnt = block_sum256(cnt, sh);
-    if (threadIdx.x == 0 && cnt > 0.f) { atomicAdd(q.acc, se); atomicAdd(q.acc + 1, cnt); }
+    if (threadIdx.x == 0) { q.acc[2 * n] = se; q.acc[2 * n + 1] = cnt; }
   }
 }
 
@@ -154,7 +195,7 @@ __global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
     }
     if constexpr (!BWD) {
       se = block_sum256(se, sh); cnt = block_sum256(cnt, sh);
-      if (threadIdx.x == 0 && cnt > 0.f) { atomicAdd(q.acc, se); atomicAdd(q.acc + 1, cnt); }
+      if (threadIdx.x == 0) { q.acc[2 * n] = se; q.acc[2 * n + 1] = cnt; }
     }
     return;
   }
@@ -188,20 +229,23 @@ __global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
     for (int c = threadIdx.x; c < K; c += blockDim.x)
       stf<T>(dp + c, k * (__expf(ldf<T>(pred + c) - lse) - (c == besti ? 1.f : 0.f)));
   } else if (threadIdx.x == 0) {
-    atomicAdd(q.acc, lse - ldf<T>(pred + besti));
-    atomicAdd(q.acc + 1, 1.f);
+    q.acc[2 * n] = lse - ldf<T>(pred + besti);
+    q.acc[2 * n + 1] = 1.f;
   }
 }
 
 // L_i = sum_i / count_i ; uncertainty: w_i = (exp(-s_i) L_i + s_i) [L_i != 0] (custom_loss.py:19-30)
-__global__ void loss_finalize_kernel(const float* __restrict__ acc, const float* __restrict__ log_vars, int Tn,
+// acc layout: [T][N][2] per-sample partial {sum, count}
+__global__ void loss_finalize_kernel(const float* __restrict__ acc, int Nn, const float* __restrict__ log_vars, int Tn,
                                      float loss_scale, float* __restrict__ losses, float* __restrict__ weighted,
                                      float* __restrict__ total, float* __restrict__ coef, float* __restrict__ dlog_vars) {
   __shared__ float w[64];
   const int i = threadIdx.x;
   float wi = 0.f;
   if (i < Tn) {
-    const float Li = acc[2 * i] / acc[2 * i + 1];
+    float ssum = 0.f, scnt = 0.f;
+    for (int n = 0; n < Nn; ++n) { ssum += acc[((size_t)i * Nn + n) * 2]; scnt += acc[((size_t)i * Nn + n) * 2 + 1]; }
+    const float Li = ssum / scnt;
     losses[i] = Li;
     float dLi = 1.f;
     if (log_vars) {
@@ -215,7 +259,7 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, const float*
       wi = Li;
       weighted[i] = Li;
     }
-    coef[i] = loss_scale * dLi / acc[2 * i + 1];
+    coef[i] = loss_scale * dLi / scnt;
   }
   w[i] = wi;
   __syncthreads();

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
                                                      const T* __restrict__ xhat, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      int act, T* __restrict__ dx, int accumulate,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ ws,
                                                      int M, int C, const uint8_t* __restrict__ rowmask) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         if (c < C) {
           const float a = red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane];
           const float b = red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane];
-          if (dgamma) atomicAdd(dgamma + c, a);
-          if (dbeta) atomicAdd(dbeta + c, b);
+          // slab ws[block][2][C]; mpmae_ln_bwd reduces the slabs into dgamma / dbeta
+          ws[((size_t)blockIdx.x * 2 + 0) * C + c] = a;
+          ws[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
         }
       }
       __syncthreads();

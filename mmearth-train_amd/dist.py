@@ -122,9 +122,7 @@ class StepRunner:
         eng = self.eng
         st = eng._stream()
         eng.gflat.zero_()
-        a = eng._fin_args
-        err = eng.lib.mpmae_loss_finalize(a[0], a[1], a[2], 1.0, a[3], a[4], a[5], a[6], a[7], st)
-        assert err == 0
+        eng.finalize_loss(st, True, 1.0)
 
     def _bwd_seg(self, i):
         self.eng._run(self.segments[i], self.eng._stream())

@@ -190,7 +190,7 @@ class Engine:
         self.pooled = self._t(N, D)
         self.dpooled = self._t(N, D)
         T = len(cfg.out_mods)
-        self.n_stats = sum(self._stat_sizes) + 2 * T
+        self.n_stats = sum(self._stat_sizes)
         self.stats = torch.zeros(self.n_stats, dtype=f32, device=dev)
         off = 0
         for blk in self.blocks + [self.dec]:
@@ -198,7 +198,7 @@ class Engine:
             for nm in ("G2", "S0", "S1"):
                 blk[nm] = self.stats[off:off + G * H]
                 off += G * H
-        self.loss_acc = self.stats[off:off + 2 * T]
+        self.loss_acc = torch.zeros(T, N, 2, dtype=f32, device=dev)      # per-sample {sum, count} partials
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
         self.total = torch.zeros(1, dtype=f32, device=dev)
@@ -214,6 +214,9 @@ class Engine:
         self.scr_dxA = self._t(maxMC)
         self.scr_dxB = self._t(maxMC)
         self.dy = self._t(N * L, D)
+        # fp32 scratch for the two-stage reductions (per-block / per-split partial slabs)
+        self.ws_floats = 32 * 1024 * 1024
+        self.ws = torch.empty(self.ws_floats, dtype=f32, device=dev)
 
     def _alloc_block(self, prefix, M, Cc, G, stage, sparse):
         H = 4 * Cc
@@ -306,6 +309,14 @@ class Engine:
         self.prep_n, self.prep_max = len(descs), mx
 
     # ------------------------------------------------------------------ op helpers
+    def _ln_bwd_fn(self, *args):
+        *a, stream = args
+        return self.lib.mpmae_ln_bwd(*a, _p(self.ws), self.ws_floats, stream)
+
+    def _colstats_fn(self, *args):
+        *a, stream = args
+        return self.lib.mpmae_colstats(*a, _p(self.ws), self.ws_floats, stream)
+
     def _op(self, lst, name, fn, *args, kind=None, nbytes=0, flops=0):
         """Append one C-ABI launch; `kind` names the kernel, nbytes/flops are its ALGORITHMIC
         traffic (operands read once + results written once) and work, for the roofline report."""
@@ -317,6 +328,7 @@ class Engine:
             setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
         if not kw.get("rpg"):
             a.rpg = max(int(a.M), 1)
+        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
         self._keepalive.append(a)
         esz = 4 if self.dt == F32 else 2
         M_, N_, K_ = int(a.M), int(a.N), int(a.K)
@@ -334,7 +346,8 @@ class Engine:
         if not kw.get("rpg"):
             a.rpg = max(int(a.M), 1)
         tiles = ((a.Nn + 63) // 64) * ((a.Kk + 63) // 64)
-        splits = max(1, min((1024 + tiles - 1) // tiles, (a.M + 255) // 256))
+        splits = max(1, min((768 + tiles - 1) // tiles, (a.M + 255) // 256))
+        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
         self._keepalive.append(a)
         esz = 4 if self.dt == F32 else 2
         M_, N_, K_ = int(a.M), int(a.Nn), int(a.Kk)
@@ -433,7 +446,7 @@ class Engine:
                  _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, 1e-6, M, Cc, _p(act), kind="ln_fwd", nbytes=3 * M * Cc * esz)
         self._gemm(lst, tag + ":pw1", "NONE", "STORE", A=blk["xn"], B=self.w[tag + ".W1"]["t"], bias=P[nm["b1"]],
                    C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
-        self._op(lst, tag + ":grn.stats", lib.mpmae_colstats, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H, rpg,
+        self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H, rpg,
                  kind="colstats", nbytes=M * H * esz)
         self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                  _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
@@ -459,7 +472,7 @@ class Engine:
                    ldb=w2t["ld"], ldc=H)
         self._wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
                     dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
-        self._op(lst, tag + ":grn.bstats", lib.mpmae_colstats, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]), _p(blk["S1"]),
+        self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]), _p(blk["S1"]),
                  M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                  _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
@@ -469,7 +482,7 @@ class Engine:
                    ldb=w1t["ld"], ldc=Cc)
         self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
                     dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        self._op(lst, tag + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+        self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                  _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                  _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
         self._dw_bwd(lst, blk, dd, dout, dx)
@@ -489,8 +502,9 @@ class Engine:
         a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
         a.ntiles_total = self.N * ts * ts
         a.act = act.data_ptr() if act is not None else 0
+        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
         self._keepalive.append(a)
-        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 1024, kind="dwconv7_wgrad",
+        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
                  nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
         self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
 
@@ -596,7 +610,7 @@ class Engine:
         self.loss_args = {}
         ipc = 0
         for t, om in enumerate(cfg.out_mods):
-            acc = self.loss_acc[2 * t:2 * t + 2]
+            acc = self.loss_acc[t]
             coef = self.coef[t:t + 1]
             tgt = self.inp[om.name]
             if om.kind == "pix_cont":
@@ -640,6 +654,14 @@ class Engine:
         self._fin_args = (_p(self.loss_acc), _p(lv), len(cfg.out_mods), _p(self.losses), _p(self.weighted),
                           _p(self.total), _p(self.coef), _p(glv))
 
+    def finalize_loss(self, stream, with_dlogvars: bool, loss_scale: float = 1.0):
+        """12 per-modality losses, uncertainty weighting, total, backward coefficients
+        (and, with_dlogvars, d total / d log_vars accumulated into the gradient buffer)."""
+        a = self._fin_args
+        err = self.lib.mpmae_loss_finalize(a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6],
+                                           a[7] if with_dlogvars else None, stream)
+        _lib.check(err, "loss_finalize")
+
     # ------------------------------------------------------------------ backward program
     def _block_bwd_fused(self, lst, blk, dout, dx):
         """dout: gradient w.r.t. the block output [M,C]; writes the gradient w.r.t. its input into dx."""
@@ -664,7 +686,7 @@ class Engine:
         self._wgrad(lst, tag + ":pw1.wgrad", "GRN_BWD", "LN_AFFINE", P=dz, P2=blk["h"], Q=blk["dhat"], M=M, Nn=H,
                     Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]], pp0=blk["scale"],
                     pp1=blk["coef"], qp0=P[nm["ln_w"]], qp1=P[nm["ln_b"]], rpg=rpg)
-        self._op(lst, tag + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+        self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                  _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                  _p(act))
         self._dw_bwd(lst, blk, dd, dout, dx)
@@ -702,7 +724,7 @@ class Engine:
             wt = self.w["head.imgT"]
             self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
                        K=self.Wimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
-            self._op(b, "head:ln.bwd", lib.mpmae_ln_bwd, dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
+            self._op(b, "head:ln.bwd", self._ln_bwd_fn, dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
                      _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, _p(self.dy), 1 if have_pix else 0,
                      _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
         # decoder block
@@ -739,7 +761,7 @@ class Engine:
                 self._gemm(b, pre + ":dgrad", "NONE", "DOWN_DGRAD", A=cur, B=wd["t"], C=dxn, M=self.M[i], N=4 * Ci, K=Co,
                            lda=Co, ldb=wd["ld"], ldc=Ci, S=self.S[i], Cseg=Ci, act_src=self.act[i - 1])
                 nxt = other[:self.M[i - 1] * Ci]
-                self._op(b, pre + ":ln.bwd", lib.mpmae_ln_bwd, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
+                self._op(b, pre + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
                          _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
                          _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
                 other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
@@ -747,14 +769,14 @@ class Engine:
         # stem
         C0, k = dims[0], cfg.stem_k
         ds = self.scr_dd[:self.M[0] * C0]
-        self._op(b, "stem:ln2.bwd", lib.mpmae_ln_bwd, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
+        self._op(b, "stem:ln2.bwd", self._ln_bwd_fn, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
                  _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, _p(ds), 0,
                  _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
         da1 = self.scr_dxn[:self.Mfull * C0]
         self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
                  _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full))
         dc1 = other[:self.Mfull * C0]
-        self._op(b, "stem:ln1.bwd", lib.mpmae_ln_bwd, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
+        self._op(b, "stem:ln1.bwd", self._ln_bwd_fn, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
                  _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
                  _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
                  _p(self.act_full))
@@ -783,9 +805,7 @@ class Engine:
         st = self._stream()
         self.stats.zero_()
         self._run(self.fwd_ops, st)
-        err = self.lib.mpmae_loss_finalize(self._fin_args[0], self._fin_args[1], self._fin_args[2], float(loss_scale),
-                                           *self._fin_args[3:7], None, st)
-        _lib.check(err, "loss_finalize")
+        self.finalize_loss(st, False, loss_scale)
         self._loss_scale = float(loss_scale)
 
     def backward(self, zero_grad: bool = True):
@@ -793,9 +813,7 @@ class Engine:
         if zero_grad:
             self.gflat.zero_()
         # d(total)/d(log_vars) and the per-modality coefficients (second finalize pass adds dlog_vars)
-        err = self.lib.mpmae_loss_finalize(self._fin_args[0], self._fin_args[1], self._fin_args[2], self._loss_scale,
-                                           *self._fin_args[3:7], self._fin_args[7], st)
-        _lib.check(err, "loss_finalize(bwd)")
+        self.finalize_loss(st, True, self._loss_scale)
         self._run(self.bwd_ops, st)
 
     def optimizer_step(self, lr: float, weight_decay: float = 0.05, beta1: float = 0.9, beta2: float = 0.95,
