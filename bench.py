@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--profile-names", action="store_true", help="per-launch (by op name) time table to stderr")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--block-mode", default=None, choices=[None, "fused", "mat"], help="override the per-block program policy")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel-kind time table to stderr")
     return ap.parse_args()
 
@@ -132,7 +133,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
-    eng = Engine(cfg, a.batch, dtype=a.dtype, device=dev)
+    eng = Engine(cfg, a.batch, dtype=a.dtype, device=dev, block_mode=a.block_mode)
     eng.load_state_dict(make_state_dict(cfg, seed=0))
     inputs, noise = make_inputs(cfg, a.batch, seed=1000 + rank)
     eng.set_inputs(inputs, noise)

@@ -192,7 +192,7 @@ int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const 
                        mpmae_stream_t stream);
 int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w,
                        float* dw, float* db, int Mout, int C, int S, int k, const uint8_t* act_in,
-                       mpmae_stream_t stream);
+                       float* ws, size_t ws_floats, mpmae_stream_t stream);
 /* mask-token blend of forward_decoder (fcmae.py:253-255) and its parameter gradient. */
 int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D,
                           mpmae_stream_t stream);

@@ -8,6 +8,7 @@
 #include "gemm_fast.cuh"
 #include "dwconv2.cuh"
 #include "dwconv3.cuh"
+#include "rows2.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -34,6 +35,7 @@ static void launch_reduce(int mode, const float* part, int P, int W, float* out,
   dim3 g(cdiv(W, 256), R);
   if (mode == 0) hipLaunchKernelGGL(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else if (mode == 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else if (mode == 3) hipLaunchKernelGGL(reduce_partials_kernel<3>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else hipLaunchKernelGGL(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
 }
 
@@ -162,6 +164,19 @@ static void launch_ln_fwd(const void* x, void* xhat, float* rstd, void* y, const
 int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
                  float eps, int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
   if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if ((C & 7) == 0 && C <= 1024) {
+    const int nvec = C / 8;
+    const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
+    const int per = cdiv(nvec, G);
+    const int rpw = 64 / G;
+    const int blocks = grid1d((long long)cdiv(M, rpw) * 64, 256, 4096);
+#define LNF(TT, GG, PP) hipLaunchKernelGGL((ln_fwd_v2_kernel<TT, GG, PP>), dim3(blocks), dim3(256), 0, S_(s), (const TT*)x, (TT*)xhat, rstd, (TT*)y, gamma, beta, act, eps, M, C, rowmask)
+#define LNF_T(TT) do { if (G == 8) LNF(TT, 8, 1); else if (G == 16) LNF(TT, 16, 1); else if (G == 32) LNF(TT, 32, 1); else if (per == 1) LNF(TT, 64, 1); else LNF(TT, 64, 2); } while (0)
+    if (dt == 0) LNF_T(float); else LNF_T(bf16_t);
+#undef LNF_T
+#undef LNF
+    RET();
+  }
   if (dt == 0) launch_ln_fwd<float>(x, xhat, rstd, y, gamma, beta, act, eps, M, C, rowmask, S_(s));
   else launch_ln_fwd<bf16_t>(x, xhat, rstd, y, gamma, beta, act, eps, M, C, rowmask, S_(s));
   RET();
@@ -174,7 +189,20 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
   int blocks = grid1d((long long)M * 64, 256, 1024);
   if (!ws || ws_floats < (size_t)2 * C) return (int)hipErrorInvalidValue;
   if ((size_t)blocks * 2 * C > ws_floats) blocks = (int)(ws_floats / ((size_t)2 * C));
-  if (dt == 0)
+  if ((C & 7) == 0 && C <= 1024) {
+    const int nvec = C / 8;
+    const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
+    const int per = cdiv(nvec, G);
+    const int rpw = 64 / G;
+    int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, 512);          // <= 2048 waves -> slab rows
+    while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
+#define LNB(TT, GG, PP) hipLaunchKernelGGL((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask)
+#define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
+    if (dt == 0) LNB_T(float); else LNB_T(bf16_t);
+#undef LNB_T
+#undef LNB
+    blocks = b2 * 4;                                                  // slab rows = waves
+  } else if (dt == 0)
     hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
                        (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);
   else
@@ -299,11 +327,18 @@ int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const 
 }
 
 int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w, float* dw, float* db,
-                       int Mout, int C, int S, int k, const uint8_t* act_in, mpmae_stream_t s) {
+                       int Mout, int C, int S, int k, const uint8_t* act_in, float* ws, size_t ws_floats, mpmae_stream_t s) {
   if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
-  const int g = 128;     // few blocks: each ends with C*(k*k+1) float atomics
-  if (dt == 0) hipLaunchKernelGGL(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, dw, db, Mout, C, S, k, act_in);
-  else hipLaunchKernelGGL(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, dw, db, Mout, C, S, k, act_in);
+  const int cpb = C < 256 ? C : 256;
+  const int rows_par = 256 / cpb > 0 ? 256 / cpb : 1;
+  const size_t per = (size_t)(k * k + 1) * C;
+  int g = 512;
+  if (!ws || ws_floats < per * rows_par) return (int)hipErrorInvalidValue;
+  while ((size_t)g * rows_par * per > ws_floats && g > 1) g /= 2;
+  if (dt == 0) hipLaunchKernelGGL(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, ws, Mout, C, S, k, act_in);
+  else hipLaunchKernelGGL(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, S, k, act_in);
+  // slab row = [k*k taps][C] then [C] bias: e = t*C + c -> t < k*k ? dw[t*C + c] : db[c]; dw is contiguous (k*k, C)
+  launch_reduce(3, ws, g * rows_par, (int)per, dw, db, k * k * C, 0, 0, 0, S_(s));
   RET();
 }
 
@@ -383,33 +418,50 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t s) {
 // ------------------------------------------------------------------------------------------
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
   if (dt != 1 || pro != PRO_NONE) return false;
-  if (epi != EPI_STORE && epi != EPI_RESID) return false;
+  const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);
+  if (epi != EPI_STORE && epi != EPI_RESID && !stats) return false;
+  if (stats && a.rpg < a.M) return false;                 // grouped statistics: generic kernel
+  if (stats && (!a.ws || a.ws_floats < (size_t)((a.M + 127) / 128) * a.N * 2)) return false;
+  if (epi == EPI_DZ_STATS && (a.ldr & 7)) return false;
   if ((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) return false;
   if (epi == EPI_RESID && (a.ldr & 7)) return false;
   return true;
 }
 
-static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
-  if (epi != EPI_RESID) a.R = nullptr;
-  const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
-  if (w64 < w128) {
-    constexpr int BN = 64;
-    const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
-    dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<BN>, g, dim3(256), lds, st, a);
-  } else {
-    constexpr int BN = 128;
-    const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
-    static bool once = false;
-    if (!once) {
-      if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return (int)hipGetLastError();
-      once = true;
-    }
-    dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel<BN>, g, dim3(256), lds, st, a);
+template <int BN>
+static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
+  const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
+  dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
+#define FAST_CASE(E)                                                                                   \
+  if (epi == E || (E == EPI_STORE && epi == EPI_RESID)) {                                              \
+    static bool once = false;                                                                          \
+    if (!once && lds > 64 * 1024) {                                                                    \
+      if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BN, E>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess) return (int)hipGetLastError();                  \
+      once = true;                                                                                     \
+    }                                                                                                  \
+    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BN, E>), g, dim3(256), lds, st, a);                        \
+    return (int)hipGetLastError();                                                                     \
   }
-  return (int)hipGetLastError();
+  FAST_CASE(EPI_STORE)
+  FAST_CASE(EPI_GELU_SUMSQ)
+  FAST_CASE(EPI_DZ_STATS)
+#undef FAST_CASE
+  return (int)hipErrorInvalidValue;
+}
+
+static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
+  if (epi == EPI_STORE) a.R = nullptr;
+  const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
+  int err = (w64 < w128) ? launch_gemm_fast_bn<64>(epi, a, st) : launch_gemm_fast_bn<128>(epi, a, st);
+  if (err) return err;
+  if (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) {
+    const int mblocks = cdiv(a.M, FBM);
+    launch_reduce(0, a.ws, mblocks, a.N, a.s0, nullptr, 0, 0, 0, 0, st);
+    if (epi == EPI_DZ_STATS) launch_reduce(0, a.ws + (size_t)mblocks * a.N, mblocks, a.N, a.s1, nullptr, 0, 0, 0, 0, st);
+    err = (int)hipGetLastError();
+  }
+  return err;
 }
 
 static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
@@ -455,6 +507,32 @@ int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, con
 
 int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M, int H, int rpg,
                    float* ws, size_t ws_floats, mpmae_stream_t s) {
+  if ((H & 7) == 0 && cdiv(H / 8, 64) <= 6 && (size_t)4 * (mode + 1) * H * sizeof(float) <= 64 * 1024) {
+    const bool single1 = rpg >= M;
+    int rpw = single1 ? 8 : rpg;
+    if (!single1 && M % rpg != 0) return (int)hipErrorInvalidValue;
+    const size_t per = (size_t)H * (mode == 1 ? 2 : 1);
+    if (single1) {
+      if (!ws || ws_floats < per) return (int)hipErrorInvalidValue;
+      while ((size_t)cdiv(M, rpw) * per > ws_floats || cdiv(M, rpw) > 4096) rpw *= 2;
+    }
+    if (single1) { rpw = 64; while ((size_t)cdiv(M, rpw) * per > ws_floats) rpw *= 2; }
+    const int nblk = cdiv(M, rpw);
+    float* o0 = single1 ? ws : s0;
+    float* o1 = single1 ? ws + (size_t)nblk * H : s1;
+    const int vpl = cdiv(H / 8, 64);
+    const size_t lds = (size_t)4 * (mode + 1) * H * sizeof(float);
+#define CS3(TT, VV) hipLaunchKernelGGL((colstats_v3_kernel<TT, VV>), dim3(nblk), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
+#define CS3_T(TT) do { if (vpl == 1) CS3(TT, 1); else if (vpl == 2) CS3(TT, 2); else if (vpl <= 4) CS3(TT, 4); else CS3(TT, 6); } while (0)
+    if (dt == 0) CS3_T(float); else CS3_T(bf16_t);
+#undef CS3_T
+#undef CS3
+    if (single1) {
+      launch_reduce(0, ws, nblk, H, s0, nullptr, 0, 0, 0, 0, S_(s));
+      if (mode == 1) launch_reduce(0, ws + (size_t)nblk * H, nblk, H, s1, nullptr, 0, 0, 0, 0, S_(s));
+    }
+    RET();
+  }
   const bool single = rpg >= M;
   int rpb = single ? 256 : rpg;
   if (single) {

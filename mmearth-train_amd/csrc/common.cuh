@@ -69,6 +69,32 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// Fast exact-form GELU for the bf16 path: erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far
+// below bf16 resolution), sharing one exp(-x^2/2) between Phi(x) and phi(x). The fp32 parity path
+// keeps libm erff.
+__device__ __forceinline__ void gelu_both_fast(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float e = __expf(-0.5f * x * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;
+  const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  g = x * cdf;
+  dg = cdf + x * e * 0.39894228040143267794f;
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+  if (sizeof(T) == 2) { float g, dg; gelu_both_fast(x, g, dg); return g; }
+  return gelu_f(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
+  if (sizeof(T) == 2) { float g, dg; gelu_both_fast(x, g, dg); return dg; }
+  return gelu_grad_f(x);
+}
+template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float& g, float& dg) {
+  if (sizeof(T) == 2) gelu_both_fast(x, g, dg);
+  else { g = gelu_f(x); dg = gelu_grad_f(x); }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -38,21 +38,40 @@ __device__ __forceinline__ void w64_setup(const Geom& g, int n, int ty0, int tx0
 
 template <typename T>
 __device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int* rowtab, T* tile, int C, int c0) {
-  // 8 channels of one halo point = one 16-byte (bf16) / 32-byte (fp32) vector per lane
-  for (int i = threadIdx.x; i < DW_HP; i += 64) {
-    const int r = rowtab[i];
-    if (sizeof(T) == 2) {
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (r >= 0) v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + c0);
-      *reinterpret_cast<uint4*>(tile + i * 8) = v;
-    } else {
-      float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-      if (r >= 0) {
-        a = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
-        b = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0 + 4);
+  // 8 channels of one halo point = one 16-byte (bf16) / 32-byte (fp32) vector per lane. All four
+  // loads of a lane are issued unconditionally (masked rows read row 0 and are zeroed afterwards):
+  // loads under a per-lane branch are serialised by hipcc with a vmcnt(0) each.
+  int r[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + 64 * k;
+    r[k] = (i < DW_HP) ? rowtab[i] : -1;
+  }
+  if (sizeof(T) == 2) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(x + (size_t)(r[k] < 0 ? 0 : r[k]) * C + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 64 * k;
+      if (i < DW_HP) *reinterpret_cast<uint4*>(tile + i * 8) = (r[k] >= 0) ? v[k] : make_uint4(0u, 0u, 0u, 0u);
+    }
+  } else {
+    float4 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const T* src = x + (size_t)(r[k] < 0 ? 0 : r[k]) * C + c0;
+      a[k] = *reinterpret_cast<const float4*>(src);
+      b[k] = *reinterpret_cast<const float4*>(src + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = threadIdx.x + 64 * k;
+      if (i < DW_HP) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(tile + i * 8) = (r[k] >= 0) ? a[k] : z;
+        *reinterpret_cast<float4*>(tile + i * 8 + 4) = (r[k] >= 0) ? b[k] : z;
       }
-      *reinterpret_cast<float4*>(tile + i * 8) = a;
-      *reinterpret_cast<float4*>(tile + i * 8 + 4) = b;
     }
   }
 }
@@ -112,17 +131,21 @@ __global__ __launch_bounds__(64, 8) void dwconv7_w64_kernel(const DwP p) {
   if (ox >= TS) return;
   T* out = reinterpret_cast<T*>(p.out);
   const T* add = reinterpret_cast<const T*>(p.add);
+  // gather the residual / activity operands of all 8 outputs first (unconditional, clamped rows)
+  int rr[8];
+  float av[8];
+  uint8_t live[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) rr[o] = (o < TS) ? rowtab[(o + 3) * DW_HALO + ox + 3] : -1;
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    if (o < TS) {
-      const int r = rowtab[(o + 3) * DW_HALO + ox + 3];
-      if (r >= 0) {
-        float v = acc[o];
-        if (add) v += ldf<T>(add + (size_t)r * C + c);
-        if (p.act && !p.act[r]) v = 0.f;
-        stf<T>(out + (size_t)r * C + c, v);
-      }
-    }
+    const size_t ro = (size_t)(rr[o] < 0 ? 0 : rr[o]);
+    av[o] = add ? ldf<T>(add + ro * C + c) : 0.f;
+    live[o] = p.act ? p.act[ro] : 1;
+  }
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    if (rr[o] >= 0) stf<T>(out + (size_t)rr[o] * C + c, live[o] ? acc[o] + av[o] : 0.f);
   }
 }
 
@@ -162,7 +185,8 @@ __global__ __launch_bounds__(64, 5) void dwconv7_wgrad_w64_kernel(const DwWgP q)
 #pragma unroll
     for (int o = 0; o < 8; ++o) {
       const int r = (o < TS && ox < TS) ? rowtab[(o + 3) * DW_HALO + ox + 3] : -1;
-      g[o] = (r >= 0) ? ldf<T>(dd + (size_t)r * C + c) : 0.f;
+      const float gv = ldf<T>(dd + (size_t)(r < 0 ? 0 : r) * C + c);      // unconditional (clamped) load
+      g[o] = (r >= 0) ? gv : 0.f;
       adb += g[o];
     }
     __syncthreads();

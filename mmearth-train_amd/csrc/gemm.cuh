@@ -93,7 +93,7 @@ __device__ __forceinline__ void load_a8(const GemmP& p, int m, int k, float (&o)
   if constexpr (PRO == PRO_GRN) {
     const int g = m / p.rpg;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (k + i < p.K) o[i] = gelu_f(o[i]) * p.p0[(size_t)g * p.K + k + i] + p.p1[k + i];
+    for (int i = 0; i < 8; ++i) if (k + i < p.K) o[i] = gelu_t<T>(o[i]) * p.p0[(size_t)g * p.K + k + i] + p.p1[k + i];
   }
   if constexpr (PRO == PRO_GRN_BWD) {
     const int g = m / p.rpg;
@@ -104,7 +104,9 @@ __device__ __forceinline__ void load_a8(const GemmP& p, int m, int k, float (&o)
 #pragma unroll
     for (int i = 0; i < 8; ++i) if (k + i < p.K) {
       const size_t gi = (size_t)g * p.K + k + i;
-      o[i] = (o[i] * p.p0[gi] + p.p1[gi] * gelu_f(h[i])) * gelu_grad_f(h[i]);
+      float g, dg;
+      gelu_both_t<T>(h[i], g, dg);
+      o[i] = (o[i] * p.p0[gi] + p.p1[gi] * g) * dg;
     }
   }
 }
@@ -237,13 +239,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmP p) {
             stf<T>(C + (size_t)row * p.ldc + col, v);
             // statistics are taken on the value as the next kernel will re-read it (rounded to T)
             const float hv = (sizeof(T) == 2) ? bf2f(f2bf(v)) : v;
-            const float g = gelu_f(hv);
+            const float g = gelu_t<T>(hv);
             if (grouped) atomicAdd(&sacc[0][row / p.rpg - g0][col - n0], g * g);
             else cs0 += g * g;
           } else if constexpr (EPI == EPI_DZ_STATS) {
             stf<T>(C + (size_t)row * p.ldc + col, v);
             const float dz = (sizeof(T) == 2) ? bf2f(f2bf(v)) : v;
-            const float g = gelu_f(ldf<T>(R + (size_t)row * p.ldr + col));
+            const float g = gelu_t<T>(ldf<T>(R + (size_t)row * p.ldr + col));
             if (grouped) {
               atomicAdd(&sacc[0][row / p.rpg - g0][col - n0], dz);
               atomicAdd(&sacc[1][row / p.rpg - g0][col - n0], dz * g);

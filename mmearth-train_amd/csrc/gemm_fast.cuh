@@ -22,8 +22,12 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
   return make_uint4(0u, 0u, 0u, 0u);
 }
 
-template <int BN>
+// EPI: EPI_STORE (bias, optional residual R, row mask) | EPI_GELU_SUMSQ (store h, per-block column
+// partials of gelu(h)^2 -> ws[blockIdx.x][N]) | EPI_DZ_STATS (store dz, partials of dz and
+// dz*gelu(R) -> ws[blockIdx.x][N], ws[gridDim.x + blockIdx.x][N]); statistics: single group only.
+template <int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
+  using T = bf16_t;
   constexpr int NJ = BN / 32;                 // 16-wide N tiles per wave (wave tile 64 x BN/2)
   constexpr int BCH = BN * 8 / 256;           // 16-byte chunks of the B tile per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -99,9 +103,64 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
 
   // ---- epilogue: registers -> LDS (fp32, 64 columns at a time) -> 16-byte global stores ----
   constexpr int SLD = 68;
+  constexpr bool STATS = (EPI == EPI_GELU_SUMSQ || EPI == EPI_DZ_STATS);
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
   const bf16_t* R = reinterpret_cast<const bf16_t*>(p.R);
   constexpr int HALVES = BN / 64;
+  if constexpr (STATS) {
+    // Column statistics straight from the accumulator layout (lane = column lr, 16 rows per wave
+    // tile column): 16 in-register adds + 2 shuffles per column instead of a 64-lane butterfly.
+    constexpr int HLD = BN + 8;
+    bf16_t* htile = reinterpret_cast<bf16_t*>(smem_raw + 128 * SLD * sizeof(float));       // [128][BN+8] (DZ_STATS)
+    float* colacc = reinterpret_cast<float*>(smem_raw + 128 * SLD * sizeof(float) + 128 * HLD * sizeof(bf16_t));  // [2][BN]
+    uint8_t* actl = reinterpret_cast<uint8_t*>(colacc + 2 * BN);                            // [128] row activity
+    for (int i = tid; i < 2 * BN; i += 256) colacc[i] = 0.f;
+    if (tid < 128) actl[tid] = (p.act && m0 + tid < p.M) ? p.act[m0 + tid] : 1;
+    if constexpr (EPI == EPI_DZ_STATS) {
+      for (int c = tid; c < 128 * (BN / 8); c += 256) {
+        const int row = c / (BN / 8), ch = (c - row * (BN / 8)) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (m0 + row < p.M && n0 + ch < p.N) v = *reinterpret_cast<const uint4*>(R + (size_t)(m0 + row) * p.ldr + n0 + ch);
+        *reinterpret_cast<uint4*>(htile + row * HLD + ch) = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int cl = wn * (BN / 2) + j * 16 + lr;
+      const int col = n0 + cl;
+      const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+      float cs0 = 0.f, cs1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = wm * 64 + i * 16 + lg * 4 + r;
+          const int row = m0 + rl;
+          if (row < p.M && col < p.N) {
+            float v = acc[i][j][r] + bias;
+            if (!actl[rl]) v = 0.f;
+            v = bf2f(f2bf(v));                       // statistics on the value as stored
+            if constexpr (EPI == EPI_GELU_SUMSQ) { const float g = gelu_t<T>(v); cs0 += g * g; }
+            else { cs0 += v; cs1 += v * gelu_t<T>(bf2f(htile[rl * HLD + cl])); }
+          }
+        }
+      cs0 += __shfl_xor(cs0, 16, 64); cs0 += __shfl_xor(cs0, 32, 64);
+      if (lg == 0) atomicAdd(&colacc[cl], cs0);
+      if constexpr (EPI == EPI_DZ_STATS) {
+        cs1 += __shfl_xor(cs1, 16, 64); cs1 += __shfl_xor(cs1, 32, 64);
+        if (lg == 0) atomicAdd(&colacc[BN + cl], cs1);
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      if (n0 + c < p.N) {
+        p.ws[(size_t)blockIdx.x * p.N + n0 + c] = colacc[c];
+        if (EPI == EPI_DZ_STATS) p.ws[((size_t)gridDim.x + blockIdx.x) * p.N + n0 + c] = colacc[BN + c];
+      }
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int half = 0; half < HALVES; ++half) {
     const bool mine = (HALVES == 1) || (wn == half);
@@ -119,6 +178,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
     {
       const int row = tid >> 1, cseg = (tid & 1) * 32;
       const int grow = m0 + row;
+
       const bool live = !p.act || (grow < p.M && p.act[grow]);
       if (grow < p.M) {
 #pragma unroll
@@ -130,10 +190,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
             const float4 s1 = *reinterpret_cast<const float4*>(stage + row * SLD + cseg + v8 * 8 + 4);
             v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
             if (p.bias) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += p.bias[col + e];
+              const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+              const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
             }
-            if (R) {
+            if (EPI == EPI_STORE && R) {
               float rr[8];
               ld8<bf16_t>(R + (size_t)grow * p.ldr + col, rr);
 #pragma unroll
@@ -275,9 +337,18 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const T* __restrict__ h,
     float v[8];
     ld8<T>(h + e, v);
     const bool live = !act || act[m];
+    // parameter vectors are loaded unconditionally as two float4 each: inside the `live` select
+    // hipcc scalarises them into 16 dependent dword loads with a vmcnt(0) after every one
     const float* sc = scale + (size_t)(m / rpg) * H + j;
+    const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(beta + j), b1 = *reinterpret_cast<const float4*>(beta + j + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float bev[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = live ? gelu_f(v[q]) * sc[q] + beta[j + q] : 0.f;
+    for (int q = 0; q < 8; ++q) {
+      const float r = gelu_t<T>(v[q]) * scv[q] + bev[q];
+      v[q] = live ? r : 0.f;
+    }
     st8<T>(z + e, v);
   }
 }
@@ -295,8 +366,16 @@ __global__ __launch_bounds__(256) void grn_bwd_apply_kernel(T* __restrict__ dz, 
     ld8<T>(dz + e, d);
     ld8<T>(h + e, hv);
     const size_t gi = (size_t)(m / rpg) * H + j;
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + gi), s1 = *reinterpret_cast<const float4*>(scale + gi + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(coef + gi), c1 = *reinterpret_cast<const float4*>(coef + gi + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float cov[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
 #pragma unroll
-    for (int q = 0; q < 8; ++q) d[q] = (d[q] * scale[gi + q] + coef[gi + q] * gelu_f(hv[q])) * gelu_grad_f(hv[q]);
+    for (int q = 0; q < 8; ++q) {
+      float g, dg;
+      gelu_both_t<T>(hv[q], g, dg);
+      d[q] = (d[q] * scv[q] + cov[q] * g) * dg;
+    }
     st8<T>(dz + e, d);
   }
 }
@@ -315,7 +394,7 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ h, 
   float a0 = 0.f, a1 = 0.f;
   if (c < H) {
     for (int m = mb + rl; m < me; m += 4) {
-      const float gv = gelu_f(ldf<T>(h + (size_t)m * H + c));
+      const float gv = gelu_t<T>(ldf<T>(h + (size_t)m * H + c));
       if (mode == 0) a0 += gv * gv;
       else { const float d = ldf<T>(dz + (size_t)m * H + c); a0 += d; a1 += d * gv; }
     }

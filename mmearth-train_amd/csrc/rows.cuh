@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
         }
         if (y) {
           float u = xh * gamma[c] + beta[c];
-          if (act == 1) u = gelu_f(u);
+          if (act == 1) u = gelu_t<T>(u);
           stf<T>(y + (size_t)m * C + c, live ? u : 0.f);
         }
       }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
         xh[i] = ldf<T>(xhat + (size_t)m * C + c);
         float d = ldf<T>(dy + (size_t)(m / dy_div) * C + c) * dy_scale;
         const float ga = gamma[c];
-        if (act == 1) d *= gelu_grad_f(xh[i] * ga + beta[c]);
+        if (act == 1) d *= gelu_grad_t<T>(xh[i] * ga + beta[c]);
         ag[i] += d * xh[i];
         ab[i] += d;
         g[i] = d * ga;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void dwstride_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void dwstride_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ in,
                                                            T* __restrict__ din, const float* __restrict__ w,
-                                                           float* __restrict__ dw, float* __restrict__ db,
+                                                           float* __restrict__ ws,
                                                            int Mout, int C, int S, int k,
                                                            const uint8_t* __restrict__ act_in) {
   // thread <-> channel (threadIdx.x % C-chunk), rows strided: keeps per-thread channel fixed so the
@@ -245,8 +245,10 @@ __global__ __launch_bounds__(256) void dwstride_bwd_kernel(const T* __restrict__
             if (live) adw[tap] += g * ldf<T>(in + (size_t)src * C + c);
           }
       }
-      for (int t = 0; t < k * k; ++t) atomicAdd(dw + t * C + c, adw[t]);
-      atomicAdd(db + c, adb);
+      // per-(block, row-lane) partial slab ws[(blockIdx.x*rows_par + tr)][(k*k+1)][C]
+      float* slab = ws + (size_t)(blockIdx.x * rows_par + tr) * (k * k + 1) * C;
+      for (int t = 0; t < k * k; ++t) slab[t * C + c] = adw[t];
+      slab[k * k * C + c] = adb;
     }
   }
 }

@@ -444,10 +444,15 @@ class Engine:
         self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
         self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]), _p(blk["xn"]),
                  _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, 1e-6, M, Cc, _p(act), kind="ln_fwd", nbytes=3 * M * Cc * esz)
-        self._gemm(lst, tag + ":pw1", "NONE", "STORE", A=blk["xn"], B=self.w[tag + ".W1"]["t"], bias=P[nm["b1"]],
-                   C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
-        self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H, rpg,
-                 kind="colstats", nbytes=M * H * esz)
+        if blk["sparse"]:      # single statistics group: column sums ride in the GEMM epilogue
+            self._gemm(lst, tag + ":pw1", "NONE", "GELU_SUMSQ", A=blk["xn"], B=self.w[tag + ".W1"]["t"],
+                       bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
+                       rpg=rpg, s0=blk["G2"], act=act)
+        else:
+            self._gemm(lst, tag + ":pw1", "NONE", "STORE", A=blk["xn"], B=self.w[tag + ".W1"]["t"], bias=P[nm["b1"]],
+                       C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
+            self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H,
+                     rpg, kind="colstats", nbytes=M * H * esz)
         self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                  _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
@@ -468,12 +473,17 @@ class Engine:
         dxn = self.scr_dxn[:M * Cc]
         dd = self.scr_dd[:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
-        self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
-                   ldb=w2t["ld"], ldc=H)
+        if blk["sparse"]:
+            self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
+                       K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
+        else:
+            self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
+                       ldb=w2t["ld"], ldc=H)
         self._wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
                     dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
-        self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]), _p(blk["S1"]),
-                 M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
+        if not blk["sparse"]:
+            self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
+                     _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                  _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
         self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
@@ -774,7 +784,8 @@ class Engine:
                  _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
         da1 = self.scr_dxn[:self.Mfull * C0]
         self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
-                 _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full))
+                 _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full),
+                 _p(self.ws), self.ws_floats)
         dc1 = other[:self.Mfull * C0]
         self._op(b, "stem:ln1.bwd", self._ln_bwd_fn, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
                  _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
