@@ -56,6 +56,16 @@ def max_over_ranks(x: float) -> float:
     return float(t.item())
 
 
+def mean_scalar(x: float) -> float:
+    """helpers.all_reduce_mean (/root/reference/helpers.py:393-401)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return x
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float32, device=dev)
+    dist.all_reduce(t)
+    return float(t.item()) / dist.get_world_size()
+
+
 def shutdown():
     if dist.is_initialized():
         dist.destroy_process_group()

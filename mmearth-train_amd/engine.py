@@ -39,7 +39,7 @@ def _rup(x, m):
 
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
-                 track_activity: bool = True, mask_ratio=None, block_mode=None):
+                 track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None):
         if cfg.decoder_depth != 1:
             raise NotImplementedError("decoder_depth != 1")
         self.lib = _lib.load()
@@ -50,6 +50,7 @@ class Engine:
         self.device = torch.device(device)
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
+        self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
         self.L = cfg.num_patches
         self.grid = cfg.grid
         self.keep = cfg.len_keep(mask_ratio)
@@ -72,8 +73,13 @@ class Engine:
         spec = state_dict_spec(self.cfg)
         total = sum(math.prod(s) for _, s, _ in spec)
         dev = self.device
-        self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        if self._ext_buffers is not None:
+            self.pflat, self.gflat = self._ext_buffers
+            assert self.pflat.numel() == total and self.gflat.numel() == total
+            assert self.pflat.device == dev and self.pflat.dtype == torch.float32
+        else:
+            self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.mflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.vflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.decay_mask = torch.zeros(total, dtype=torch.uint8, device=dev)
@@ -419,7 +425,7 @@ class Engine:
     def _block_mode(self, blk):
         if self.block_mode_override:
             return self.block_mode_override
-        return "mat" if (self.dt == BF16 and blk["C"] >= 128) else "fused"
+        return "mat" if self.dt == BF16 else "fused"      # measured on MI355X: mat 13.2 vs fused-small-C 14.5 ms/step
 
     def _block_fwd(self, lst, blk, x):
         blk["mode"] = self._block_mode(blk)

@@ -1,0 +1,63 @@
+"""Pretraining epoch loop (drop-in for /root/reference/engine_pretrain.py:21-122) without the
+reference's 14 host synchronisations per iteration: losses stay on the device and are read back
+only every `print_freq` iterations."""
+import math
+import sys
+import time
+
+import torch
+
+from . import dist as mdist
+
+
+def adjust_learning_rate(optimizer, epoch, args):
+    """Warm-up then half-cycle cosine, per iteration (/root/reference/helpers.py:647-665)."""
+    if epoch < args.warmup_epochs:
+        lr = args.lr * epoch / args.warmup_epochs
+    else:
+        lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * (
+            1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+    if optimizer is not None:
+        for g in optimizer.param_groups:
+            g["lr"] = lr * g["lr_scale"] if "lr_scale" in g else lr
+    return lr
+
+
+def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=None, print_freq=20):
+    """model: fcmae.FCMAE. data_loader yields dicts modality -> tensor. With `runner`
+    (dist.StepRunner) the fused HIP optimizer / HIP-graph path is used instead of torch autograd."""
+    update_freq = args.update_freq
+    n_iter = len(data_loader)
+    t0 = time.time()
+    loss_value, loss_dict, log_vars, normalized = float("nan"), {}, None, None
+    if optimizer is not None:
+        optimizer.zero_grad()
+    for it, samples in enumerate(data_loader):
+        lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args) if it % update_freq == 0 else None
+        samples = {k: v.to(device, non_blocking=True) for k, v in samples.items()}
+        if runner is not None:
+            if lr is not None:
+                runner.lr = lr
+            eng = runner.eng
+            noise = torch.randn(eng.N, eng.L, device=device)
+            eng.set_inputs(model._crop(samples), noise)
+            runner.step()
+            losses_t, total_t = eng.losses, eng.total
+        else:
+            loss, pred, mask, loss_dict_, log_vars, normalized = model(samples, mask_ratio=args.mask_ratio)
+            (loss / update_freq).backward()
+            if (it + 1) % update_freq == 0:
+                optimizer.step()
+                optimizer.zero_grad()
+            losses_t, total_t = model._engine.losses, loss.detach()
+        if it % print_freq == 0 or it == n_iter - 1:
+            loss_value = float(total_t.item())           # the only host sync of the loop
+            if not math.isfinite(loss_value):
+                print("Loss is {}, stopping training".format(loss_value))
+                sys.exit(1)
+            names = [om.name for om in model.cfg.out_mods]
+            loss_dict = dict(zip(names, losses_t.tolist()))
+            mean = mdist.mean_scalar(loss_value)
+            print(f"Epoch: [{epoch}]  [{it}/{n_iter}]  loss: {mean:.4f}  "
+                  f"img/s: {(it + 1) * samples['sentinel2'].shape[0] / (time.time() - t0):.0f}", flush=True)
+    return {"loss": loss_value}, loss_dict, log_vars, normalized

@@ -122,3 +122,35 @@ def test_gloo_world2_bucketed_allreduce():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res)
     assert all(mx == 2.0 for _, _, mx in res)
+
+
+def test_fcmae_module_state_dict_layout_cpu(lib):
+    """Module tree reproduces the reference's state-dict keys/shapes without a GPU."""
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    m = fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True,
+                              patch_size=8, img_size=56, args=default_args(), loss_fn=UncertaintyWeightingStrategy(12),
+                              sparse=True, device="cpu")
+    sd = m.state_dict()
+    assert len(sd) == 290
+    assert tuple(sd["encoder.initial_conv.0.kernel"].shape) == (9, 12, 40)
+    assert tuple(sd["encoder.stages.2.5.pwconv1.linear.weight"].shape) == (640, 160)
+    assert tuple(sd["encoder.downsample_layers.1.1.kernel"].shape) == (4, 80, 160)
+    assert tuple(sd["decoder_dict.esa_worldcover.0.grn.gamma"].shape) == (1, 1, 1, 2048)
+    assert tuple(sd["pred_dict.sentinel2.weight"].shape) == (768, 512, 1, 1)
+    assert tuple(sd["loss_fn.log_vars"].shape) == (12,)
+    assert sd["decoder_dict.lat.0.pwconv2.weight"].data_ptr() == sd["decoder_dict.sentinel2.0.pwconv2.weight"].data_ptr()
+    assert sum(p.numel() for p in m.parameters()) == 7580674
+    assert hasattr(m, "encoder") and hasattr(m, "proj") and hasattr(m, "pred_dict") and hasattr(m, "layer_norm_tmp")
+    golden = __import__("tests.golden_cases", fromlist=["load_fixture"]).load_fixture("misc")
+    # checkpoint remap contract (helpers.remap_checkpoint_keys): our encoder keys are the ones it expects
+    enc_keys = [k for k in sd if k.startswith("encoder.")]
+    assert len(enc_keys) == len(golden["remap_keys"])
+    import main_pretrain
+    flags = {a.dest for a in main_pretrain.get_args_parser()._actions}
+    for f in ["model", "input_size", "patch_size", "mask_ratio", "norm_pix_loss", "decoder_depth", "decoder_embed_dim",
+              "use_orig_stem", "loss_aggr", "batch_size", "update_freq", "epochs", "warmup_epochs", "blr", "lr", "min_lr",
+              "weight_decay", "use_mixed", "sparse", "distributed", "no_ffcv", "output_dir", "auto_resume", "save_ckpt",
+              "save_ckpt_freq", "save_ckpt_num", "seed", "device"]:
+        assert f in flags, f

@@ -125,6 +125,20 @@ def test_bf16_step_within_stated_tolerance(name):
             assert cs >= 0.99, (k, cs)
 
 
+def test_fp32_materialised_block_program_matches_oracle():
+    """the 'mat' block program (materialised xn / z / dh, statistics in GEMM epilogues) in exact-f32 mode"""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    (loss, pred, mask, loss_dict, _, _), taps, grads = _oracle(cfg, sd, inputs, noise)
+    eng = _engine(cfg, c["N"], "f32", sd, inputs, noise, block_mode="mat")
+    eng.forward(); eng.backward(); torch.cuda.synchronize()
+    assert abs(eng.total.item() - loss.item()) <= 1e-4 * abs(loss.item())
+    for k in sd:
+        den = grads[k].abs().max().item()
+        assert (eng.grads[k].cpu() - grads[k]).abs().max().item() <= 2e-4 * den + 1e-9, k
+
+
 def test_adamw_step_matches_oracle():
     from oracle import mpmae_ref as O
     c = CASES["allmod_atto_56"]
@@ -186,3 +200,41 @@ def test_product_path_fails_loudly_without_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmpmae_hip.so")
     with pytest.raises(_lib.HipLibraryError):
         _lib.load()
+
+
+def test_fcmae_module_dropin_api():
+    """fcmae.FCMAE: reference constructor / forward tuple / autograd `loss.backward()` /
+    torch optimizer, checked against the oracle on a golden case (fp32 mode)."""
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    from mmearth_train_amd.synth import expand_aliases
+    from mmearth_train_amd import MODALITIES as MM
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    args = default_args(out_modalities=MM.subset("all_mod"))
+    model = fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True,
+                                  patch_size=8, img_size=56, args=args, loss_fn=UncertaintyWeightingStrategy(12),
+                                  sparse=True, device="cuda:0", dtype="f32")
+    missing = model.load_state_dict(expand_aliases(cfg, sd), strict=True)     # reference-layout checkpoint
+    assert len(model.state_dict()) == 290 and sum(p.numel() for p in model.parameters()) == 7580674
+    torch.manual_seed(c["nseed"])          # the module draws randn(N, L) like the reference
+    dev_inputs = {k: v.to("cuda:0") for k, v in inputs.items()}
+    loss, pred, mask, loss_dict, log_vars, normalized = model(dev_inputs, mask_ratio=0.6)
+    assert list(loss_dict.keys()) == [om.name for om in cfg.out_mods] and len(log_vars) == 12
+    assert tuple(pred["sentinel2"].shape) == (2, 768, 7, 7) and tuple(mask.shape) == (2, 49)
+    # same mask rule as the reference on the noise actually drawn on the device
+    (oloss, opred, omask, oloss_dict, _, ow), taps, grads = _oracle(cfg, sd, inputs, model._engine.noise.cpu())
+    assert torch.equal(mask.cpu(), omask)
+    assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+    assert torch.allclose(normalized.cpu(), ow.detach(), rtol=1e-4, atol=1e-6)
+    loss.backward()
+    for k in ["encoder.stages.2.3.grn.gamma", "proj.weight", "loss_fn.log_vars", "pred_dict.eco_region.weight",
+              "decoder_dict.sentinel2.0.pwconv1.weight", "encoder.initial_conv.0.kernel"]:
+        p = dict(model.named_parameters())[k]
+        assert _rel(p.grad, grads[k]) < 2e-4, k
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    before = model._pflat.clone()
+    opt.step()
+    assert not torch.equal(before, model._pflat)      # torch optimizers update the engine's flat buffer in place
