@@ -29,10 +29,10 @@ static inline int grid1d(long long total, int per_block = 256, int cap = 16384) 
 // second stage of the two-stage reductions (see reduce_partials_kernel in misc.cuh)
 static void launch_reduce(int mode, const float* part, int P, int W, float* out, float* out2, int a, int b, int c, int d,
                           hipStream_t st) {
-  int R = P / 32;
+  int R = P / 16;                 // >= 4 rows per thread (4 row lanes per block)
   if (R < 1) R = 1;
-  if (R > 16) R = 16;
-  dim3 g(cdiv(W, 256), R);
+  if (R > 32) R = 32;
+  dim3 g(cdiv(W, 64), R);
   if (mode == 0) hipLaunchKernelGGL(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else if (mode == 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else if (mode == 3) hipLaunchKernelGGL(reduce_partials_kernel<3>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
@@ -472,7 +472,8 @@ static int launch_wgrad_fast(WgradP a, hipStream_t st) {
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
   const int tiles = cdiv(a.Nn, 128) * cdiv(a.Kk, 128);
-  int splits = cdiv(768, tiles);                 // ~3 workgroups per CU
+  int splits = cdiv(512, tiles);                 // ~2 workgroups per CU
+  if (splits > 128) splits = 128;               // bound the second-stage reduction
   const int maxs = cdiv(a.M, 256);               // at least 8 reduction slabs per workgroup
   if (splits > maxs) splits = maxs;
   if (splits > (int)(a.ws_floats / per)) splits = (int)(a.ws_floats / per);

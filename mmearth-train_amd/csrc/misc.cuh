@@ -129,12 +129,21 @@ template <int MODE>
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, int W,
                                                               float* __restrict__ out, float* __restrict__ out2,
                                                               int a, int b, int c, int d) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= W) return;
+  // block = 64 columns x 4 row lanes; grid = (ceil(W/64), R row chunks)
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
   const int chunk = (P + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
   float s = 0.f;
-  for (int p = p0; p < p1; ++p) s += part[(size_t)p * W + e];
+  if (e < W) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || e >= W) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
   float* dst;
   if (MODE == 0) dst = out + e;
   else if (MODE == 1) { const int n = e / a, k = e - n * a; dst = out + (size_t)n * b + (size_t)k * c; }
@@ -142,8 +151,7 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   else {
     const int tap = e / a, ch = e - tap * a;
     if (tap < 49) { const int kh = tap / 7, kw = tap - kh * 7; dst = out + kh * b + kw * c + ch * d; }
-    else dst = out2 + ch;
-    if (tap >= 49 && out2 == nullptr) return;
+    else { if (!out2) return; dst = out2 + ch; }
   }
   if (gridDim.y == 1) *dst += s;
   else atomicAdd(dst, s);
