@@ -259,9 +259,13 @@ static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
   if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
-    dim3 g(a->g.N * a->tiles_side * a->tiles_side, a->C / 8);
-    if (dt == 0) hipLaunchKernelGGL(dwconv7_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
-    else hipLaunchKernelGGL(dwconv7_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
+    const int chunks = a->C / 8;
+    const int nw = chunks <= 8 ? chunks : (chunks % 5 == 0 ? 5 : 8);      // waves per block sharing the tables
+    const size_t esz = dt == 0 ? 4 : 2;
+    const size_t lds = (DW_HP + W64_MAXL) * sizeof(int) + (size_t)nw * (DW_HP * 8 * esz + 49 * 8 * sizeof(float));
+    dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(chunks, nw));
+    if (dt == 0) hipLaunchKernelGGL(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), *a);
+    else hipLaunchKernelGGL(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), *a);
     RET();
   }
   if ((a->C & 7) == 0) {

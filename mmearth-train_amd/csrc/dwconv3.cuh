@@ -16,23 +16,23 @@ constexpr int W64_MAXL = 256;   // patches per sample supported by the LDS copy 
 
 template <typename T>
 __device__ __forceinline__ void w64_setup(const Geom& g, int n, int ty0, int tx0, int* invs, int* rowtab) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;                     // whole block (1..8 waves) shares the row table
   const int L = g.grid * g.grid;
-  if (g.inv) { for (int i = lane; i < L; i += 64) invs[i] = g.inv[n * L + i]; }
-  else { for (int i = lane; i < L; i += 64) invs[i] = i; }
-  __syncthreads();
   const int ext = g.grid * g.S, P = g.S * g.S;
-  for (int i = lane; i < DW_HP; i += 64) {
+  const int sh = (g.S == 8) ? 3 : (g.S == 4) ? 2 : (g.S == 2) ? 1 : 0;     // S is a power of two
+  for (int i = lane; i < DW_HP; i += blockDim.x) {
     const int hy = i / DW_HALO, hx = i - hy * DW_HALO;
     const int gy = ty0 - 3 + hy, gx = tx0 - 3 + hx;
     int r = -1;
     if (gy >= 0 && gx >= 0 && gy < ext && gx < ext) {
-      const int py = gy / g.S, px = gx / g.S;
-      const int slot = invs[py * g.grid + px];
-      if (slot >= 0) r = (n * g.keep + slot) * P + (gy - py * g.S) * g.S + (gx - px * g.S);
+      const int py = gy >> sh, px = gx >> sh;
+      const int patch = py * g.grid + px;
+      const int slot = g.inv ? g.inv[n * L + patch] : patch;     // single global round trip (L2-resident table)
+      if (slot >= 0) r = (n * g.keep + slot) * P + ((gy - (py << sh)) << sh) + (gx - (px << sh));
     }
     rowtab[i] = r;
   }
+  (void)invs;
   __syncthreads();
 }
 
@@ -41,10 +41,11 @@ __device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int
   // 8 channels of one halo point = one 16-byte (bf16) / 32-byte (fp32) vector per lane. All four
   // loads of a lane are issued unconditionally (masked rows read row 0 and are zeroed afterwards):
   // loads under a per-lane branch are serialised by hipcc with a vmcnt(0) each.
+  const int lane = threadIdx.x & 63;
   int r[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + 64 * k;
+    const int i = lane + 64 * k;
     r[k] = (i < DW_HP) ? rowtab[i] : -1;
   }
   if (sizeof(T) == 2) {
@@ -53,7 +54,7 @@ __device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int
     for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(x + (size_t)(r[k] < 0 ? 0 : r[k]) * C + c0);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int i = threadIdx.x + 64 * k;
+      const int i = lane + 64 * k;
       if (i < DW_HP) *reinterpret_cast<uint4*>(tile + i * 8) = (r[k] >= 0) ? v[k] : make_uint4(0u, 0u, 0u, 0u);
     }
   } else {
@@ -66,7 +67,7 @@ __device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int i = threadIdx.x + 64 * k;
+      const int i = lane + 64 * k;
       if (i < DW_HP) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(tile + i * 8) = (r[k] >= 0) ? a[k] : z;
@@ -76,26 +77,31 @@ __device__ __forceinline__ void w64_load_tile(const T* __restrict__ x, const int
   }
 }
 
+// block = NW waves (blockDim.x = 64*NW): shared visibility tables, one 8-channel chunk per wave
 template <typename T>
-__global__ __launch_bounds__(64, 8) void dwconv7_w64_kernel(const DwP p) {
-  __shared__ __attribute__((aligned(16))) T tile[DW_HP * 8];
-  __shared__ float wl[49 * 8];
-  __shared__ int rowtab[DW_HP];
-  __shared__ int invs[W64_MAXL];
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(512) void dwconv7_w64_kernel(const DwP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char w64_smem[];
+  const int wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  int* rowtab = reinterpret_cast<int*>(w64_smem);
+  int* invs = rowtab + DW_HP;
+  T* tile = reinterpret_cast<T*>(w64_smem + (DW_HP + W64_MAXL) * sizeof(int) + ((size_t)wave * DW_HP * 8) * sizeof(T));
+  float* wl = reinterpret_cast<float*>(w64_smem + (DW_HP + W64_MAXL) * sizeof(int) + ((size_t)NW * DW_HP * 8) * sizeof(T)) + wave * 49 * 8;
+  const int lane = threadIdx.x & 63;
   const int tps = p.tiles_side * p.tiles_side;
   const int n = blockIdx.x / tps, t = blockIdx.x - n * tps;
   const int tyi = t / p.tiles_side, txi = t - tyi * p.tiles_side;
   const int TS = p.TP * p.g.S;
   const int ty0 = tyi * TS, tx0 = txi * TS;
-  const int c0 = blockIdx.y * 8;
   const int C = p.C;
+  int c0 = (blockIdx.y * NW + wave) * 8;
+  const bool chunk_ok = c0 < C;
+  if (!chunk_ok) c0 = 0;                      // idle waves of the last block mirror chunk 0 (no stores)
 
   w64_setup<T>(p.g, n, ty0, tx0, invs, rowtab);
   {
     const int oy = lane >> 3, oxx = lane & 7;
     const int valid = (oy < TS && oxx < TS && rowtab[(oy + 3) * DW_HALO + oxx + 3] >= 0);
-    if (!__any(valid)) return;
+    if (!__any(valid)) return;                // same tile for every wave of the block: uniform exit
   }
   w64_load_tile<T>(reinterpret_cast<const T*>(p.x), rowtab, tile, C, c0);
   for (int i = lane; i < 49 * 8; i += 64) {
@@ -113,6 +119,21 @@ __global__ __launch_bounds__(64, 8) void dwconv7_w64_kernel(const DwP p) {
   const float b = p.bias ? p.bias[c] : 0.f;
 #pragma unroll
   for (int o = 0; o < 8; ++o) acc[o] = b;
+  // residual / activity operands of the 8 outputs are requested BEFORE the tap loop (clamped rows,
+  // unconditional) so their latency hides behind the 392 FMAs
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* add = reinterpret_cast<const T*>(p.add);
+  int rr[8];
+  float av[8];
+  uint8_t live[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) rr[o] = (o < TS && ox < 8) ? rowtab[(o + 3) * DW_HALO + (ox < TS ? ox : 0) + 3] : -1;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    const size_t ro = (size_t)(rr[o] < 0 ? 0 : rr[o]);
+    av[o] = add ? ldf<T>(add + ro * C + c) : 0.f;
+    live[o] = p.act ? p.act[ro] : 1;
+  }
 #pragma unroll 1                        // rolled: one kx-slab of LDS reads live at a time (54 VGPRs, 8 waves/SIMD);
   for (int kx = 0; kx < 7; ++kx) {      // fully unrolled, hipcc hoists all 98 reads first (156 VGPRs, 3 waves/SIMD)
     float w7[7];
@@ -128,24 +149,9 @@ __global__ __launch_bounds__(64, 8) void dwconv7_w64_kernel(const DwP p) {
       }
     }
   }
-  if (ox >= TS) return;
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* add = reinterpret_cast<const T*>(p.add);
-  // gather the residual / activity operands of all 8 outputs first (unconditional, clamped rows)
-  int rr[8];
-  float av[8];
-  uint8_t live[8];
-#pragma unroll
-  for (int o = 0; o < 8; ++o) rr[o] = (o < TS) ? rowtab[(o + 3) * DW_HALO + ox + 3] : -1;
 #pragma unroll
   for (int o = 0; o < 8; ++o) {
-    const size_t ro = (size_t)(rr[o] < 0 ? 0 : rr[o]);
-    av[o] = add ? ldf<T>(add + ro * C + c) : 0.f;
-    live[o] = p.act ? p.act[ro] : 1;
-  }
-#pragma unroll
-  for (int o = 0; o < 8; ++o) {
-    if (rr[o] >= 0) stf<T>(out + (size_t)rr[o] * C + c, live[o] ? acc[o] + av[o] : 0.f);
+    if (rr[o] >= 0 && ox < TS && chunk_ok) stf<T>(out + (size_t)rr[o] * C + c, live[o] ? acc[o] + av[o] : 0.f);
   }
 }
 
