@@ -126,6 +126,24 @@ typedef struct MpmaeImgArgs {
   float* acc; const float* coef;
 } MpmaeImgArgs;
 
+/* Row-streaming fused pointwise kernels for the bandwidth-bound stages (bf16 only; C in {40,80,96},
+ * H = 4C): which = 0: x-hat, rstd, xn, h = LN(d) W1^T + b1 and sum gelu(h)^2     (LN + pwconv1)
+ *          which = 1: dz = dout W2 and (sum dz, sum dz*gelu(h))                   (pwconv2 data grad)
+ *          which = 2: out = x + z W2^T + b2                                        (pwconv2 + residual)
+ *          which = 3: dd = LayerNorm-backward(dh W1), dgamma, dbeta                (pwconv1 data grad + LN)
+ * Field use per kernel is documented in csrc/rs.cuh. Replaces convnextv2_sparse.py:40-43,55 and
+ * their autograd for the stages where C <= 96. */
+typedef struct MpmaeRsArgs {
+  const void* A; const void* A2; const void* W; int ldw;
+  const float* bias; const float* v0; const float* v1;
+  void* out; void* xhat; void* xn; float* rstd; const void* R; const float* lng;
+  float* ws; const uint8_t* act; int M;
+  int C, H;                        /* layer shape */
+  float* s0; float* s1;            /* statistics / parameter-gradient outputs (accumulated) */
+  size_t ws_floats;
+} MpmaeRsArgs;
+int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
+
 /* ---- masks / activity --------------------------------------------------------------------- */
 /* FCMAE.gen_random_mask (models/fcmae.py:214-231) on explicit noise [N,L]: mask f32 [N,L]
  * (1 = removed), vis [N,keep], inv [N,L]. */

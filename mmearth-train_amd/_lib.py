@@ -92,6 +92,14 @@ class ImgArgs(C.Structure):
                 ("acc", c_void_p), ("coef", c_void_p)]
 
 
+class RsArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("A2", c_void_p), ("W", c_void_p), ("ldw", c_int),
+                ("bias", c_void_p), ("v0", c_void_p), ("v1", c_void_p),
+                ("out", c_void_p), ("xhat", c_void_p), ("xn", c_void_p), ("rstd", c_void_p), ("R", c_void_p),
+                ("lng", c_void_p), ("ws", c_void_p), ("act", c_void_p), ("M", c_int),
+                ("C", c_int), ("H", c_int), ("s0", c_void_p), ("s1", c_void_p), ("ws_floats", c_size_t)]
+
+
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 
@@ -116,6 +124,7 @@ SYMBOLS = {
     "mpmae_grn_bwd_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                        c_void_p],
+    "mpmae_rs": [c_int, P(RsArgs), c_void_p],
     "mpmae_dwconv7_fwd": [c_int, P(DwArgs), c_void_p],
     "mpmae_dwconv7_wgrad": [c_int, P(DwWgArgs), c_int, c_void_p],
     "mpmae_dwstride_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -9,6 +9,7 @@
 #include "dwconv2.cuh"
 #include "dwconv3.cuh"
 #include "rows2.cuh"
+#include "rs.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -554,4 +555,68 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
     if (mode == 1) launch_reduce(0, ws + (size_t)rblocks * H, rblocks, H, s1, nullptr, 0, 0, 0, 0, S_(s));
   }
   RET();
+}
+
+// ------------------------------------------------------------------------------------------
+// row-streaming fused pointwise kernels
+// ------------------------------------------------------------------------------------------
+template <int KC, int HN>
+static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
+  RsP p;
+  p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
+  p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
+  p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
+  const int ngroups = a.M / 16;
+  if (which == 0 || which == 1) {
+    constexpr int KS = (KC + 31) / 32, LDW = KS * 32 + 8, SLD = HN + 8;
+    int nw = 8;
+    size_t lds = (size_t)HN * LDW * 2 + (size_t)nw * 16 * SLD * 2 + 2 * HN * 4;
+    if (lds > 160 * 1024) { nw = 4; lds = (size_t)HN * LDW * 2 + (size_t)nw * 16 * SLD * 2 + 2 * HN * 4; }
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    int blocks = 256 * (per_cu > 2 ? 2 : per_cu);
+    if (blocks > cdiv(ngroups, nw)) blocks = cdiv(ngroups, nw);
+    const size_t need = (size_t)blocks * HN * (which == 1 ? 2 : 1);
+    if (!a.ws || a.ws_floats < need) return (int)hipErrorInvalidValue;
+    if (which == 0) {
+      static bool once = false;
+      if (!once) { if (hipFuncSetAttribute((const void*)rs_wide_kernel<KC, HN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
+      hipLaunchKernelGGL((rs_wide_kernel<KC, HN, 0>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      launch_reduce(0, a.ws, blocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+    } else {
+      static bool once = false;
+      if (!once) { if (hipFuncSetAttribute((const void*)rs_wide_kernel<KC, HN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
+      hipLaunchKernelGGL((rs_wide_kernel<KC, HN, 1>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      launch_reduce(0, a.ws, blocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+      launch_reduce(0, a.ws + (size_t)blocks * HN, blocks, HN, a.s1, nullptr, 0, 0, 0, 0, st);
+    }
+  } else {
+    constexpr int NT = (KC + 15) / 16, NP = NT * 16, LDW = HN + 8, SLD = NP + 8;
+    const int nw = 8;
+    const size_t lds = (size_t)NP * LDW * 2 + 2 * HN * 4 + 2 * NP * 4 + (size_t)nw * 16 * SLD * 2;
+    const int per_cu = (int)((160 * 1024) / lds) > 0 ? (int)((160 * 1024) / lds) : 1;
+    int blocks = 256 * (per_cu > 2 ? 2 : per_cu);
+    if (blocks > cdiv(ngroups, nw)) blocks = cdiv(ngroups, nw);
+    if (which == 2) {
+      static bool once = false;
+      if (!once) { if (hipFuncSetAttribute((const void*)rs_narrow_kernel<KC, HN, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
+      hipLaunchKernelGGL((rs_narrow_kernel<KC, HN, 0, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
+    } else {
+      if (!a.ws || a.ws_floats < (size_t)blocks * 2 * KC) return (int)hipErrorInvalidValue;
+      static bool once = false;
+      if (!once) { if (hipFuncSetAttribute((const void*)rs_narrow_kernel<KC, HN, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
+      hipLaunchKernelGGL((rs_narrow_kernel<KC, HN, 1, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
+      if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+      launch_reduce(1, a.ws, blocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
+  if (!a || which < 0 || which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;
+  if (a->C == 40 && a->H == 160) return launch_rs<40, 160>(which, *a, S_(s));
+  if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
+  if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));
+  return (int)hipErrorInvalidValue;
 }

@@ -50,6 +50,7 @@ class Engine:
         self.device = torch.device(device)
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
+        self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
         self.L = cfg.num_patches
         self.grid = cfg.grid
@@ -362,6 +363,19 @@ class Engine:
         self._op(lst, name, self.lib.mpmae_wgrad, self.dt, PRO[ppro], PRO[qpro], C.byref(a), splits,
                  kind=f"wgrad<{ppro},{qpro}>", nbytes=p_bytes + q_bytes + N_ * K_ * 4, flops=2 * M_ * N_ * K_)
 
+    def _rs_ok(self, blk):
+        return (self.dt == BF16 and blk["sparse"] and (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384))
+                and blk["M"] % 16 == 0 and not self.disable_rs)
+
+    def _rs(self, lst, name, which, blk, nbytes, flops, **kw):
+        a = _lib.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H = blk["M"], blk["C"], blk["H"]
+        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+        self._keepalive.append(a)
+        self._op(lst, name, self.lib.mpmae_rs, which, C.byref(a), kind=f"rs<{which}>", nbytes=nbytes, flops=flops)
+
     def _geom(self, stage):
         g = _lib.Geom()
         if stage is None:      # dense decoder grid
@@ -448,9 +462,20 @@ class Engine:
             blk["xn"] = self._t(M, Cc)
             blk["z"] = self._t(M, H)
         self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
-        self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]), _p(blk["xn"]),
-                 _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, 1e-6, M, Cc, _p(act), kind="ln_fwd", nbytes=3 * M * Cc * esz)
-        if blk["sparse"]:      # single statistics group: column sums ride in the GEMM epilogue
+        rs = self._rs_ok(blk)
+        blk["rs"] = rs
+        if rs:   # LN + pwconv1 + GELU^2 column sums in one row-streaming kernel
+            self._rs(lst, tag + ":ln+pw1", 0, blk, (3 * M * Cc + M * H) * esz, 2 * M * Cc * H, A=blk["d"],
+                     W=self.w[tag + ".W1"]["t"], ldw=self.w[tag + ".W1"]["ld"], bias=P[nm["b1"]], v0=P[nm["ln_w"]],
+                     v1=P[nm["ln_b"]], out=blk["h"], xhat=blk["dhat"], xn=blk["xn"], rstd=blk["rstd"], act=act,
+                     s0=blk["G2"])
+        else:
+            self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]),
+                     _p(blk["xn"]), _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, 1e-6, M, Cc, _p(act), kind="ln_fwd",
+                     nbytes=3 * M * Cc * esz)
+        if rs:
+            pass
+        elif blk["sparse"]:      # single statistics group: column sums ride in the GEMM epilogue
             self._gemm(lst, tag + ":pw1", "NONE", "GELU_SUMSQ", A=blk["xn"], B=self.w[tag + ".W1"]["t"],
                        bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
                        rpg=rpg, s0=blk["G2"], act=act)
@@ -463,8 +488,13 @@ class Engine:
                  _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                  _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
-        self._gemm(lst, tag + ":pw2", "NONE", "RESID", A=blk["z"], B=self.w[tag + ".W2"]["t"], bias=P[nm["b2"]],
-                   C=blk["out"], R=x, M=M, N=Cc, K=H, lda=H, ldb=self.w[tag + ".W2"]["ld"], ldc=Cc, ldr=Cc, act=act)
+        if rs:
+            self._rs(lst, tag + ":pw2", 2, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["z"],
+                     W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], out=blk["out"], R=x,
+                     act=act)
+        else:
+            self._gemm(lst, tag + ":pw2", "NONE", "RESID", A=blk["z"], B=self.w[tag + ".W2"]["t"], bias=P[nm["b2"]],
+                       C=blk["out"], R=x, M=M, N=Cc, K=H, lda=H, ldb=self.w[tag + ".W2"]["ld"], ldc=Cc, ldr=Cc, act=act)
         return blk["out"]
 
     def _block_bwd_mat(self, lst, blk, dout, dx):
@@ -479,7 +509,11 @@ class Engine:
         dxn = self.scr_dxn[:M * Cc]
         dd = self.scr_dd[:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
-        if blk["sparse"]:
+        rs = blk.get("rs", False)
+        if rs:
+            self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + 2 * M * H) * esz, 2 * M * Cc * H, A=dout, W=w2t["t"],
+                     ldw=w2t["ld"], out=dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
+        elif blk["sparse"]:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
                        K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
         else:
@@ -494,13 +528,19 @@ class Engine:
                  _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
         self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
                  _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
-        self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
-                   ldb=w1t["ld"], ldc=Cc)
+        if rs:   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
+            self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
+                     W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
+                     s0=Gd[nm["ln_w"]], s1=Gd[nm["ln_b"]])
+        else:
+            self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
+                       ldb=w1t["ld"], ldc=Cc)
         self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
                     dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
-                 _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
-                 _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
+        if not rs:
+            self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+                     _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
+                     _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
         self._dw_bwd(lst, blk, dd, dout, dx)
 
     def _dw_bwd(self, lst, blk, dd, dout, dx):
