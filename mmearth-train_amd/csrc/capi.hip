@@ -79,6 +79,7 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
   }
   GEMM_CASE(PRO_NONE, EPI_STORE)
   GEMM_CASE(PRO_NONE, EPI_RESID)
+  GEMM_CASE(PRO_NONE, EPI_GELU_SUMSQ)
   GEMM_CASE(PRO_NONE, EPI_SCATTER_ROWS)
   GEMM_CASE(PRO_NONE, EPI_DZ_STATS)
   GEMM_CASE(PRO_NONE, EPI_DOWN_DGRAD)

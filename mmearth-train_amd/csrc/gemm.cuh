@@ -87,8 +87,15 @@ __device__ __forceinline__ void load_a8(const GemmP& p, int m, int k, float (&o)
   if (k + 8 <= p.K) ld8<T>(ap, o);
   else { for (int i = 0; i < 8 && k + i < p.K; ++i) o[i] = ldf<T>(ap + i); }
   if constexpr (PRO == PRO_LN_AFFINE || PRO == PRO_DOWN_GATHER) {
+    if (k + 8 <= p.K) {      // unconditional 16-byte parameter loads (scalar loads under a branch serialise)
+      const float4 g0 = *reinterpret_cast<const float4*>(p.p0 + kc), g1 = *reinterpret_cast<const float4*>(p.p0 + kc + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(p.p1 + kc), b1 = *reinterpret_cast<const float4*>(p.p1 + kc + 4);
+      o[0] = o[0] * g0.x + b0.x; o[1] = o[1] * g0.y + b0.y; o[2] = o[2] * g0.z + b0.z; o[3] = o[3] * g0.w + b0.w;
+      o[4] = o[4] * g1.x + b1.x; o[5] = o[5] * g1.y + b1.y; o[6] = o[6] * g1.z + b1.z; o[7] = o[7] * g1.w + b1.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) if (k + i < p.K) o[i] = o[i] * p.p0[kc + i] + p.p1[kc + i];
+      for (int i = 0; i < 8; ++i) if (k + i < p.K) o[i] = o[i] * p.p0[kc + i] + p.p1[kc + i];
+    }
   }
   if constexpr (PRO == PRO_GRN) {
     const int g = m / p.rpg;

@@ -90,19 +90,76 @@ __device__ __forceinline__ void loss_pix_cont_patch(const PixContP& q, int b, fl
   }
 }
 
+// forward, wave-granular: each of the 4 waves of a sample's block walks patches l = wave, wave+4, ...
+// with wave-level reductions only; the block combines the four partials once at the end.
+template <typename T>
+__device__ __forceinline__ void loss_pix_cont_patch_wave(const PixContP& q, int b, float& acc_s, float& acc_c) {
+  const int lane = threadIdx.x & 63;
+  const int n = b / q.L, l = b - n * q.L;
+  const int py = l / q.grid, px = l - py * q.grid;
+  const int p = q.p, C = q.C, PP = p * p, J = PP * C;
+  const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+  if (q.mask[b] == 0.f) {
+    if (lane == 0) { q.patch_l[b] = 0.f; q.patch_cnt[b] = 0.f; q.patch_mean[b] = 0.f; q.patch_rstd[b] = 1.f; }
+    return;
+  }
+  const float* tg = q.target + ((size_t)n * C * q.H + py * p) * q.H + px * p;
+  float mean = 0.f, rstd = 1.f;
+  if (q.norm_pix) {
+    float s = 0.f, s2 = 0.f;
+    for (int i = lane; i < J; i += 64) {
+      const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+      const float t = nan_to_num0(tg[((size_t)c * q.H + ph) * q.H + pw]);
+      s += t; s2 += t * t;
+    }
+    s = wave_sum(s); s2 = wave_sum(s2);
+    mean = s / J;
+    // unbiased variance; two-pass form for accuracy
+    float v = 0.f;
+    for (int i = lane; i < J; i += 64) {
+      const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+      const float d = nan_to_num0(tg[((size_t)c * q.H + ph) * q.H + pw]) - mean;
+      v += d * d;
+    }
+    v = wave_sum(v);
+    rstd = 1.f / sqrtf(v / (J - 1) + 1.0e-6f);
+  }
+  float se = 0.f, cnt = 0.f;
+  for (int i = lane; i < J; i += 64) {
+    const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+    float t = nan_to_num0(tg[((size_t)c * q.H + ph) * q.H + pw]);
+    t = (t - mean) * rstd;
+    const float d = ldf<T>(pred + (ph * p + pw) * C + c) - t;
+    const float e = d * d;
+    if (!isnan(e)) { se += e; cnt += 1.f; }
+  }
+  se = wave_sum(se); cnt = wave_sum(cnt);
+  const float lp = se / cnt;
+  const float qv = lp * q.mask[b];
+  const bool counted = !isnan(qv) && qv != 0.f;
+  if (lane == 0) {
+    q.patch_l[b] = counted ? lp : 0.f;
+    q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
+  }
+  if (counted) { acc_s += qv; acc_c += 1.f; }
+}
+
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
   __shared__ float sh[4];
+  __shared__ float part[4][2];
   float as = 0.f, ac = 0.f;
   if constexpr (BWD) {
     loss_pix_cont_patch<T, true>(q, blockIdx.x, sh, as, ac);
   } else {
-    const int n = blockIdx.x;
-    for (int l = 0; l < q.L; ++l) {
-      loss_pix_cont_patch<T, false>(q, n * q.L + l, sh, as, ac);
-      __syncthreads();
+    const int n = blockIdx.x, wave = threadIdx.x >> 6;
+    for (int l = wave; l < q.L; l += 4) loss_pix_cont_patch_wave<T>(q, n * q.L + l, as, ac);
+    if ((threadIdx.x & 63) == 0) { part[wave][0] = as; part[wave][1] = ac; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      q.acc[2 * n] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
+      q.acc[2 * n + 1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
     }
-    if (threadIdx.x == 0) { q.acc[2 * n] = as; q.acc[2 * n + 1] = ac; }
   }
 }
 
