@@ -10,6 +10,7 @@
 #include "dwconv3.cuh"
 #include "rows2.cuh"
 #include "rs.cuh"
+#include "dwconv4.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -258,8 +259,41 @@ static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
   else hipLaunchKernelGGL((dwconv7_wgrad_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
 }
 
+template <typename T, int S>
+static void launch_dw_v4(const MpmaeDwArgs& a, hipStream_t st) {
+  using D = Dw4<S>;
+  const int chunks = a.C / D::CW;
+  int nw = 1;
+  for (int d = 8; d >= 1; --d) if (chunks % d == 0) { nw = d; break; }
+  const size_t lds = ((D::HP + 3) & ~3) * sizeof(int) +
+                     (size_t)nw * (D::HP * D::CW * sizeof(T) + (S > 1 ? 49 * D::CW * sizeof(float) : 0));
+  dim3 g(a.g.N * a.g.keep, chunks / nw);
+  hipLaunchKernelGGL((dwconv7_v4_kernel<T, S>), g, dim3(64 * nw), lds, st, a);
+}
+
+template <typename T, int S>
+static void launch_dwwg_v4(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
+  using D = Dw4<S>;
+  dim3 g(nblocks, a.C / D::CW);
+  hipLaunchKernelGGL((dwconv7_wgrad_v4_kernel<T, S>), g, dim3(64), 0, st, a);
+}
+
+static bool dw_v4_ok(int C, int S) {
+  // per-visible-patch tiles pay for S >= 2; at S == 1 (stage 3, dense decoder) every output would drag
+  // its own 49-point halo, so the positional 8x8 tiles of dwconv3.cuh are used there
+  if (S != 8 && S != 4 && S != 2) return false;
+  return C % (64 / S) == 0;
+}
+
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dw_v4_ok(a->C, a->g.S)) {
+#define DW4(TT) do { switch (a->g.S) { case 8: launch_dw_v4<TT, 8>(*a, S_(s)); break; case 4: launch_dw_v4<TT, 4>(*a, S_(s)); break; \
+                                      case 2: launch_dw_v4<TT, 2>(*a, S_(s)); break; default: launch_dw_v4<TT, 1>(*a, S_(s)); } } while (0)
+    if (dt == 0) DW4(float); else DW4(bf16_t);
+#undef DW4
+    RET();
+  }
   if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
     const int chunks = a->C / 8;
     const int nw = chunks <= 8 ? chunks : (chunks % 5 == 0 ? 5 : 8);      // waves per block sharing the tables
@@ -289,6 +323,19 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dw_v4_ok(a->C, a->g.S)) {
+    const size_t per = (size_t)50 * a->C;
+    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
+    const int npatches = a->g.N * a->g.keep;
+    if (nblocks > npatches) nblocks = npatches;
+    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
+#define DWW4(TT) do { switch (a->g.S) { case 8: launch_dwwg_v4<TT, 8>(*a, nblocks, S_(s)); break; case 4: launch_dwwg_v4<TT, 4>(*a, nblocks, S_(s)); break; \
+                                       case 2: launch_dwwg_v4<TT, 2>(*a, nblocks, S_(s)); break; default: launch_dwwg_v4<TT, 1>(*a, nblocks, S_(s)); } } while (0)
+    if (dt == 0) DWW4(float); else DWW4(bf16_t);
+#undef DWW4
+    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
+    RET();
+  }
   if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
