@@ -176,7 +176,7 @@ def main():
                       f"{gbs:8.0f} GB/s {tfs:8.1f} TFLOP/s  {100 * d['ms'] / tot:5.1f}%", file=sys.stderr)
         if a.profile_names:
             byn = per_kernel_times(eng, by_name=True)
-            for k, d in sorted(byn.items(), key=lambda kv: -kv[1]["ms"])[:70]:
+            for k, d in sorted(byn.items(), key=lambda kv: -kv[1]["ms"])[:400]:
                 gbs = d["bytes"] / max(d["ms"], 1e-9) / 1e6
                 tfs = d["flops"] / max(d["ms"], 1e-9) / 1e9
                 print(f"{k:58s} {d['ms'] / 3 * 1e3:9.1f} us {gbs:8.0f} GB/s {tfs:8.1f} TF/s", file=sys.stderr)

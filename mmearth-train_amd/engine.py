@@ -51,6 +51,10 @@ class Engine:
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
+        self.concurrent = (self.device.type == "cuda")   # weight gradients on a side HIP stream
+        self.lanes = self.concurrent and (block_mode or ("mat" if self.dt == BF16 else "fused")) == "mat"
+        self._side_readers = {}
+        self._evseq = 0
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
         self.L = cfg.num_patches
         self.grid = cfg.grid
@@ -215,15 +219,18 @@ class Engine:
         # backward scratch
         maxMH = max(b["M"] * b["H"] for b in self.blocks + [self.dec])
         maxMC = max(max(b["M"] * b["C"] for b in self.blocks + [self.dec]), self.Mfull * C0)
-        self.scr_dz = self._t(maxMH)
+        self.scr_dz2 = [self._t(maxMH), self._t(maxMH)]   # dz / dh, alternating per block (side lane reads dh)
+        self.scr_dz = self.scr_dz2[0]
         self.scr_dxn = self._t(maxMC)
-        self.scr_dd = self._t(maxMC)
+        self.scr_dd2 = [self._t(maxMC), self._t(maxMC)]   # dd, alternating per block (side lane reads it)
+        self.scr_dd = self.scr_dd2[0]
         self.scr_dxA = self._t(maxMC)
         self.scr_dxB = self._t(maxMC)
         self.dy = self._t(N * L, D)
         # fp32 scratch for the two-stage reductions (per-block / per-split partial slabs)
         self.ws_floats = 32 * 1024 * 1024
         self.ws = torch.empty(self.ws_floats, dtype=f32, device=dev)
+        self.ws2 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # side-lane (weight-gradient) scratch
 
     def _alloc_block(self, prefix, M, Cc, G, stage, sparse):
         H = 4 * Cc
@@ -324,10 +331,56 @@ class Engine:
         *a, stream = args
         return self.lib.mpmae_colstats(*a, _p(self.ws), self.ws_floats, stream)
 
-    def _op(self, lst, name, fn, *args, kind=None, nbytes=0, flops=0):
+    def _op(self, lst, name, fn, *args, kind=None, nbytes=0, flops=0, lane=0, wait=(), signal=None):
         """Append one C-ABI launch; `kind` names the kernel, nbytes/flops are its ALGORITHMIC
-        traffic (operands read once + results written once) and work, for the roofline report."""
-        lst.append((name, fn, args, dict(kind=kind or fn.__name__, bytes=int(nbytes), flops=int(flops))))
+        traffic (operands read once + results written once) and work, for the roofline report.
+        lane 0 = main dependency chain, lane 1 = side HIP stream (weight gradients); `wait` /
+        `signal` are event keys ordering the two lanes (see _run)."""
+        lst.append((name, fn, args, dict(kind=kind or fn.__name__, bytes=int(nbytes), flops=int(flops), lane=lane,
+                                         wait=tuple(wait), signal=signal)))
+
+    # -- cross-lane hazard tracking (build time) --------------------------------------------
+    def _side_read(self, key, *tensors):
+        """A side-lane op (signalling `key` when done) reads these scratch tensors."""
+        for t in tensors:
+            self._side_readers.setdefault(t.untyped_storage().data_ptr(), []).append(key)
+
+    def _after(self, lst):
+        """Event key signalled by the most recent main-lane op of `lst` (its results are ready)."""
+        for i in range(len(lst) - 1, -1, -1):
+            m = lst[i][3]
+            if m["lane"] == 0:
+                if m["signal"] is None:
+                    self._evseq += 1
+                    m["signal"] = f"m{self._evseq}"
+                return m["signal"]
+        return None
+
+    def _guard(self, lst, *tensors):
+        """The op just appended (main lane) overwrites these scratch tensors: make it wait for every
+        side-lane op still reading them."""
+        keys = self._write_waits(*tensors)
+        if keys:
+            m = lst[-1][3]
+            m["wait"] = tuple(m["wait"]) + tuple(keys)
+
+    def _side_wgrad(self, lst, name, ppro, qpro, reads, **kw):
+        """Weight gradient on the side lane: starts once the latest main-lane op has finished,
+        and protects the scratch tensors it reads (`reads`) from later main-lane writers."""
+        if not self.lanes:
+            return self._wgrad(lst, name, ppro, qpro, **kw)
+        k = self._after(lst)
+        self._evseq += 1
+        key = f"s{self._evseq}"
+        self._wgrad(lst, name, ppro, qpro, lane=1, wait=(k,) if k else (), signal=key, **kw)
+        self._side_read(key, *reads)
+
+    def _write_waits(self, *tensors):
+        """Event keys a main-lane op must wait for before overwriting these scratch tensors."""
+        keys = []
+        for t in tensors:
+            keys += self._side_readers.pop(t.untyped_storage().data_ptr(), [])
+        return keys
 
     def _gemm(self, lst, name, pro, epi, **kw):
         a = _lib.GemmArgs()
@@ -346,7 +399,7 @@ class Engine:
         self._op(lst, name, self.lib.mpmae_gemm, self.dt, PRO[pro], EPI[epi], C.byref(a),
                  kind=f"gemm<{pro},{epi}>", nbytes=a_bytes + c_bytes + N_ * K_ * esz, flops=2 * M_ * N_ * K_)
 
-    def _wgrad(self, lst, name, ppro, qpro, **kw):
+    def _wgrad(self, lst, name, ppro, qpro, lane=0, wait=(), signal=None, **kw):
         a = _lib.WgradArgs()
         for k, v in kw.items():
             setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
@@ -354,14 +407,15 @@ class Engine:
             a.rpg = max(int(a.M), 1)
         tiles = ((a.Nn + 63) // 64) * ((a.Kk + 63) // 64)
         splits = max(1, min((768 + tiles - 1) // tiles, (a.M + 255) // 256))
-        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+        a.ws, a.ws_floats = (self.ws2 if lane == 1 else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
         esz = 4 if self.dt == F32 else 2
         M_, N_, K_ = int(a.M), int(a.Nn), int(a.Kk)
         p_bytes = M_ * N_ * esz * (2 if ppro == "GRN_BWD" else 1)
         q_bytes = M_ * int(a.Cseg) * 4 if qpro == "IM2COL3" else M_ * K_ * esz
         self._op(lst, name, self.lib.mpmae_wgrad, self.dt, PRO[ppro], PRO[qpro], C.byref(a), splits,
-                 kind=f"wgrad<{ppro},{qpro}>", nbytes=p_bytes + q_bytes + N_ * K_ * 4, flops=2 * M_ * N_ * K_)
+                 kind=f"wgrad<{ppro},{qpro}>", nbytes=p_bytes + q_bytes + N_ * K_ * 4, flops=2 * M_ * N_ * K_,
+                 lane=lane, wait=wait, signal=signal)
 
     def _rs_ok(self, blk):
         return (self.dt == BF16 and blk["sparse"] and (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384))
@@ -505,9 +559,10 @@ class Engine:
         rpg = M if blk["sparse"] else self.L
         tag = blk["prefix"]
         esz = 4 if dt == F32 else 2
-        dz = self.scr_dz[:M * H]
+        t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1      # dz / dd alternate per block: the side lane reads them
+        dz = self.scr_dz2[t & 1][:M * H]
         dxn = self.scr_dxn[:M * Cc]
-        dd = self.scr_dd[:M * Cc]
+        dd = self.scr_dd2[t & 1][:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
         rs = blk.get("rs", False)
         if rs:
@@ -519,7 +574,8 @@ class Engine:
         else:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
                        ldb=w2t["ld"], ldc=H)
-        self._wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
+        self._guard(lst, dz)
+        self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
                     dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
         if not blk["sparse"]:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
@@ -535,12 +591,14 @@ class Engine:
         else:
             self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
                        ldb=w1t["ld"], ldc=Cc)
-        self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
+        self._guard(lst, dd)
+        self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
                     dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
         if not rs:
             self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
+            self._guard(lst, dd)
         self._dw_bwd(lst, blk, dd, dout, dx)
 
     def _dw_bwd(self, lst, blk, dd, dout, dx):
@@ -558,11 +616,20 @@ class Engine:
         a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
         a.ntiles_total = self.N * ts * ts
         a.act = act.data_ptr() if act is not None else 0
-        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+        a.ws, a.ws_floats = (self.ws2 if self.lanes else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
-        self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
-                 nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
+        if self.lanes:
+            k = self._after(lst)
+            self._evseq += 1
+            key = f"s{self._evseq}"
+            self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
+                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc, lane=1, wait=(k,), signal=key)
+            self._side_read(key, dd)
+        else:
+            self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
+                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
         self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
+        self._guard(lst, dx)
 
     def _block_fwd_fused(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
@@ -764,7 +831,7 @@ class Engine:
         ldp = self.pred_pix.shape[1]
         for om in cfg.pix_mods:
             pv = self.dpred_pix.view(-1)[self.head_cols[om.name]:]
-            self._wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", P=pv, Q=y, M=N * L, Nn=om.head_out, Kk=D, ldp=ldp,
+            self._side_wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", [], P=pv, Q=y, M=N * L, Nn=om.head_out, Kk=D, ldp=ldp,
                         ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1, db=Gd[f"pred_dict.{om.name}.bias"])
         have_pix = bool(cfg.pix_mods)
         if have_pix:
@@ -774,7 +841,7 @@ class Engine:
         if cfg.img_mods:
             for om in cfg.img_mods:
                 pv = self.dpred_img.view(-1)[self.head_cols[om.name]:]
-                self._wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", P=pv, Q=self.pooled, M=N, Nn=om.head_out, Kk=D,
+                self._side_wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", [], P=pv, Q=self.pooled, M=N, Nn=om.head_out, Kk=D,
                             ldp=self.ldimg, ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1,
                             db=Gd[f"pred_dict.{om.name}.bias"])
             wt = self.w["head.imgT"]
@@ -787,13 +854,14 @@ class Engine:
         dxdec = self.scr_dxA[:N * L * D]
         self._block_bwd(b, self.dec, self.dy, dxdec)
         self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D)
-        self._wgrad(b, "proj.wgrad", "ROW_GATHER", "NONE", P=dxdec, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
+        self._side_wgrad(b, "proj.wgrad", "ROW_GATHER", "NONE", [dxdec], P=dxdec, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
                     ldq=dims[3], dW=Gd["proj.weight"], sn=dims[3], sk=1, db=Gd["proj.bias"], vis=self.vis,
                     keep=self.keep, L=L)
         wpt = self.w["proj.WT"]
         cur = self.scr_dxB[:self.M[3] * dims[3]]
         self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
                    ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
+        self._guard(b, cur)
         other = self.scr_dxA
         bi = len(self.blocks) - 1
         for i in range(3, -1, -1):
@@ -808,7 +876,7 @@ class Engine:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
                 Ci, Co = dims[i - 1], dims[i]
-                self._wgrad(b, pre + ":wgrad", "NONE", "DOWN_GATHER", P=cur, Q=dn["xhat"], M=self.M[i], Nn=Co, Kk=4 * Ci,
+                self._side_wgrad(b, pre + ":wgrad", "NONE", "DOWN_GATHER", [cur], P=cur, Q=dn["xhat"], M=self.M[i], Nn=Co, Kk=4 * Ci,
                             ldp=Co, ldq=Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"],
                             qp0=P[pre + ".0.ln.weight"], qp1=P[pre + ".0.ln.bias"], S=self.S[i], Cseg=Ci,
                             act_src=self.act[i - 1])
@@ -820,6 +888,7 @@ class Engine:
                 self._op(b, pre + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
                          _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
                          _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
+                self._guard(b, nxt)
                 other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
                 cur = nxt
         # stem
@@ -828,6 +897,7 @@ class Engine:
         self._op(b, "stem:ln2.bwd", self._ln_bwd_fn, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
                  _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, _p(ds), 0,
                  _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
+        self._guard(b, ds)
         da1 = self.scr_dxn[:self.Mfull * C0]
         self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
                  _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full),
@@ -837,6 +907,7 @@ class Engine:
                  _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
                  _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
                  _p(self.act_full))
+        self._guard(b, dc1)
         self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,
                     Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,
                     db=Gd["encoder.initial_conv.0.bias"], vis=self.vis, inv=self.inv, keep=self.keep, L=L, S=self.p,
@@ -846,11 +917,40 @@ class Engine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _run(self, ops, stream):
-        for name, fn, args, _ in ops:
-            err = fn(*args, stream)
+    def _run(self, ops, stream=None):
+        """Enqueue a launch program. Lane-1 ops (weight gradients) go to a side HIP stream forked
+        from the current stream and ordered by events; the side stream is joined at the end, so a
+        program is self-contained (and capturable into one HIP graph with parallel branches)."""
+        two = self.concurrent and any(m["lane"] == 1 for _, _, _, m in ops)
+        main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
+        if not two:
+            st = C.c_void_p(main.cuda_stream) if main is not None else stream
+            for name, fn, args, _ in ops:
+                err = fn(*args, st)
+                if err != 0:
+                    raise _lib.HipLibraryError(f"{name}: hipError {err}")
+            return
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        side.wait_stream(main)                     # fork
+        streams = (main, side)
+        handles = (C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream))
+        events = {}
+        for name, fn, args, m in ops:
+            lane = m["lane"]
+            for key in m["wait"]:
+                ev = events.get(key)
+                if ev is not None:                 # recorded earlier in THIS program (else: already joined)
+                    streams[lane].wait_event(ev)
+            err = fn(*args, handles[lane])
             if err != 0:
                 raise _lib.HipLibraryError(f"{name}: hipError {err}")
+            if m["signal"] is not None:
+                ev = torch.cuda.Event()
+                ev.record(streams[lane])
+                events[m["signal"]] = ev
+        main.wait_stream(side)                     # join
 
     def set_inputs(self, imgs_dict, noise):
         """Copy a (cropped) batch and the mask noise into the engine's static device buffers."""
