@@ -88,6 +88,31 @@ def per_kernel_times(eng, reps=3, by_name=False):
     return acc
 
 
+# bench "kind" -> HIP kernel symbol (as rocprofv3 prints it) of the launch that moves the data
+KIND_TO_KERNEL = {
+    "wgrad<NONE,NONE>": "gemm_tn_bf16_kernel",
+    "dwconv7": "dwconv7_v5_kernel",
+    "dwconv7_wgrad": "dwconv7_wgrad_v5_kernel",
+    "grn_apply": "grn_apply_kernel",
+    "grn_bwd_apply": "grn_bwd_apply_kernel",
+}
+
+
+def pmc_traffic(kind, path=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "pmc_traffic.json")):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py); None when that kernel was not sampled."""
+    sym = KIND_TO_KERNEL.get(kind)
+    if sym is None or not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    tot = n = 0
+    for name, d in ks.items():
+        if sym in name:
+            tot += d["traffic_bytes"] * d["launches_sampled"]
+            n += d["launches_sampled"]
+    return int(tot / n) if n else None
+
+
 def cpu_baseline(cfg, batch, steps):
     """Oracle (CPU restatement, kind 'port') forward+backward+AdamW on the host cores."""
     from oracle import mpmae_ref as O
@@ -182,8 +207,10 @@ def main():
                 print(f"{k:58s} {d['ms'] / 3 * 1e3:9.1f} us {gbs:8.0f} GB/s {tfs:8.1f} TF/s", file=sys.stderr)
         key = (a.model, a.img, a.subset)
         step_roof = STEP_ROOFLINE_US.get(key)
+        traffic = pmc_traffic(dom_kind)
         roof = dict(bound="hbm", kernel=dom_kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    algorithmic_bytes=int(avg_bytes),
                     kernel_avg_us=round(avg_ms * 1e3, 2), kernel_launches_per_step=dom["n"] // 3,
                     kernel_share_of_step=round(dom["ms"] / tot, 3))
         if step_roof and a.batch == 256:

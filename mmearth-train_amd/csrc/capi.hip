@@ -10,7 +10,7 @@
 #include "dwconv3.cuh"
 #include "rows2.cuh"
 #include "rs.cuh"
-#include "dwconv4.cuh"
+#include "dwconv5.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -278,6 +278,51 @@ static void launch_dwwg_v4(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
   hipLaunchKernelGGL((dwconv7_wgrad_v4_kernel<T, S>), g, dim3(64), 0, st, a);
 }
 
+// v5 (one sample's whole map in LDS): returns false when the map does not fit / the attribute cannot be raised
+template <typename T, int S>
+static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
+  constexpr int CW = 64 / S;
+  const size_t lds = dw5_map_bytes<T, S>(a.g.grid) + 49 * CW * sizeof(float);
+  if (lds > 160 * 1024 - 512) return false;
+  static size_t cur = 64 * 1024;
+  if (lds > cur) {
+    if (hipFuncSetAttribute((const void*)dwconv7_v5_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    cur = lds;
+  }
+  dim3 g(a.g.N, a.C / CW);
+  hipLaunchKernelGGL((dwconv7_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  return true;
+}
+
+template <typename T, int S>
+static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
+  constexpr int CW = 64 / S;
+  size_t lds = dw5_map_bytes<T, S>(a.g.grid);
+  const size_t red = (size_t)4 * 50 * CW * sizeof(float);
+  if (red > lds) lds = red;
+  if (lds > 160 * 1024 - 512) return false;
+  static size_t cur = 64 * 1024;
+  if (lds > cur) {
+    if (hipFuncSetAttribute((const void*)dwconv7_wgrad_v5_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    cur = lds;
+  }
+  dim3 g(nblocks, a.C / CW);
+  hipLaunchKernelGGL((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  return true;
+}
+
+static int dw_variant() {      // MPMAE_DW=4 forces the per-patch kernels (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MPMAE_DW"); v = e ? atoi(e) : 5; }
+  return v;
+}
+
 static bool dw_v4_ok(int C, int S) {
   // per-visible-patch tiles pay for S >= 2; at S == 1 (stage 3, dense decoder) every output would drag
   // its own 49-point halo, so the positional 8x8 tiles of dwconv3.cuh are used there
@@ -287,6 +332,14 @@ static bool dw_v4_ok(int C, int S) {
 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
+    bool ok = false;
+#define DW5(TT) do { switch (a->g.S) { case 8: ok = launch_dw_v5<TT, 8>(*a, S_(s)); break; case 4: ok = launch_dw_v5<TT, 4>(*a, S_(s)); break; \
+                                      default: ok = launch_dw_v5<TT, 2>(*a, S_(s)); } } while (0)
+    if (dt == 0) DW5(float); else DW5(bf16_t);
+#undef DW5
+    if (ok) RET();
+  }
   if (dw_v4_ok(a->C, a->g.S)) {
 #define DW4(TT) do { switch (a->g.S) { case 8: launch_dw_v4<TT, 8>(*a, S_(s)); break; case 4: launch_dw_v4<TT, 4>(*a, S_(s)); break; \
                                       case 2: launch_dw_v4<TT, 2>(*a, S_(s)); break; default: launch_dw_v4<TT, 1>(*a, S_(s)); } } while (0)
@@ -323,6 +376,21 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
+    const size_t per = (size_t)50 * a->C;
+    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
+    int nb = a->g.N < 128 ? a->g.N : 128;
+    if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
+    bool ok = false;
+#define DWW5(TT) do { switch (a->g.S) { case 8: ok = launch_dwwg_v5<TT, 8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v5<TT, 4>(*a, nb, S_(s)); break; \
+                                       default: ok = launch_dwwg_v5<TT, 2>(*a, nb, S_(s)); } } while (0)
+    if (dt == 0) DWW5(float); else DWW5(bf16_t);
+#undef DWW5
+    if (ok) {
+      launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
+      RET();
+    }
+  }
   if (dw_v4_ok(a->C, a->g.S)) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;

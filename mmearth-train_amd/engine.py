@@ -15,6 +15,7 @@ Reference call path reproduced (paths relative to /root/reference):
   forward_loss             models/fcmae.py:267-412, custom_loss.py:19-30
   backward / optimizer     engine_pretrain.py:87-94, main_pretrain.py:312-320
 """
+import os
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -53,6 +54,7 @@ class Engine:
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.concurrent = (self.device.type == "cuda")   # weight gradients on a side HIP stream
         self.lanes = self.concurrent and (block_mode or ("mat" if self.dt == BF16 else "fused")) == "mat"
+        self.dw_lane = int(os.environ.get("MPMAE_DW_LANE", "1"))
         self._side_readers = {}
         self._evseq = 0
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
@@ -231,6 +233,7 @@ class Engine:
         self.ws_floats = 32 * 1024 * 1024
         self.ws = torch.empty(self.ws_floats, dtype=f32, device=dev)
         self.ws2 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # side-lane (weight-gradient) scratch
+        self.ws3 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # second side lane (depthwise weight gradients)
 
     def _alloc_block(self, prefix, M, Cc, G, stage, sparse):
         H = 4 * Cc
@@ -616,14 +619,14 @@ class Engine:
         a.C, a.CC, a.TP, a.tiles_side = Cc, CC, TP, ts
         a.ntiles_total = self.N * ts * ts
         a.act = act.data_ptr() if act is not None else 0
-        a.ws, a.ws_floats = (self.ws2 if self.lanes else self.ws).data_ptr(), self.ws_floats
+        a.ws, a.ws_floats = (self.ws3 if self.lanes else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
         if self.lanes:
             k = self._after(lst)
             self._evseq += 1
             key = f"s{self._evseq}"
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
-                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc, lane=1, wait=(k,), signal=key)
+                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc, lane=self.dw_lane, wait=(k,), signal=key)
             self._side_read(key, dd)
         else:
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
@@ -921,21 +924,23 @@ class Engine:
         """Enqueue a launch program. Lane-1 ops (weight gradients) go to a side HIP stream forked
         from the current stream and ordered by events; the side stream is joined at the end, so a
         program is self-contained (and capturable into one HIP graph with parallel branches)."""
-        two = self.concurrent and any(m["lane"] == 1 for _, _, _, m in ops)
+        nl = (max(m["lane"] for _, _, _, m in ops) + 1) if (self.concurrent and ops) else 1
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
-        if not two:
+        if nl == 1:
             st = C.c_void_p(main.cuda_stream) if main is not None else stream
             for name, fn, args, _ in ops:
                 err = fn(*args, st)
                 if err != 0:
                     raise _lib.HipLibraryError(f"{name}: hipError {err}")
             return
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream(device=self.device)
-        side = self._side_stream
-        side.wait_stream(main)                     # fork
-        streams = (main, side)
-        handles = (C.c_void_p(main.cuda_stream), C.c_void_p(side.cuda_stream))
+        if not hasattr(self, "_side_streams"):
+            self._side_streams = []
+        while len(self._side_streams) < nl - 1:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        streams = [main] + self._side_streams[:nl - 1]
+        for st in streams[1:]:
+            st.wait_stream(main)                   # fork
+        handles = [C.c_void_p(st.cuda_stream) for st in streams]
         events = {}
         for name, fn, args, m in ops:
             lane = m["lane"]
@@ -950,7 +955,8 @@ class Engine:
                 ev = torch.cuda.Event()
                 ev.record(streams[lane])
                 events[m["signal"]] = ev
-        main.wait_stream(side)                     # join
+        for st in streams[1:]:
+            main.wait_stream(st)                   # join
 
     def set_inputs(self, imgs_dict, noise):
         """Copy a (cropped) batch and the mask noise into the engine's static device buffers."""
