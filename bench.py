@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--subset", default="all_mod")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying HIP graphs")
+    ap.add_argument("--mode", default="program", choices=["program", "hipgraph", "eager"],
+                    help="step driver: native launch program (default), HIP graph replay, or the Python loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--profile-names", action="store_true", help="per-launch (by op name) time table to stderr")
@@ -59,7 +61,7 @@ def parse():
     return ap.parse_args()
 
 
-def per_kernel_times(eng, reps=3, by_name=False):
+def per_kernel_times(eng, reps=3, by_name=False, split_lanes=False):
     """Eager pass with HIP events (torch.cuda.Event on the launch stream) around every launch."""
     stream = torch.cuda.current_stream()
     acc = {}
@@ -80,7 +82,8 @@ def per_kernel_times(eng, reps=3, by_name=False):
                 evs.append((dict(meta, name=name), e0, e1))
         torch.cuda.synchronize()
         for meta, e0, e1 in evs:
-            d = acc.setdefault(meta["kind"] if not by_name else meta["name"], dict(ms=0.0, n=0, bytes=0, flops=0))
+            key = meta["name"] if by_name else meta["kind"] + (" [side]" if split_lanes and meta.get("lane") else "")
+            d = acc.setdefault(key, dict(ms=0.0, n=0, bytes=0, flops=0))
             d["ms"] += e0.elapsed_time(e1)
             d["n"] += 1
             d["bytes"] += meta["bytes"]
@@ -163,7 +166,7 @@ def main():
     inputs, noise = make_inputs(cfg, a.batch, seed=1000 + rank)
     eng.set_inputs(inputs, noise)
     torch.cuda.synchronize()
-    trainer = mdist.StepRunner(eng, world_size=world, use_graph=not a.no_graph, lr=1e-4)
+    trainer = mdist.StepRunner(eng, world_size=world, lr=1e-4, mode="eager" if a.no_graph else a.mode)
 
     for _ in range(a.warmup):
         trainer.step()
@@ -194,7 +197,11 @@ def main():
         avg_bytes = dom["bytes"] / dom["n"]
         achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         if a.profile_ops:
-            for k, d in sorted(acc.items(), key=lambda kv: -kv[1]["ms"]):
+            acc2 = per_kernel_times(eng, split_lanes=True)
+            tot2 = sum(d["ms"] for d in acc2.values())
+            side = sum(d["ms"] for k, d in acc2.items() if k.endswith("[side]"))
+            print(f"eager sum {tot2 / 3:.3f} ms/step, side lane {side / 3:.3f} ms/step", file=sys.stderr)
+            for k, d in sorted(acc2.items(), key=lambda kv: -kv[1]["ms"]):
                 gbs = d["bytes"] / max(d["ms"], 1e-9) / 1e6
                 tfs = d["flops"] / max(d["ms"], 1e-9) / 1e9
                 print(f"{k:36s} {d['ms'] / 3:9.3f} ms/step {d['n'] // 3:4d} launches "

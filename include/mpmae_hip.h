@@ -237,6 +237,31 @@ int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, f
                 float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask,
                 mpmae_stream_t stream);
 int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
+/* hyper-parameter hand-over for replayed steps: copies record (*counter % slots) of a pinned,
+ * device-visible ring of {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} records into hp and
+ * increments *counter, in stream order (the host fills slot t % slots before enqueueing step t and
+ * must not run more than `slots` steps ahead). */
+int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, mpmae_stream_t stream);
+
+/* ---- launch programs ----------------------------------------------------------------------
+ * The reference drives its step from Python (engine_pretrain.py:46-118, one autograd graph per
+ * iteration). Here a step is a fixed list of launches; a program records it once and replays it
+ * from C. While an op is open (begin_op .. next begin_op / end) every entry point of this header
+ * called from the same thread appends its fully-resolved kernel launches to the program instead of
+ * issuing them (the stream argument is ignored). run() issues ops [first, first+count) in order:
+ * lane 0 on `main`, lane k on the program's k-th side stream (forked from / joined to `main`
+ * around the call); an op first waits for the events named in `waits` that were signalled earlier
+ * in the same run() call and records its own `signal` event (ids > 0; 0 = none) when enqueued. */
+typedef struct MpmaeProgram MpmaeProgram;
+MpmaeProgram* mpmae_program_create(void);
+void mpmae_program_destroy(MpmaeProgram* p);
+int mpmae_program_begin_op(MpmaeProgram* p, int lane, const int* waits, int nwaits, int signal);
+int mpmae_program_end(MpmaeProgram* p);
+int mpmae_program_num_ops(const MpmaeProgram* p);
+int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_stream);
+/* recordable fills / host->device copies (gradient and statistics clears, the AdamW hyper-parameter record) */
+int mpmae_memset_async(void* ptr, int value, size_t bytes, mpmae_stream_t stream);
+int mpmae_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, mpmae_stream_t stream);
 
 /* library identification: returns the gfx arch the kernels were built for (950). */
 int mpmae_arch(void);

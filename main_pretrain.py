@@ -166,7 +166,7 @@ def main(args):
     if args.fast_path and args.update_freq == 1:
         eng = model._get_engine(args.batch_size)
         model._engine = eng
-        runner = mdist.StepRunner(eng, world_size=world, use_graph=True, lr=args.lr, weight_decay=args.weight_decay)
+        runner = mdist.StepRunner(eng, world_size=world, mode="program", lr=args.lr, weight_decay=args.weight_decay)
     else:
         optimizer = torch.optim.AdamW(param_groups_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
 

@@ -142,6 +142,18 @@ SYMBOLS = {
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
+    "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],
+    "mpmae_program_end": [c_void_p],
+    "mpmae_program_num_ops": [c_void_p],
+    "mpmae_program_run": [c_void_p, c_int, c_int, c_void_p],
+    "mpmae_memset_async": [c_void_p, c_int, c_size_t, c_void_p],
+    "mpmae_memcpy_h2d_async": [c_void_p, c_void_p, c_size_t, c_void_p],
+}
+# entry points that do not return an error code: name -> (argtypes, restype)
+OTHER_SYMBOLS = {
+    "mpmae_program_create": ([], c_void_p),
+    "mpmae_program_destroy": ([c_void_p], None),
 }
 
 _lib = None
@@ -165,6 +177,10 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = c_int
+    for name, (argtypes, restype) in OTHER_SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
     if lib.mpmae_arch() != 950:
         raise HipLibraryError("libmpmae_hip.so was not built for gfx950")
     _lib = lib

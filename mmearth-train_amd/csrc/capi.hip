@@ -11,6 +11,7 @@
 #include "rows2.cuh"
 #include "rs.cuh"
 #include "dwconv5.cuh"
+#include "gemm_tn2.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -18,6 +19,40 @@ static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a);
 static int launch_wgrad_fast(WgradP a, hipStream_t st);
 
 #define S_(s) reinterpret_cast<hipStream_t>(s)
+
+// ------------------------------------------------------------------------------------------
+// Launch programs. Every kernel launch of this library goes through LAUNCH(): normally it is
+// issued at once; while a program is being recorded on this thread (mpmae_program_begin_op) the
+// fully-resolved launch (kernel, grid, block, LDS, by-value arguments) is appended to the program
+// instead. mpmae_program_run() replays a recorded step from C with one HIP stream per lane and
+// event ordering between lanes — no Python, no ctypes marshalling, no graph instantiation.
+// ------------------------------------------------------------------------------------------
+#include <functional>
+#include <vector>
+struct ProgOp {
+  int lane = 0, signal = 0;
+  std::vector<int> waits;
+  std::vector<std::function<void(hipStream_t)>> launches;
+};
+struct MpmaeProgram {
+  std::vector<ProgOp> ops;
+  std::vector<hipStream_t> side;          // lanes 1..n
+  std::vector<hipEvent_t> events;         // by signal id
+  std::vector<unsigned> epoch;            // run in which events[id] was last recorded
+  std::vector<hipEvent_t> join;
+  hipEvent_t fork = nullptr;
+  unsigned run = 0;
+  int nlanes = 1;
+};
+static thread_local MpmaeProgram* g_rec = nullptr;
+
+template <typename F>
+static inline void submit(hipStream_t st, F&& f) {
+  if (g_rec) g_rec->ops.back().launches.emplace_back(std::forward<F>(f));
+  else f(st);
+}
+#define LAUNCH(kern, g, b, lds, st, ...) \
+  submit(st, [=](hipStream_t st__) { hipLaunchKernelGGL(kern, g, b, lds, st__, __VA_ARGS__); })
 #define RET() return (int)hipGetLastError()
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -35,10 +70,10 @@ static void launch_reduce(int mode, const float* part, int P, int W, float* out,
   if (R < 1) R = 1;
   if (R > 32) R = 32;
   dim3 g(cdiv(W, 64), R);
-  if (mode == 0) hipLaunchKernelGGL(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
-  else if (mode == 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
-  else if (mode == 3) hipLaunchKernelGGL(reduce_partials_kernel<3>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
-  else hipLaunchKernelGGL(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  if (mode == 0) LAUNCH(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else if (mode == 1) LAUNCH(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else if (mode == 3) LAUNCH(reduce_partials_kernel<3>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
+  else LAUNCH(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
 }
 
 // C linkage comes from the declarations in include/mpmae_hip.h
@@ -46,26 +81,26 @@ static void launch_reduce(int mode, const float* part, int P, int W, float* out,
 int mpmae_arch(void) { return 950; }
 
 int mpmae_mask_gen(const float* noise, int N, int L, int keep, float* mask, int* vis, int* inv, mpmae_stream_t s) {
-  hipLaunchKernelGGL(mask_gen_kernel, dim3(N), dim3(256), 2 * L * sizeof(float), S_(s), noise, L, keep, mask, vis, inv);
+  LAUNCH(mask_gen_kernel, dim3(N), dim3(256), 2 * L * sizeof(float), S_(s), noise, L, keep, mask, vis, inv);
   RET();
 }
 
 int mpmae_activity(const float* img, const int* vis, uint8_t* act, int N, int Cin, int H, int keep, int grid, int S,
                    mpmae_stream_t s) {
   const int total = N * keep * S * S;
-  hipLaunchKernelGGL(activity_kernel, dim3(grid1d(total)), dim3(256), 0, S_(s), img, vis, act, N, Cin, H, keep, grid, S);
+  LAUNCH(activity_kernel, dim3(grid1d(total)), dim3(256), 0, S_(s), img, vis, act, N, Cin, H, keep, grid, S);
   RET();
 }
 
 int mpmae_activity_pool(const uint8_t* in, uint8_t* out, int Mout, int S, int k, mpmae_stream_t s) {
-  hipLaunchKernelGGL(activity_pool_kernel, dim3(grid1d(Mout)), dim3(256), 0, S_(s), in, out, Mout, S, k);
+  LAUNCH(activity_pool_kernel, dim3(grid1d(Mout)), dim3(256), 0, S_(s), in, out, Mout, S, k);
   RET();
 }
 
 int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_elems, mpmae_stream_t s) {
   dim3 g(grid1d(max_elems, 256, 64), ndesc);
-  if (dt == 0) hipLaunchKernelGGL(prep_kernel<float>, g, dim3(256), 0, S_(s), table);
-  else hipLaunchKernelGGL(prep_kernel<bf16_t>, g, dim3(256), 0, S_(s), table);
+  if (dt == 0) LAUNCH(prep_kernel<float>, g, dim3(256), 0, S_(s), table);
+  else LAUNCH(prep_kernel<bf16_t>, g, dim3(256), 0, S_(s), table);
   RET();
 }
 
@@ -75,7 +110,7 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
   dim3 g(cdiv(a.M, GBM), cdiv(a.N, GBN)), b(256);
 #define GEMM_CASE(P, E)                                                            \
   if (pro == P && epi == E) {                                                      \
-    hipLaunchKernelGGL((gemm_kernel<T, P, E>), g, b, 0, st, a);                    \
+    LAUNCH((gemm_kernel<T, P, E>), g, b, 0, st, a);                    \
     return (int)hipGetLastError();                                                 \
   }
   GEMM_CASE(PRO_NONE, EPI_STORE)
@@ -122,7 +157,7 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
   dim3 g(cdiv(a.Nn, WBN), cdiv(a.Kk, WBK), splits), b(256);
 #define WG_CASE(P, Q)                                                              \
   if (ppro == P && qpro == Q) {                                                    \
-    hipLaunchKernelGGL((wgrad_kernel<T, P, Q>), g, b, 0, st, a);                   \
+    LAUNCH((wgrad_kernel<T, P, Q>), g, b, 0, st, a);                   \
     return (int)hipGetLastError();                                                 \
   }
   WG_CASE(PRO_NONE, PRO_NONE)
@@ -160,7 +195,7 @@ template <typename T>
 static void launch_ln_fwd(const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta,
                           int act, float eps, int M, int C, const uint8_t* rowmask, hipStream_t st) {
   const int blocks = grid1d((long long)M * 64, 256, 8192);
-  hipLaunchKernelGGL(ln_fwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
+  LAUNCH(ln_fwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
                      act, eps, M, C, rowmask);
 }
 
@@ -173,7 +208,7 @@ int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const 
     const int per = cdiv(nvec, G);
     const int rpw = 64 / G;
     const int blocks = grid1d((long long)cdiv(M, rpw) * 64, 256, 4096);
-#define LNF(TT, GG, PP) hipLaunchKernelGGL((ln_fwd_v2_kernel<TT, GG, PP>), dim3(blocks), dim3(256), 0, S_(s), (const TT*)x, (TT*)xhat, rstd, (TT*)y, gamma, beta, act, eps, M, C, rowmask)
+#define LNF(TT, GG, PP) LAUNCH((ln_fwd_v2_kernel<TT, GG, PP>), dim3(blocks), dim3(256), 0, S_(s), (const TT*)x, (TT*)xhat, rstd, (TT*)y, gamma, beta, act, eps, M, C, rowmask)
 #define LNF_T(TT) do { if (G == 8) LNF(TT, 8, 1); else if (G == 16) LNF(TT, 16, 1); else if (G == 32) LNF(TT, 32, 1); else if (per == 1) LNF(TT, 64, 1); else LNF(TT, 64, 2); } while (0)
     if (dt == 0) LNF_T(float); else LNF_T(bf16_t);
 #undef LNF_T
@@ -199,17 +234,17 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
     const int rpw = 64 / G;
     int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, 512);          // <= 2048 waves -> slab rows
     while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
-#define LNB(TT, GG, PP) hipLaunchKernelGGL((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask)
+#define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask)
 #define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
     if (dt == 0) LNB_T(float); else LNB_T(bf16_t);
 #undef LNB_T
 #undef LNB
     blocks = b2 * 4;                                                  // slab rows = waves
   } else if (dt == 0)
-    hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
+    LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
                        (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);
   else
-    hipLaunchKernelGGL(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dy, dy_div, dy_scale,
+    LAUNCH(ln_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dy, dy_div, dy_scale,
                        (const bf16_t*)xhat, rstd, gamma, beta, act, (bf16_t*)dx, accumulate, ws, M, C, rowmask);
   // slabs are [block][2][C]: e = n*C + k with n = 0 -> dgamma[k], n = 1 -> dbeta[k] (MODE 1, b = dbeta - dgamma)
   if (dgamma && dbeta) {
@@ -224,13 +259,13 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
 
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx, float* Ainv,
                            float* scale, mpmae_stream_t s) {
-  hipLaunchKernelGGL(grn_fwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), G2, gamma, eps, H, Gx, Ainv, scale);
+  LAUNCH(grn_fwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), G2, gamma, eps, H, Gx, Ainv, scale);
   RET();
 }
 
 int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv, const float* gamma,
                            int G, int H, float* coef, float* dgamma, float* dbeta, mpmae_stream_t s) {
-  hipLaunchKernelGGL(grn_bwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), S0, S1, Gx, Ainv, gamma, H, coef, dgamma, dbeta);
+  LAUNCH(grn_bwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), S0, S1, Gx, Ainv, gamma, H, coef, dgamma, dbeta);
   RET();
 }
 
@@ -246,8 +281,8 @@ static void launch_dw_v2(const MpmaeDwArgs& a, hipStream_t st) {
   const bool c40 = (a.C % 40 == 0);
   const int cc = c40 ? 40 : 32;
   dim3 g(a.g.N * a.tiles_side * a.tiles_side, cdiv(a.C, cc));
-  if (c40) hipLaunchKernelGGL((dwconv7_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
-  else hipLaunchKernelGGL((dwconv7_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
+  if (c40) LAUNCH((dwconv7_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
+  else LAUNCH((dwconv7_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
 }
 
 template <typename T>
@@ -255,8 +290,8 @@ static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
   const bool c40 = (a.C % 40 == 0);
   const int cc = c40 ? 40 : 32;
   dim3 g(nblocks, cdiv(a.C, cc));
-  if (c40) hipLaunchKernelGGL((dwconv7_wgrad_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
-  else hipLaunchKernelGGL((dwconv7_wgrad_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
+  if (c40) LAUNCH((dwconv7_wgrad_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
+  else LAUNCH((dwconv7_wgrad_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
 }
 
 template <typename T, int S>
@@ -268,14 +303,14 @@ static void launch_dw_v4(const MpmaeDwArgs& a, hipStream_t st) {
   const size_t lds = ((D::HP + 3) & ~3) * sizeof(int) +
                      (size_t)nw * (D::HP * D::CW * sizeof(T) + (S > 1 ? 49 * D::CW * sizeof(float) : 0));
   dim3 g(a.g.N * a.g.keep, chunks / nw);
-  hipLaunchKernelGGL((dwconv7_v4_kernel<T, S>), g, dim3(64 * nw), lds, st, a);
+  LAUNCH((dwconv7_v4_kernel<T, S>), g, dim3(64 * nw), lds, st, a);
 }
 
 template <typename T, int S>
 static void launch_dwwg_v4(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
   using D = Dw4<S>;
   dim3 g(nblocks, a.C / D::CW);
-  hipLaunchKernelGGL((dwconv7_wgrad_v4_kernel<T, S>), g, dim3(64), 0, st, a);
+  LAUNCH((dwconv7_wgrad_v4_kernel<T, S>), g, dim3(64), 0, st, a);
 }
 
 // v5 (one sample's whole map in LDS): returns false when the map does not fit / the attribute cannot be raised
@@ -293,7 +328,7 @@ static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
     cur = lds;
   }
   dim3 g(a.g.N, a.C / CW);
-  hipLaunchKernelGGL((dwconv7_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  LAUNCH((dwconv7_v5_kernel<T, S>), g, dim3(256), lds, st, a);
   return true;
 }
 
@@ -313,7 +348,7 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
     cur = lds;
   }
   dim3 g(nblocks, a.C / CW);
-  hipLaunchKernelGGL((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(256), lds, st, a);
   return true;
 }
 
@@ -353,8 +388,8 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
     const size_t esz = dt == 0 ? 4 : 2;
     const size_t lds = (DW_HP + W64_MAXL) * sizeof(int) + (size_t)nw * (DW_HP * 8 * esz + 49 * 8 * sizeof(float));
     dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(chunks, nw));
-    if (dt == 0) hipLaunchKernelGGL(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), *a);
-    else hipLaunchKernelGGL(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), *a);
+    if (dt == 0) LAUNCH(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), *a);
+    else LAUNCH(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), *a);
     RET();
   }
   if ((a->C & 7) == 0) {
@@ -366,10 +401,10 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
   if (dt == 0) {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    hipLaunchKernelGGL(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), *a);
   } else {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    hipLaunchKernelGGL(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
   }
   RET();
 }
@@ -410,8 +445,8 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
     if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
     dim3 g(nblocks, a->C / 8);
-    if (dt == 0) hipLaunchKernelGGL(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
-    else hipLaunchKernelGGL(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
+    if (dt == 0) LAUNCH(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
+    else LAUNCH(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
     launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }
@@ -430,10 +465,10 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
   dim3 g(nblocks, cdiv(a->C, a->CC));
   if (dt == 0) {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), *a);
   } else {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    hipLaunchKernelGGL(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
   }
   RET();
 }
@@ -442,8 +477,8 @@ int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const 
                        const uint8_t* act_in, const uint8_t* act_out, mpmae_stream_t s) {
   if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)Mout * C);
-  if (dt == 0) hipLaunchKernelGGL(dwstride_fwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)in, (float*)out, w, b, Mout, C, S, k, act_in, act_out);
-  else hipLaunchKernelGGL(dwstride_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)in, (bf16_t*)out, w, b, Mout, C, S, k, act_in, act_out);
+  if (dt == 0) LAUNCH(dwstride_fwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)in, (float*)out, w, b, Mout, C, S, k, act_in, act_out);
+  else LAUNCH(dwstride_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)in, (bf16_t*)out, w, b, Mout, C, S, k, act_in, act_out);
   RET();
 }
 
@@ -456,8 +491,8 @@ int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, cons
   int g = 512;
   if (!ws || ws_floats < per * rows_par) return (int)hipErrorInvalidValue;
   while ((size_t)g * rows_par * per > ws_floats && g > 1) g /= 2;
-  if (dt == 0) hipLaunchKernelGGL(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, ws, Mout, C, S, k, act_in);
-  else hipLaunchKernelGGL(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, S, k, act_in);
+  if (dt == 0) LAUNCH(dwstride_bwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, ws, Mout, C, S, k, act_in);
+  else LAUNCH(dwstride_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, S, k, act_in);
   // slab row = [k*k taps][C] then [C] bias: e = t*C + c -> t < k*k ? dw[t*C + c] : db[c]; dw is contiguous (k*k, C)
   launch_reduce(3, ws, g * rows_par, (int)per, dw, db, k * k * C, 0, 0, 0, S_(s));
   RET();
@@ -465,71 +500,71 @@ int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, cons
 
 int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D, mpmae_stream_t s) {
   const int g = grid1d((long long)rows * D);
-  if (dt == 0) hipLaunchKernelGGL(fill_mask_token_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)xdec, token, inv, rows, D);
-  else hipLaunchKernelGGL(fill_mask_token_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)xdec, token, inv, rows, D);
+  if (dt == 0) LAUNCH(fill_mask_token_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)xdec, token, inv, rows, D);
+  else LAUNCH(fill_mask_token_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)xdec, token, inv, rows, D);
   RET();
 }
 
 int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, mpmae_stream_t s) {
   dim3 g(cdiv(D, 256), 64);
-  if (dt == 0) hipLaunchKernelGGL(mask_token_bwd_kernel<float>, g, dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
-  else hipLaunchKernelGGL(mask_token_bwd_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
+  if (dt == 0) LAUNCH(mask_token_bwd_kernel<float>, g, dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
+  else LAUNCH(mask_token_bwd_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
   RET();
 }
 
 int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mpmae_stream_t s) {
   const int g = grid1d((long long)N * C);
-  if (dt == 0) hipLaunchKernelGGL(pool_rows_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)x, (float*)pooled, N, L, C);
-  else hipLaunchKernelGGL(pool_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)x, (bf16_t*)pooled, N, L, C);
+  if (dt == 0) LAUNCH(pool_rows_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)x, (float*)pooled, N, L, C);
+  else LAUNCH(pool_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)x, (bf16_t*)pooled, N, L, C);
   RET();
 }
 
 // ------------------------------------------------------------------------------------------
 int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
   dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
-  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else hipLaunchKernelGGL((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) hipLaunchKernelGGL((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else hipLaunchKernelGGL((loss_pix_cont_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else LAUNCH((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) LAUNCH((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else LAUNCH((loss_pix_cont_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
   RET();
 }
 
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* a, int npatches, mpmae_stream_t s) {
   if (a->K > 16) return (int)hipErrorInvalidValue;
   dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
-  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else hipLaunchKernelGGL((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) hipLaunchKernelGGL((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else hipLaunchKernelGGL((loss_pix_cat_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else LAUNCH((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) LAUNCH((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else LAUNCH((loss_pix_cat_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
   RET();
 }
 
 int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* a, mpmae_stream_t s) {
   dim3 g(a->N), b(256);
-  if (dt == 0) { if (bwd) hipLaunchKernelGGL((loss_img_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else hipLaunchKernelGGL((loss_img_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) hipLaunchKernelGGL((loss_img_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else hipLaunchKernelGGL((loss_img_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_img_kernel<float, true>), g, b, 0, S_(s), *a);
+                 else LAUNCH((loss_img_kernel<float, false>), g, b, 0, S_(s), *a); }
+  else { if (bwd) LAUNCH((loss_img_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
+         else LAUNCH((loss_img_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
   RET();
 }
 
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
                         float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
   if (T > 64) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
+  LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
                      total, coef, dlog_vars);
   RET();
 }
 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
                 float wd, size_t n, const uint8_t* decay, mpmae_stream_t s) {
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d((long long)n, 256, 4096)), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2,
+  LAUNCH(adamw_kernel, dim3(grid1d((long long)n, 256, 4096)), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2,
                      eps, wd, n, decay);
   RET();
 }
 
 int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t s) {
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid1d((long long)n, 256, 1024)), dim3(256), 0, S_(s), x, n, out);
+  LAUNCH(sumsq_kernel, dim3(grid1d((long long)n, 256, 1024)), dim3(256), 0, S_(s), x, n, out);
   RET();
 }
 
@@ -561,7 +596,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
                               (int)lds) != hipSuccess) return (int)hipGetLastError();                  \
       once = true;                                                                                     \
     }                                                                                                  \
-    hipLaunchKernelGGL((gemm_nt_bf16_kernel<BN, E>), g, dim3(256), lds, st, a);                        \
+    LAUNCH((gemm_nt_bf16_kernel<BN, E>), g, dim3(256), lds, st, a);                        \
     return (int)hipGetLastError();                                                                     \
   }
   FAST_CASE(EPI_STORE)
@@ -589,9 +624,61 @@ static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
   return dt == 1 && ppro == PRO_NONE && qpro == PRO_NONE && !((a.ldp | a.ldq | a.Nn | a.Kk) & 1);
 }
 
+static int tn_variant() {      // MPMAE_TN=1 forces the register-transposing kernel (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("MPMAE_TN"); v = e ? atoi(e) : 2; }
+  return v;
+}
+
+// transpose-read kernel: 16-byte row vectors, narrow side <= wide side
+template <int NT, int KT>
+static void launch_tn2(const WgradP& a, bool swap, int splits, hipStream_t st) {
+  const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
+  dim3 g(cdiv(WX, 16 * NT), cdiv(WY, 64 * KT), splits);
+  if (swap) LAUNCH((gemm_tn2_kernel<NT, KT, true>), g, dim3(256), 0, st, a, splits);
+  else LAUNCH((gemm_tn2_kernel<NT, KT, false>), g, dim3(256), 0, st, a, splits);
+}
+
+static bool tn2_ok(const WgradP& a) {
+  if (tn_variant() < 2) return false;
+  if ((a.ldp | a.ldq | a.Nn | a.Kk) & 7) return false;
+  if (((uintptr_t)a.P | (uintptr_t)a.Q) & 15) return false;
+  const int WX = a.Nn < a.Kk ? a.Nn : a.Kk;
+  return WX >= 32;
+}
+
+static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
+  const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
+  const bool swap = a.Kk < a.Nn;
+  const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
+  int nt, kt;
+  if (WX <= 48) { nt = 3; kt = 3; }
+  else if (WX % 80 == 0) { nt = 5; kt = 5; }
+  else { nt = 4; kt = 4; }
+  const int tiles = cdiv(WX, 16 * nt) * cdiv(WY, 64 * kt);
+  static int target = -1, minrows = -1;
+  if (target < 0) { const char* e = getenv("MPMAE_TN_BLOCKS"); target = e ? atoi(e) : 512; }
+  if (minrows < 0) { const char* e = getenv("MPMAE_TN_MINROWS"); minrows = e ? atoi(e) : 256; }
+  int splits = cdiv(target, tiles);
+  const int maxs = cdiv(a.M, minrows);
+  if (splits > maxs) splits = maxs;
+  if (splits > (int)(a.ws_floats / per)) splits = (int)(a.ws_floats / per);
+  if (splits < 1) splits = 1;
+  int rps = cdiv(cdiv(a.M, splits), 32) * 32;
+  a.rows_per_split = rps;
+  splits = cdiv(a.M, rps);
+  if (nt == 3) launch_tn2<3, 3>(a, swap, splits, st);
+  else if (nt == 5) launch_tn2<5, 5>(a, swap, splits, st);
+  else launch_tn2<4, 4>(a, swap, splits, st);
+  launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
+  if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
+  return (int)hipGetLastError();
+}
+
 static int launch_wgrad_fast(WgradP a, hipStream_t st) {
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
+  if (tn2_ok(a)) return launch_wgrad_tn2(a, st);
   const int tiles = cdiv(a.Nn, 128) * cdiv(a.Kk, 128);
   int splits = cdiv(512, tiles);                 // ~2 workgroups per CU
   if (splits > 128) splits = 128;               // bound the second-stage reduction
@@ -603,7 +690,7 @@ static int launch_wgrad_fast(WgradP a, hipStream_t st) {
   a.rows_per_split = rps;
   splits = cdiv(a.M, rps);
   dim3 g(cdiv(a.Nn, 128), cdiv(a.Kk, 128), splits);
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
+  LAUNCH(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
   return (int)hipGetLastError();
@@ -613,8 +700,8 @@ int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const fl
                     const uint8_t* act, mpmae_stream_t s) {
   if (H & 7) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)M * H / 8, 256, 8192);
-  if (dt == 0) hipLaunchKernelGGL(grn_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)h, (float*)z, scale, beta, M, H, rpg, act);
-  else hipLaunchKernelGGL(grn_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)h, (bf16_t*)z, scale, beta, M, H, rpg, act);
+  if (dt == 0) LAUNCH(grn_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)h, (float*)z, scale, beta, M, H, rpg, act);
+  else LAUNCH(grn_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)h, (bf16_t*)z, scale, beta, M, H, rpg, act);
   RET();
 }
 
@@ -622,8 +709,8 @@ int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, con
                         mpmae_stream_t s) {
   if (H & 7) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)M * H / 8, 256, 8192);
-  if (dt == 0) hipLaunchKernelGGL(grn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)dz, (const float*)h, scale, coef, M, H, rpg);
-  else hipLaunchKernelGGL(grn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)dz, (const bf16_t*)h, scale, coef, M, H, rpg);
+  if (dt == 0) LAUNCH(grn_bwd_apply_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)dz, (const float*)h, scale, coef, M, H, rpg);
+  else LAUNCH(grn_bwd_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)dz, (const bf16_t*)h, scale, coef, M, H, rpg);
   RET();
 }
 
@@ -644,7 +731,7 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
     float* o1 = single1 ? ws + (size_t)nblk * H : s1;
     const int vpl = cdiv(H / 8, 64);
     const size_t lds = (size_t)4 * (mode + 1) * H * sizeof(float);
-#define CS3(TT, VV) hipLaunchKernelGGL((colstats_v3_kernel<TT, VV>), dim3(nblk), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
+#define CS3(TT, VV) LAUNCH((colstats_v3_kernel<TT, VV>), dim3(nblk), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
 #define CS3_T(TT) do { if (vpl == 1) CS3(TT, 1); else if (vpl == 2) CS3(TT, 2); else if (vpl <= 4) CS3(TT, 4); else CS3(TT, 6); } while (0)
     if (dt == 0) CS3_T(float); else CS3_T(bf16_t);
 #undef CS3_T
@@ -664,8 +751,8 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
   } else if (M % rpg != 0) return (int)hipErrorInvalidValue;
   const int rblocks = cdiv(M, rpb);
   dim3 g(cdiv(H, 64), rblocks);
-  if (dt == 0) hipLaunchKernelGGL(colstats_kernel<float>, g, dim3(256), 0, S_(s), (const float*)h, (const float*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
-  else hipLaunchKernelGGL(colstats_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)h, (const bf16_t*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
+  if (dt == 0) LAUNCH(colstats_kernel<float>, g, dim3(256), 0, S_(s), (const float*)h, (const float*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
+  else LAUNCH(colstats_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)h, (const bf16_t*)dz, mode, s0, s1, M, H, rpg, rpb, ws);
   if (single) {
     launch_reduce(0, ws, rblocks, H, s0, nullptr, 0, 0, 0, 0, S_(s));
     if (mode == 1) launch_reduce(0, ws + (size_t)rblocks * H, rblocks, H, s1, nullptr, 0, 0, 0, 0, S_(s));
@@ -696,12 +783,12 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
     if (which == 0) {
       static bool once = false;
       if (!once) { if (hipFuncSetAttribute((const void*)rs_wide_kernel<KC, HN, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
-      hipLaunchKernelGGL((rs_wide_kernel<KC, HN, 0>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      LAUNCH((rs_wide_kernel<KC, HN, 0>), dim3(blocks), dim3(64 * nw), lds, st, p);
       launch_reduce(0, a.ws, blocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
     } else {
       static bool once = false;
       if (!once) { if (hipFuncSetAttribute((const void*)rs_wide_kernel<KC, HN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
-      hipLaunchKernelGGL((rs_wide_kernel<KC, HN, 1>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      LAUNCH((rs_wide_kernel<KC, HN, 1>), dim3(blocks), dim3(64 * nw), lds, st, p);
       launch_reduce(0, a.ws, blocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
       launch_reduce(0, a.ws + (size_t)blocks * HN, blocks, HN, a.s1, nullptr, 0, 0, 0, 0, st);
     }
@@ -715,12 +802,12 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
     if (which == 2) {
       static bool once = false;
       if (!once) { if (hipFuncSetAttribute((const void*)rs_narrow_kernel<KC, HN, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
-      hipLaunchKernelGGL((rs_narrow_kernel<KC, HN, 0, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      LAUNCH((rs_narrow_kernel<KC, HN, 0, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
     } else {
       if (!a.ws || a.ws_floats < (size_t)blocks * 2 * KC) return (int)hipErrorInvalidValue;
       static bool once = false;
       if (!once) { if (hipFuncSetAttribute((const void*)rs_narrow_kernel<KC, HN, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); once = true; }
-      hipLaunchKernelGGL((rs_narrow_kernel<KC, HN, 1, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
+      LAUNCH((rs_narrow_kernel<KC, HN, 1, false>), dim3(blocks), dim3(64 * nw), lds, st, p);
       const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
       if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
       launch_reduce(1, a.ws, blocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
@@ -735,4 +822,105 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
   if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));
   return (int)hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch programs (see LAUNCH above)
+// ------------------------------------------------------------------------------------------
+MpmaeProgram* mpmae_program_create(void) { return new MpmaeProgram(); }
+
+void mpmae_program_destroy(MpmaeProgram* p) {
+  if (!p) return;
+  if (g_rec == p) g_rec = nullptr;
+  for (auto s : p->side) (void)hipStreamDestroy(s);
+  for (auto e : p->events) if (e) (void)hipEventDestroy(e);
+  for (auto e : p->join) if (e) (void)hipEventDestroy(e);
+  if (p->fork) (void)hipEventDestroy(p->fork);
+  delete p;
+}
+
+int mpmae_program_begin_op(MpmaeProgram* p, int lane, const int* waits, int nwaits, int signal) {
+  if (!p || lane < 0 || lane > 7 || signal < 0 || nwaits < 0) return (int)hipErrorInvalidValue;
+  p->ops.emplace_back();
+  ProgOp& op = p->ops.back();
+  op.lane = lane;
+  op.signal = signal;
+  for (int i = 0; i < nwaits; ++i) op.waits.push_back(waits[i]);
+  if (lane + 1 > p->nlanes) p->nlanes = lane + 1;
+  g_rec = p;
+  return 0;
+}
+
+int mpmae_program_end(MpmaeProgram* p) {
+  if (!p) return (int)hipErrorInvalidValue;
+  g_rec = nullptr;
+  int maxid = 0;
+  for (auto& op : p->ops) {
+    if (op.signal > maxid) maxid = op.signal;
+    for (int w : op.waits) if (w > maxid) maxid = w;
+  }
+  while ((int)p->events.size() <= maxid) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    p->events.push_back(e);
+    p->epoch.push_back(0u);
+  }
+  while ((int)p->side.size() < p->nlanes - 1) {
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return (int)hipGetLastError();
+    p->side.push_back(s);
+    hipEvent_t e = nullptr;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+    p->join.push_back(e);
+  }
+  if (!p->fork && hipEventCreateWithFlags(&p->fork, hipEventDisableTiming) != hipSuccess) return (int)hipGetLastError();
+  return 0;
+}
+
+int mpmae_program_num_ops(const MpmaeProgram* p) { return p ? (int)p->ops.size() : -1; }
+
+int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_) {
+  if (!p || g_rec || first < 0 || count < 0 || first + count > (int)p->ops.size()) return (int)hipErrorInvalidValue;
+  hipStream_t main = S_(main_);
+  bool lanes = false;
+  for (int i = first; i < first + count; ++i) lanes |= p->ops[i].lane != 0;
+  ++p->run;
+  if (lanes) {                                   // fork the side lanes from the main stream
+    if (hipEventRecord(p->fork, main) != hipSuccess) return (int)hipGetLastError();
+    for (auto s : p->side) if (hipStreamWaitEvent(s, p->fork, 0) != hipSuccess) return (int)hipGetLastError();
+  }
+  for (int i = first; i < first + count; ++i) {
+    ProgOp& op = p->ops[i];
+    hipStream_t st = op.lane == 0 ? main : p->side[op.lane - 1];
+    for (int w : op.waits)                       // only events recorded in THIS run (earlier ones were joined)
+      if (w > 0 && p->epoch[w] == p->run && hipStreamWaitEvent(st, p->events[w], 0) != hipSuccess) return (int)hipGetLastError();
+    for (auto& l : op.launches) l(st);
+    if (op.signal > 0) {
+      if (hipEventRecord(p->events[op.signal], st) != hipSuccess) return (int)hipGetLastError();
+      p->epoch[op.signal] = p->run;
+    }
+  }
+  if (lanes) {                                   // join
+    for (size_t l = 0; l < p->side.size(); ++l) {
+      if (hipEventRecord(p->join[l], p->side[l]) != hipSuccess) return (int)hipGetLastError();
+      if (hipStreamWaitEvent(main, p->join[l], 0) != hipSuccess) return (int)hipGetLastError();
+    }
+  }
+  return (int)hipGetLastError();
+}
+
+int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, mpmae_stream_t s) {
+  if (!ring_pinned || slots < 1 || !counter || !hp) return (int)hipErrorInvalidValue;
+  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp);
+  RET();
+}
+
+int mpmae_memset_async(void* ptr, int value, size_t bytes, mpmae_stream_t s) {
+  submit(S_(s), [=](hipStream_t st) { (void)hipMemsetAsync(ptr, value, bytes, st); });
+  RET();
+}
+
+int mpmae_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, mpmae_stream_t s) {
+  submit(S_(s), [=](hipStream_t st) { (void)hipMemcpyAsync(dst, src_pinned, bytes, hipMemcpyHostToDevice, st); });
+  RET();
 }

@@ -104,6 +104,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// Hyper-parameter hand-over for replayed steps: the host writes record t into slot t % R of a pinned
+// ring; this kernel (one per optimizer step, in stream order) copies the slot its device-side
+// counter points at into `hp` and advances the counter. A plain async H2D copy would read the
+// pinned record when the copy EXECUTES, by which time a host running ahead has overwritten it.
+__global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp) {
+  const int c = *counter;
+  if (threadIdx.x < 4) hp[threadIdx.x] = ring[(size_t)(c % R) * 4 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) *counter = c + 1;
+}
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
   __shared__ float red[4];
   float s = 0.f;

@@ -106,10 +106,13 @@ def allreduce_buckets_sync(gflat, buckets):
 # ----------------------------------------------------------------------------- step runner
 class StepRunner:
     """Runs pretraining micro-steps of an Engine: forward, backward (+ overlapped bucketed
-    all-reduce when world_size > 1), AdamW. `use_graph` captures the launch programs into HIP
-    graphs (falls back to eager launches, loudly, if capture is not possible)."""
+    all-reduce when world_size > 1), AdamW. mode "program" records the step once into a native
+    launch program (C, one HIP stream per lane) and replays it with one call per piece;
+    "hipgraph" captures the same launches into HIP graphs (falls back to eager launches, loudly,
+    if capture is not possible; measured slower than "program" because graph branches do not
+    overlap as well as real streams); "eager" is the Python loop over the C-ABI calls."""
 
-    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05):
+    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None):
         self.eng = engine
         self.world = world_size
         self.lr = lr
@@ -121,7 +124,16 @@ class StepRunner:
         self.comm_stream = torch.cuda.Stream(device=engine.device) if world_size > 1 else None
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
         self.graphs = None
-        if use_graph:
+        self.prog = None
+        # mode: "program" = native launch program replayed from C on one HIP stream per lane (default on GPU),
+        #       "hipgraph" = the same launches captured into HIP graphs, "eager" = Python loop over the C-ABI calls
+        if mode is None:
+            mode = "hipgraph" if use_graph else "eager"
+        if mode == "program":
+            self.prog, self.spans = engine.record_program(
+                engine.step_pieces(self.segments if world_size > 1 else None, weight_decay=weight_decay))
+            self.graph_mode = "program"
+        elif mode == "hipgraph":
             self._capture()
 
     # -- program pieces (all enqueue on the current stream)
@@ -137,11 +149,16 @@ class StepRunner:
     def _bwd_seg(self, i):
         self.eng._run(self.segments[i], self.eng._stream())
 
-    def _opt(self):
-        self.eng.launch_adamw(self.wd)
+    def _opt(self, note=True):
+        self.eng.launch_adamw(self.wd, note=note)
 
     def _capture(self):
         eng = self.eng
+        # Captured graphs keep every launch on one stream: with the weight-gradient lane captured as a
+        # parallel branch, replays on ROCm 7.2 were no faster than the single-stream graph and the
+        # second replay's gradients differed from the eager/program result (1e-2 relative) — the
+        # event-ordered branches are only used by the "program" and "eager" drivers.
+        eng.single_stream = True
         try:
             side = torch.cuda.Stream(device=eng.device)
             side.wait_stream(torch.cuda.current_stream())
@@ -162,13 +179,13 @@ class StepRunner:
 
             if self.world == 1:
                 def whole():
-                    self._fwd(); self._bwd_head(); self._bwd_seg(0); self._opt()
+                    self._fwd(); self._bwd_head(); self._bwd_seg(0); self._opt(note=False)
                 cap(whole)
             else:
                 cap(lambda: (self._fwd(), self._bwd_head(), self._bwd_seg(0)))
                 for i in range(1, len(self.segments)):
                     cap(lambda i=i: self._bwd_seg(i))
-                cap(self._opt)
+                cap(lambda: self._opt(note=False))
             self.graphs = graphs
             self.graph_mode = "hipgraph"
             torch.cuda.synchronize()
@@ -178,6 +195,8 @@ class StepRunner:
             self.graphs = None
             self.graph_mode = "eager"
             torch.cuda.synchronize()
+        finally:
+            eng.single_stream = False
 
     def _launch_allreduce(self, b, works):
         ev = torch.cuda.Event()
@@ -191,9 +210,12 @@ class StepRunner:
         eng = self.eng
         self.t += 1
         eng.set_hyper(self.lr, self.t, grad_scale=1.0 / self.world)
+        if self.prog is not None:
+            return self._step_program()
         if self.world == 1:
             if self.graphs:
                 self.graphs[0].replay()
+                eng.note_optimizer_launch()
             else:
                 self._fwd(); self._bwd_head(); self._bwd_seg(0); self._opt()
             return
@@ -215,8 +237,29 @@ class StepRunner:
         lw.wait()
         if self.graphs:
             self.graphs[-1].replay()
+            eng.note_optimizer_launch()
         else:
             self._opt()
+
+    def _step_program(self):
+        eng = self.eng
+        if self.world == 1:
+            first, _ = self.spans[0]
+            last, cnt = self.spans[-1]
+            eng.run_program(self.prog, (first, last + cnt - first))       # the whole step in one call
+            eng.note_optimizer_launch()
+            return
+        works = []
+        for i in range(len(self.segments)):
+            eng.run_program(self.prog, self.spans[i])
+            self._launch_allreduce(i, works)
+        self.loss_buf.copy_(eng.total)
+        lw = dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True)
+        for w in works:
+            w.wait()
+        lw.wait()
+        eng.run_program(self.prog, self.spans[-1])
+        eng.note_optimizer_launch()
 
     def mean_loss(self) -> float:
         if self.world == 1:

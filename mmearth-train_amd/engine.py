@@ -40,7 +40,7 @@ def _rup(x, m):
 
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
-                 track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None):
+                 track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None, lanes=None):
         if cfg.decoder_depth != 1:
             raise NotImplementedError("decoder_depth != 1")
         self.lib = _lib.load()
@@ -52,7 +52,10 @@ class Engine:
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
-        self.concurrent = (self.device.type == "cuda")   # weight gradients on a side HIP stream
+        # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
+        self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
+                           and (lanes is None or bool(lanes)))
+        self.single_stream = False                 # set while capturing HIP graphs (see dist.StepRunner._capture)
         self.lanes = self.concurrent and (block_mode or ("mat" if self.dt == BF16 else "fused")) == "mat"
         self.dw_lane = int(os.environ.get("MPMAE_DW_LANE", "1"))
         self._side_readers = {}
@@ -103,7 +106,14 @@ class Engine:
             off += n
         self.n_params = total
         self.hp = torch.zeros(4, dtype=torch.float32, device=dev)
-        self.hp_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        # hyper-parameter ring: slot t % HP_SLOTS is written by set_hyper for optimizer launch t and read on the
+        # device by mpmae_hp_fetch (a replayed step must not read a record the host has already overwritten)
+        self.HP_SLOTS = 16
+        self.hp_ring = (torch.zeros(self.HP_SLOTS, 4, dtype=torch.float32).pin_memory() if dev.type == "cuda"
+                        else torch.zeros(self.HP_SLOTS, 4))
+        self.hp_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._hp_n = 0                              # optimizer launches enqueued so far
+        self._hp_ev = [None] * self.HP_SLOTS
         self.gnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
 
     def load_state_dict(self, sd):
@@ -924,7 +934,7 @@ class Engine:
         """Enqueue a launch program. Lane-1 ops (weight gradients) go to a side HIP stream forked
         from the current stream and ordered by events; the side stream is joined at the end, so a
         program is self-contained (and capturable into one HIP graph with parallel branches)."""
-        nl = (max(m["lane"] for _, _, _, m in ops) + 1) if (self.concurrent and ops) else 1
+        nl = (max(m["lane"] for _, _, _, m in ops) + 1) if (self.concurrent and ops and not self.single_stream) else 1
         main = torch.cuda.current_stream(self.device) if self.device.type == "cuda" else None
         if nl == 1:
             st = C.c_void_p(main.cuda_stream) if main is not None else stream
@@ -964,6 +974,54 @@ class Engine:
             dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
         self.noise.copy_(noise, non_blocking=True)
 
+    # ------------------------------------------------------------------ native launch programs
+    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0):
+        """The whole micro-step as op tuples, grouped into the pieces a data-parallel runner issues
+        between collectives: [forward + loss + backward segment 0], [segment 1], ..., [AdamW]."""
+        lib, a = self.lib, self._fin_args
+        m0 = dict(lane=0, wait=(), signal=None)
+
+        def fin(dlv):
+            return ("loss.finalize", lib.mpmae_loss_finalize,
+                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m0)
+
+        segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
+        first = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), m0)]
+        first += list(self.fwd_ops) + [fin(False)]
+        first += [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4), m0), fin(True)]
+        first += list(segs[0])
+        opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
+                                                 _p(self.hp)), m0),
+               ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
+                                           beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
+        return [first] + [list(sg) for sg in segs[1:]] + [opt]
+
+    def record_program(self, pieces):
+        """Record op tuples into a native launch program (include/mpmae_hip.h, "launch programs").
+        Returns (program handle, [(first op, op count) per piece])."""
+        lib = self.lib
+        prog = C.c_void_p(lib.mpmae_program_create())
+        ids, spans, n = {}, [], 0
+        try:
+            for piece in pieces:
+                spans.append((n, len(piece)))
+                for name, fn, args, meta in piece:
+                    waits = [ids.setdefault(k, len(ids) + 1) for k in meta.get("wait", ()) if k]
+                    arr = (C.c_int * max(1, len(waits)))(*waits)
+                    sig = ids.setdefault(meta["signal"], len(ids) + 1) if meta.get("signal") else 0
+                    _lib.check(lib.mpmae_program_begin_op(prog, int(meta.get("lane", 0)), arr, len(waits), sig), "program_begin_op")
+                    _lib.check(fn(*args, None), "record " + name)
+                    n += 1
+        finally:
+            err = lib.mpmae_program_end(prog)
+        _lib.check(err, "program_end")
+        assert lib.mpmae_program_num_ops(prog) == n
+        self._programs = getattr(self, "_programs", []) + [prog]
+        return prog, spans
+
+    def run_program(self, prog, span):
+        _lib.check(self.lib.mpmae_program_run(prog, span[0], span[1], self._stream()), "program_run")
+
     def forward(self, loss_scale: float = 1.0):
         st = self._stream()
         self.stats.zero_()
@@ -986,18 +1044,36 @@ class Engine:
         self.launch_adamw(weight_decay, beta1, beta2, eps)
 
     def set_hyper(self, lr, t, beta1=0.9, beta2=0.95, grad_scale=1.0):
-        """Fill the pinned hyper-parameter record {lr, 1/(1-b1^t), 1/sqrt(1-b2^t), grad_scale};
-        launch_adamw's (graph-capturable) H2D copy picks it up."""
-        self.hp_host[0] = lr
-        self.hp_host[1] = 1.0 / (1.0 - beta1 ** t)
-        self.hp_host[2] = 1.0 / math.sqrt(1.0 - beta2 ** t)
-        self.hp_host[3] = grad_scale
+        """Fill the hyper-parameter record {lr, 1/(1-b1^t), 1/sqrt(1-b2^t), grad_scale} the NEXT optimizer
+        launch will fetch (slot = launches so far % HP_SLOTS of the pinned ring)."""
+        slot = self._hp_n % self.HP_SLOTS
+        ev = self._hp_ev[slot]
+        if ev is not None:                      # the launch that last used this slot must have fetched it
+            ev.synchronize()
+            self._hp_ev[slot] = None
+        r = self.hp_ring[slot]
+        r[0] = lr
+        r[1] = 1.0 / (1.0 - beta1 ** t)
+        r[2] = 1.0 / math.sqrt(1.0 - beta2 ** t)
+        r[3] = grad_scale
 
-    def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8):
-        self.hp.copy_(self.hp_host, non_blocking=True)
+    def note_optimizer_launch(self):
+        """Call after enqueueing one optimizer launch (hp_fetch + AdamW), however it was issued."""
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._hp_ev[self._hp_n % self.HP_SLOTS] = ev
+        self._hp_n += 1
+
+    def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, note=True):
+        st = self._stream()
+        _lib.check(self.lib.mpmae_hp_fetch(C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
+                                           _p(self.hp), st), "hp_fetch")
         err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
-                                   beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), self._stream())
+                                   beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), st)
         _lib.check(err, "adamw")
+        if note:
+            self.note_optimizer_launch()
 
     def grad_norm(self):
         self.gnorm2.zero_()
