@@ -126,13 +126,18 @@ typedef struct MpmaeImgArgs {
   float* acc; const float* coef;
 } MpmaeImgArgs;
 
-/* Row-streaming fused pointwise kernels for the bandwidth-bound stages (bf16 only; C in {40,80,96},
- * H = 4C): which = 0: x-hat, rstd, xn, h = LN(d) W1^T + b1 and sum gelu(h)^2     (LN + pwconv1)
- *          which = 1: dz = dout W2 and (sum dz, sum dz*gelu(h))                   (pwconv2 data grad)
- *          which = 2: out = x + z W2^T + b2                                        (pwconv2 + residual)
- *          which = 3: dd = LayerNorm-backward(dh W1), dgamma, dbeta                (pwconv1 data grad + LN)
- * Field use per kernel is documented in csrc/rs.cuh. Replaces convnextv2_sparse.py:40-43,55 and
- * their autograd for the stages where C <= 96. */
+/* Row-streaming fused pointwise kernels of a sparse ConvNeXtV2 block (bf16 only, H = 4C):
+ *   which = 0: x-hat, rstd, xn, h = LN(d) W1^T + b1 and sum gelu(h)^2          (LN + pwconv1)
+ *   which = 1: dz = dout W2 and (sum dz, sum dz*gelu(h))                        (pwconv2 data grad)
+ *   which = 2: out = x + z W2^T + b2                                             (pwconv2 + residual)
+ *   which = 3: dd = LayerNorm-backward(dh W1), dgamma, dbeta                     (pwconv1 data grad + LN)
+ *   which = 4: z = gelu(h)*scale + beta (stored to xn), out = x + z W2^T + b2    (GRN apply + pwconv2)
+ *   which = 5: dh = (dz*scale + coef*gelu(h))*gelu'(h) stored OVER dz (= A), then as which = 3
+ * C in {40,80,96}: which 0-3, whole weight matrix resident in LDS (csrc/rs.cuh), M % 16 == 0.
+ * C in {160,320}: which 0,1,4,5, weights streamed through LDS in chunks (csrc/rsc.cuh), any M;
+ * scale / coef are [M / rpg][H] (rpg = rows per GRN group; 0 = one group).
+ * Field use per kernel is documented in those files. Replaces convnextv2_sparse.py:40-43,55 and
+ * their autograd. */
 typedef struct MpmaeRsArgs {
   const void* A; const void* A2; const void* W; int ldw;
   const float* bias; const float* v0; const float* v1;
@@ -141,6 +146,7 @@ typedef struct MpmaeRsArgs {
   int C, H;                        /* layer shape */
   float* s0; float* s1;            /* statistics / parameter-gradient outputs (accumulated) */
   size_t ws_floats;
+  int rpg;                         /* rows per GRN group (which = 4, 5); 0 = all rows */
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 

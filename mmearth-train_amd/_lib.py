@@ -97,7 +97,8 @@ class RsArgs(C.Structure):
                 ("bias", c_void_p), ("v0", c_void_p), ("v1", c_void_p),
                 ("out", c_void_p), ("xhat", c_void_p), ("xn", c_void_p), ("rstd", c_void_p), ("R", c_void_p),
                 ("lng", c_void_p), ("ws", c_void_p), ("act", c_void_p), ("M", c_int),
-                ("C", c_int), ("H", c_int), ("s0", c_void_p), ("s1", c_void_p), ("ws_floats", c_size_t)]
+                ("C", c_int), ("H", c_int), ("s0", c_void_p), ("s1", c_void_p), ("ws_floats", c_size_t),
+                ("rpg", c_int)]
 
 
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)

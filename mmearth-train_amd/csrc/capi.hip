@@ -12,6 +12,7 @@
 #include "rs.cuh"
 #include "dwconv5.cuh"
 #include "gemm_tn2.cuh"
+#include "rsc.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -816,8 +817,69 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
   return (int)hipGetLastError();
 }
 
+// chunked variants (rsc.cuh): weights streamed through LDS, any M
+static int rsc_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+template <int KC, int RT, int NC, int KCH>
+static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
+  RsP p;
+  p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
+  p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
+  p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
+  const int HN = a.H;
+  if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
+  if ((a.ldw & 7) || HN % NC || HN % KCH) return (int)hipErrorInvalidValue;
+  const int rowblocks = cdiv(a.M, 64 * RT);
+  if (which == 0 || which == 1) {
+    // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
+    static int target = rsc_env("MPMAE_RSC_BLOCKS", 768);
+    int nsplit = 1;
+    while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
+    const int cps = HN / nsplit;
+    const size_t lds = (size_t)2 * NC * (KC + 8) * 2 + (size_t)2 * cps * 4;
+    const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
+    if (!a.ws || a.ws_floats < need || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    dim3 g(rowblocks, nsplit);
+    if (which == 0) {
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 0, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_wide_kernel<KC, 0, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
+      launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+    } else {
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 1, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_wide_kernel<KC, 1, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
+      launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+      launch_reduce(0, a.ws + (size_t)rowblocks * HN, rowblocks, HN, a.s1, nullptr, 0, 0, 0, 0, st);
+    }
+  } else if (which == 4 || which == 5) {
+    const int rpg = a.rpg > 0 ? a.rpg : a.M;
+    const size_t lds = (size_t)2 * KC * (KCH + 8) * 2 + (size_t)2 * KC * 4;
+    if (lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    if (which == 4) {
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 0, RT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_narrow_kernel<KC, 0, RT, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
+    } else {
+      if (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC) return (int)hipErrorInvalidValue;
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 1, RT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_narrow_kernel<KC, 1, RT, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
+      const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
+      if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+      launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+    }
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  return (int)hipGetLastError();
+}
+
 int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
-  if (!a || which < 0 || which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;
+  if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
+  if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
+  if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
+  if (which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;
   if (a->C == 40 && a->H == 160) return launch_rs<40, 160>(which, *a, S_(s));
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
   if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));

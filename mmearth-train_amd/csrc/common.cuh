@@ -15,11 +15,13 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 // scalar conversions
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round-nearest-even
-  return (bf16_t)(u >> 16);
+// round-to-nearest-even through gfx950's v_cvt_pk_bf16_f32 (one instruction per PAIR of values; the
+// integer emulation this replaces cost 6-7 VALU instructions per value in every epilogue)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2bf2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  const bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p);
@@ -50,10 +52,10 @@ template <> __device__ __forceinline__ void st8<float>(float* p, const float (&v
 }
 template <> __device__ __forceinline__ void st8<bf16_t>(bf16_t* p, const float (&v)[8]) {
   uint4 a;
-  a.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  a.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  a.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  a.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  a.x = f2bf2(v[0], v[1]);
+  a.y = f2bf2(v[2], v[3]);
+  a.z = f2bf2(v[4], v[5]);
+  a.w = f2bf2(v[6], v[7]);
   *reinterpret_cast<uint4*>(p) = a;
 }
 
@@ -93,6 +95,16 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
 template <typename T> __device__ __forceinline__ void gelu_both_t(float x, float& g, float& dg) {
   if (sizeof(T) == 2) gelu_both_fast(x, g, dg);
   else { g = gelu_f(x); dg = gelu_grad_f(x); }
+}
+
+// sum over the 16 lanes of a DPP row (lanes sharing lane>>4), result in every lane: 4 v_add_f32_dpp
+// (quad_perm xor 1, xor 2, row_ror 4, row_ror 8) instead of 4 ds_bpermute round trips
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float sum16(float v) {
+  v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x128>(v);
+  return v;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

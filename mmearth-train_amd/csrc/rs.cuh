@@ -39,10 +39,10 @@ struct RsP {
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(const float (&v)[8]) {
   uint4 u;
-  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-  u.z = (uint32_t)f2bf(v[4]) | ((uint32_t)f2bf(v[5]) << 16);
-  u.w = (uint32_t)f2bf(v[6]) | ((uint32_t)f2bf(v[7]) << 16);
+  u.x = f2bf2(v[0], v[1]);
+  u.y = f2bf2(v[2], v[3]);
+  u.z = f2bf2(v[4], v[5]);
+  u.w = f2bf2(v[6], v[7]);
   return __builtin_bit_cast(bf16x8_t, u);
 }
 __device__ __forceinline__ void unpack8(const uint4& a, float (&o)[8]) {

@@ -1,0 +1,380 @@
+// Chunked row-streaming fused pointwise kernels for the compute-shaped sparse stages (C = 160 / 320, H = 4C).
+//
+// rs.cuh keeps a whole weight matrix in LDS, which stops fitting at C = 160 (205 KB). Here the
+// activation rows stay in REGISTERS for the whole kernel and the weights stream through LDS in
+// double-buffered chunks shared by the 4 waves of a workgroup (one barrier per chunk):
+//   * A operand: loaded from global memory directly in MFMA fragment layout (lane (lr, lg) reads
+//     16 B of row lr at k = 32 s + 8 lg), LayerNorm / GRN / GELU' prologues are lane-local plus
+//     two cross-lane adds; no LDS round trip for activations at all;
+//   * the MFMA is issued TRANSPOSED, D[n][m] = W[n][:] . A[m][:], so that a lane ends up with 4
+//     consecutive output columns of ONE row (col = lr -> row m, rows lg*4+r -> columns n): bias,
+//     residual, GELU, LayerNorm-backward row sums are lane-local and results leave as 8-byte
+//     stores / operands arrive as 8-byte loads with no transpose tile;
+//   * column statistics (GRN sums, LayerNorm gamma/beta gradients) are folded over the 16 lanes
+//     that share a column group and leave through LDS float atomics -> one slab row per workgroup.
+// rsc_wide  (N = H, chunks over N): MODE 0: x-hat, rstd, xn, h = LN(d) W1^T + b1, sum gelu(h)^2
+//                                   MODE 1: dz = dout W2, (sum dz, sum dz*gelu(h))
+// rsc_narrow (N = C, chunks over K = H):
+//                                   MODE 0: z = gelu(h)*scale + beta (stored), out = x + z W2^T + b2
+//                                   MODE 1: dh = (dz*scale + coef*gelu(h))*gelu'(h) (stored over dz),
+//                                           dd = LayerNorm-backward(dh W1), dgamma, dbeta partials
+#pragma once
+#include "rs.cuh"
+
+__device__ __forceinline__ uint2 pack_bf16x4(const float (&v)[4]) {
+  uint2 u;
+  u.x = f2bf2(v[0], v[1]);
+  u.y = f2bf2(v[2], v[3]);
+  return u;
+}
+__device__ __forceinline__ void unpack4(const uint2& a, float (&o)[4]) {
+  o[0] = __uint_as_float(a.x << 16); o[1] = __uint_as_float(a.x & 0xffff0000u);
+  o[2] = __uint_as_float(a.y << 16); o[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+
+// =====================================================================================
+// grid = (ceil(M / (64*RT)), HN / cols_per_split); block = 256
+template <int KC, int MODE, int RT, int NC>
+__global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int cols_per_split) {
+  using T = bf16_t;
+  constexpr int KS = KC / 32, LDW = KC + 8, VPR = KC / 8, WV = (NC * VPR + 255) / 256;
+  static_assert(KC % 32 == 0 && ((KC / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
+  bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][NC][LDW]
+  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NC * LDW * sizeof(bf16_t));   // [2][cols_per_split]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
+  const int n_begin = blockIdx.y * cols_per_split;
+  const int nch = cols_per_split / NC;
+  for (int i = tid; i < 2 * cols_per_split; i += 256) red[i] = 0.f;
+
+  uint4 wr[WV];
+  auto wload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      wr[i] = (v < NC * VPR) ? *reinterpret_cast<const uint4*>(p.W + (size_t)(n_begin + c * NC + n) * p.ldw + k)
+                             : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      if (v < NC * VPR) *reinterpret_cast<uint4*>(Wc + (size_t)buf * NC * LDW + n * LDW + k) = wr[i];
+    }
+  };
+  wload(0);
+
+  // ---- activation fragments (whole K extent) for this wave's RT row tiles
+  bf16x8_t af[RT][KS];
+  bool live[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = rbase + rt * 16 + lr;
+    const bool inb = row < p.M;
+    live[rt] = inb && (!p.act || p.act[row]);
+    uint4 raw[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      raw[s] = inb ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * KC + s * 32 + lg * 8) : make_uint4(0u, 0u, 0u, 0u);
+    if (MODE == 0) {
+      float v[KS][8];
+      float s1 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        unpack8(raw[s], v[s]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += v[s][e];
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      const float mean = s1 / KC;
+      float s2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[s][e] - mean; s2 += d * d; }
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float rstd = rsqrtf(s2 / KC + 1e-6f);
+      const bool wr_side = inb && blockIdx.y == 0;
+      if (wr_side && lg == 0) p.rstd[row] = live[rt] ? rstd : 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const int k = s * 32 + lg * 8;
+        const float4 g0 = *reinterpret_cast<const float4*>(p.v0 + k), g1 = *reinterpret_cast<const float4*>(p.v0 + k + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.v1 + k), b1 = *reinterpret_cast<const float4*>(p.v1 + k + 4);
+        const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float xh[8], xn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[e] = live[rt] ? (v[s][e] - mean) * rstd : 0.f;
+          xh[e] = bf2f(f2bf(xh[e]));                          // consumers (and backward) see the stored value
+          xn[e] = live[rt] ? xh[e] * ga[e] + be[e] : 0.f;
+        }
+        af[rt][s] = pack_bf16x8(xn);
+        if (wr_side) {
+          st8<T>(p.xhat + (size_t)row * KC + k, xh);
+          if (p.xn) *reinterpret_cast<uint4*>(p.xn + (size_t)row * KC + k) = __builtin_bit_cast(uint4, af[rt][s]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) af[rt][s] = __builtin_bit_cast(bf16x8_t, raw[s]);
+    }
+  }
+  wstore(0);
+  __syncthreads();
+
+  for (int c = 0; c < nch; ++c) {
+    if (c + 1 < nch) wload(c + 1);
+    const bf16_t* wb = Wc + (size_t)(c & 1) * NC * LDW;
+#pragma unroll
+    for (int j = 0; j < NC / 16; ++j) {
+      const int nl = c * NC + j * 16 + lg * 4;            // first of this lane's 4 columns, relative to n_begin
+      const int n4 = n_begin + nl;
+      uint2 hraw[RT];
+      if (MODE == 1) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const int row = rbase + rt * 16 + lr;
+          hraw[rt] = (row < p.M) ? *reinterpret_cast<const uint2*>(p.R + (size_t)row * HN + n4) : make_uint2(0u, 0u);
+        }
+      }
+      bf16x8_t wf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        wf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (j * 16 + lr) * LDW + s * 32 + lg * 8));
+      float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
+      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      if (MODE == 0 && p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
+        bias[0] = b.x; bias[1] = b.y; bias[2] = b.z; bias[3] = b.w;
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[rt][s], acc, 0, 0, 0);
+        const int row = rbase + rt * 16 + lr;
+        float o[4];
+        if (MODE == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = live[rt] ? acc[r] + bias[r] : 0.f;
+            o[r] = bf2f(f2bf(v));                               // statistics on the value as stored
+            const float gl = gelu_t<T>(o[r]);
+            cs0[r] += gl * gl;
+          }
+        } else {
+          float hv[4];
+          unpack4(hraw[rt], hv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = bf2f(f2bf(acc[r]));
+            cs0[r] += o[r];
+            cs1[r] += o[r] * gelu_t<T>(hv[r]);
+          }
+        }
+        if (row < p.M) *reinterpret_cast<uint2*>(p.out + (size_t)row * HN + n4) = pack_bf16x4(o);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = sum16(cs0[r]);
+        if (lr == 0) atomicAdd(&red[nl + r], a);
+        if (MODE == 1) {
+          const float b = sum16(cs1[r]);
+          if (lr == 0) atomicAdd(&red[cols_per_split + nl + r], b);
+        }
+      }
+    }
+    if (c + 1 < nch) wstore((c + 1) & 1);
+    __syncthreads();
+  }
+  for (int i = tid; i < cols_per_split; i += 256) {
+    p.ws[(size_t)blockIdx.x * HN + n_begin + i] = red[i];
+    if (MODE == 1) p.ws[((size_t)gridDim.x + blockIdx.x) * HN + n_begin + i] = red[cols_per_split + i];
+  }
+}
+
+// =====================================================================================
+// grid = ceil(M / (64*RT)); block = 256. rpg = rows per GRN group (M for the batch-global sparse GRN).
+template <int KC, int MODE, int RT, int KCH>
+__global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, int rpg) {
+  using T = bf16_t;
+  constexpr int NT = KC / 16, KSC = KCH / 32, LDW = KCH + 8, VPR = KCH / 8, WV = (KC * VPR + 255) / 256;
+  static_assert(KC % 16 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
+  bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][KC][LDW]
+  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * KC * LDW * sizeof(bf16_t));   // [2][KC] (MODE 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+  const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
+  const int nkc = HN / KCH;
+  if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
+
+  uint4 wr[WV];
+  auto wload = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      wr[i] = (v < KC * VPR) ? *reinterpret_cast<const uint4*>(p.W + (size_t)n * p.ldw + kc * KCH + k) : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WV; ++i) {
+      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      if (v < KC * VPR) *reinterpret_cast<uint4*>(Wc + (size_t)buf * KC * LDW + n * LDW + k) = wr[i];
+    }
+  };
+
+  int rowv[RT];
+  bool inb[RT], live[RT];
+  size_t goff[RT];                       // row's GRN group offset into scale / beta / coef
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    rowv[rt] = rbase + rt * 16 + lr;
+    inb[rt] = rowv[rt] < p.M;
+    live[rt] = inb[rt] && (!p.act || p.act[rowv[rt]]);
+    goff[rt] = inb[rt] ? (size_t)(rowv[rt] / rpg) * HN : 0;
+  }
+  uint4 araw[RT][KSC], hraw[RT][KSC];
+  auto aload = [&](int kc) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int s = 0; s < KSC; ++s) {
+        const size_t off = (size_t)rowv[rt] * HN + kc * KCH + s * 32 + lg * 8;
+        araw[rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == 1) hraw[rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
+      }
+  };
+
+  f32x4_t acc[RT][NT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[rt][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  wload(0);
+  aload(0);
+  wstore(0);
+  __syncthreads();
+  for (int kc = 0; kc < nkc; ++kc) {
+    // ---- prologue on this chunk's activation fragments (registers), results stored once
+    bf16x8_t af[RT][KSC];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int s = 0; s < KSC; ++s) {
+        const int k = kc * KCH + s * 32 + lg * 8;
+        const float* sp = p.v0 + goff[rt] + k;
+        const float* tp = p.v1 + ((MODE == 0) ? 0 : goff[rt]) + k;       // grn beta is per channel, coef per group
+        const float4 sa = *reinterpret_cast<const float4*>(sp), sb = *reinterpret_cast<const float4*>(sp + 4);
+        const float4 ta = *reinterpret_cast<const float4*>(tp), tb = *reinterpret_cast<const float4*>(tp + 4);
+        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+        const float tc[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+        float a[8], z[8];
+        unpack8(araw[rt][s], a);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) z[e] = live[rt] ? gelu_t<T>(a[e]) * sc[e] + tc[e] : 0.f;      // GRN(gelu(h))
+        } else {
+          float h[8];
+          unpack8(hraw[rt][s], h);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float gl, dg;
+            gelu_both_t<T>(h[e], gl, dg);
+            z[e] = (a[e] * sc[e] + tc[e] * gl) * dg;                                                 // dh
+          }
+        }
+        af[rt][s] = pack_bf16x8(z);
+        if (inb[rt]) {
+          bf16_t* dst = (MODE == 0) ? p.xn : const_cast<bf16_t*>(p.A);
+          if (dst) *reinterpret_cast<uint4*>(dst + (size_t)rowv[rt] * HN + k) = __builtin_bit_cast(uint4, af[rt][s]);
+        }
+      }
+    if (kc + 1 < nkc) { wload(kc + 1); aload(kc + 1); }
+    const bf16_t* wb = Wc + (size_t)(kc & 1) * KC * LDW;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bf16x8_t wf[KSC];
+#pragma unroll
+      for (int s = 0; s < KSC; ++s)
+        wf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (j * 16 + lr) * LDW + s * 32 + lg * 8));
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int s = 0; s < KSC; ++s)
+          acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[rt][s], acc[rt][j], 0, 0, 0);
+    }
+    if (kc + 1 < nkc) wstore((kc + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds row m = lr, columns n = j*16 + lg*4 + r
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int row = rowv[rt];
+    if (MODE == 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        if (inb[rt] && p.R) unpack4(*reinterpret_cast<const uint2*>(p.R + (size_t)row * KC + n4), x);
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n4);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = live[rt] ? acc[rt][j][r] + bb[r] + x[r] : 0.f;
+        if (inb[rt]) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+      }
+    } else {
+      // LayerNorm backward: row sums are lane-local over (j, r) plus the 4 lane groups
+      uint2 xraw[NT];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        xraw[j] = inb[rt] ? *reinterpret_cast<const uint2*>(p.xhat + (size_t)row * KC + n4) : make_uint2(0u, 0u);
+        float xh[4];
+        unpack4(xraw[j], xh);
+        const float4 g = *reinterpret_cast<const float4*>(p.lng + n4);
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dxn = live[rt] ? bf2f(f2bf(acc[rt][j][r])) : 0.f;      // bf16 like the unfused path
+          const float ga = sum16(dxn * xh[r]), gb = sum16(dxn);
+          if (lr == 0) { atomicAdd(&red[n4 + r], ga); atomicAdd(&red[KC + n4 + r], gb); }
+          const float gq = dxn * gg[r];
+          acc[rt][j][r] = gq;
+          s1 += gq;
+          s2 += gq * xh[r];
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1 /= KC; s2 /= KC;
+      const float rs = inb[rt] ? p.rstd[row] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        float xh[4], o[4];
+        unpack4(xraw[j], xh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = live[rt] ? rs * (acc[rt][j][r] - s1 - xh[r] * s2) : 0.f;
+        if (inb[rt]) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+      }
+    }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    for (int i = tid; i < KC; i += 256) {
+      p.ws[((size_t)blockIdx.x * 2 + 0) * KC + i] = red[i];
+      p.ws[((size_t)blockIdx.x * 2 + 1) * KC + i] = red[KC + i];
+    }
+  }
+}

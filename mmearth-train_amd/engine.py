@@ -52,6 +52,7 @@ class Engine:
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
+        self.disable_rsc = os.environ.get("MPMAE_RSC", "1") == "0"
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
                            and (lanes is None or bool(lanes)))
@@ -431,8 +432,16 @@ class Engine:
                  lane=lane, wait=wait, signal=signal)
 
     def _rs_ok(self, blk):
-        return (self.dt == BF16 and blk["sparse"] and (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384))
-                and blk["M"] % 16 == 0 and not self.disable_rs)
+        if self.dt != BF16 or not blk["sparse"] or self.disable_rs:
+            return False
+        if (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384)):     # whole weight matrix in LDS (rs.cuh)
+            return blk["M"] % 16 == 0
+        return self._rsc_ok(blk)
+
+    def _rsc_ok(self, blk):
+        """chunked row-streaming kernels (rsc.cuh) with the GRN application / its backward fused in"""
+        return (self.dt == BF16 and blk["sparse"] and not self.disable_rs and not self.disable_rsc
+                and (blk["C"], blk["H"]) in ((160, 640), (320, 1280)))
 
     def _rs(self, lst, name, which, blk, nbytes, flops, **kw):
         a = _lib.RsArgs()
@@ -553,6 +562,11 @@ class Engine:
                      rpg, kind="colstats", nbytes=M * H * esz)
         self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                  _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
+        if rs and self._rsc_ok(blk):   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
+            self._rs(lst, tag + ":grn.apply+pw2", 4, blk, (2 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["h"],
+                     W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
+                     v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0)
+            return blk["out"]
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                  _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
         if rs:
@@ -595,9 +609,16 @@ class Engine:
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                  _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
-        self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
-                 _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
-        if rs:   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
+        rsc = rs and self._rsc_ok(blk)
+        if not rsc:
+            self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
+                     _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
+        if rsc:  # dh (written over dz) in the operand prologue, pwconv1 data gradient, LayerNorm backward
+            self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, (3 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H,
+                     A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
+                     xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act, s0=Gd[nm["ln_w"]],
+                     s1=Gd[nm["ln_b"]], rpg=0)
+        elif rs:   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
             self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
                      W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
                      s0=Gd[nm["ln_w"]], s1=Gd[nm["ln_b"]])

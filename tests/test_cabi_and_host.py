@@ -36,7 +36,8 @@ def test_struct_layouts_match_header(tmp_path):
     from mmearth_train_amd import _lib
     names = dict(MpmaeGeom=_lib.Geom, MpmaeGemmArgs=_lib.GemmArgs, MpmaeWgradArgs=_lib.WgradArgs,
                  MpmaeDwArgs=_lib.DwArgs, MpmaeDwWgArgs=_lib.DwWgArgs, MpmaePrepDesc=_lib.PrepDesc,
-                 MpmaePixContArgs=_lib.PixContArgs, MpmaePixCatArgs=_lib.PixCatArgs, MpmaeImgArgs=_lib.ImgArgs)
+                 MpmaePixContArgs=_lib.PixContArgs, MpmaePixCatArgs=_lib.PixCatArgs, MpmaeImgArgs=_lib.ImgArgs,
+                 MpmaeRsArgs=_lib.RsArgs)
     src = tmp_path / "sz.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "mpmae_hip.h"\nint main(void) {{\n{body}\n  return 0;\n}}\n')
