@@ -329,7 +329,10 @@ static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
     cur = lds;
   }
   dim3 g(a.g.N, a.C / CW);
-  LAUNCH((dwconv7_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  static int nt8 = -1;
+  if (nt8 < 0) { const char* e = getenv("MPMAE_DW_NT8"); nt8 = e ? atoi(e) : 512; }
+  // S = 8: the 62x62 map takes 61 KB, so two workgroups per CU; 8 waves each keep 4 waves per SIMD busy
+  LAUNCH((dwconv7_v5_kernel<T, S>), g, dim3(S == 8 ? nt8 : 256), lds, st, a);
   return true;
 }
 
@@ -337,7 +340,10 @@ template <typename T, int S>
 static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
   constexpr int CW = 64 / S;
   size_t lds = dw5_map_bytes<T, S>(a.g.grid);
-  const size_t red = (size_t)4 * 50 * CW * sizeof(float);
+  static int nt8 = -1;
+  if (nt8 < 0) { const char* e = getenv("MPMAE_DW_NT8"); nt8 = e ? atoi(e) : 512; }
+  const int nthreads = S == 8 ? nt8 : 256;
+  const size_t red = (size_t)(nthreads / 64) * 50 * CW * sizeof(float);
   if (red > lds) lds = red;
   if (lds > 160 * 1024 - 512) return false;
   static size_t cur = 64 * 1024;
@@ -349,7 +355,7 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
     cur = lds;
   }
   dim3 g(nblocks, a.C / CW);
-  LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(256), lds, st, a);
+  LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(nthreads), lds, st, a);
   return true;
 }
 
@@ -671,8 +677,13 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   if (nt == 3) launch_tn2<3, 3>(a, swap, splits, st);
   else if (nt == 5) launch_tn2<5, 5>(a, swap, splits, st);
   else launch_tn2<4, 4>(a, swap, splits, st);
-  launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
-  if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
+  const int nk = a.Nn * a.Kk;
+  if (a.sn == a.Kk && a.sk == 1) {               // contiguous dW: weights and bias fold in one launch
+    launch_reduce(3, a.ws, splits, nk + a.Nn, a.dW, a.db, nk, 0, 0, 0, st);
+  } else {
+    launch_reduce(1, a.ws, splits, nk + a.Nn, a.dW, nullptr, a.Kk, a.sn, a.sk, nk, st);
+    if (a.db) launch_reduce(3, a.ws, splits, nk + a.Nn, nullptr, a.db, nk, 1, 0, 0, st);
+  }
   return (int)hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void dw5_scatter(const Geom& g, int n, const T* __res
 
 // grid = (N samples, C / CW); block = 256
 template <typename T, int S>
-__global__ __launch_bounds__(256) void dwconv7_v5_kernel(const DwP p) {
+__global__ __launch_bounds__(512) void dwconv7_v5_kernel(const DwP p) {
   using D = Dw5<T, S>;
   constexpr int CW = D::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void dwconv7_v5_kernel(const DwP p) {
 // weight / bias gradient: persistent workgroups over samples; grid = (nblocks, C/CW), block 256;
 // slab ws[blockIdx.x][50][C]
 template <typename T, int S>
-__global__ __launch_bounds__(256) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
+__global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
   using D = Dw5<T, S>;
   constexpr int CW = D::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];

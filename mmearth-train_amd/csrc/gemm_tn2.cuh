@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const WgradP w, int split
   }
 
   // D layout: col = lr, row = lg*4 + r. !SWAP: row = x (n), col = y (k). SWAP: row = y (n), col = x (k).
-  float* slab = w.ws + (size_t)blockIdx.z * w.Nn * w.Kk;
+  // slab layout: [split][Nn*Kk weights | Nn bias] so that one second-stage launch folds both
+  float* slab = w.ws + (size_t)blockIdx.z * ((size_t)w.Nn * w.Kk + w.Nn);
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const WgradP w, int split
         if (n < w.Nn && k < w.Kk) slab[(size_t)n * w.Kk + k] = acc[i][j][r];
       }
   if (do_db && lr == 0) {
-    float* dslab = w.ws + (size_t)splits * w.Nn * w.Kk + (size_t)blockIdx.z * w.Nn;
+    float* dslab = slab + (size_t)w.Nn * w.Kk;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
 #pragma unroll

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
 // price list, "fanin"); per-block partial slabs + this kernel replace them. With gridDim.y == 1
 // the result is a plain read-modify-write (deterministic); otherwise <= 16-way atomics.
 //   MODE 0: addr = e
-//   MODE 1: e = n*a + k        -> out[n*b + k*c]                       (strided weight layouts)
-//   MODE 3: e < a ? out[e] : out2[e - a]                                  (weights then bias)
+//   MODE 1: e = n*a + k        -> out[n*b + k*c], only e < d when d > 0   (strided weight layouts)
+//   MODE 3: e < a ? out[e] : out2[e - a]; a null out / out2 skips its part (weights then bias)
 //   MODE 2: e = tap*a + ch     -> tap < 49 ? out[kh*b + kw*c + ch*d] : out2[ch]   (depthwise 7x7)
 // ---------------------------------------------------------------------------------
 template <int MODE>
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
   float* dst;
   if (MODE == 0) dst = out + e;
-  else if (MODE == 1) { const int n = e / a, k = e - n * a; dst = out + (size_t)n * b + (size_t)k * c; }
-  else if (MODE == 3) { if (e < a) dst = out + e; else { if (!out2) return; dst = out2 + (e - a); } }
+  else if (MODE == 1) { if (d > 0 && e >= d) return; const int n = e / a, k = e - n * a; dst = out + (size_t)n * b + (size_t)k * c; }
+  else if (MODE == 3) { if (e < a) { if (!out) return; dst = out + e; } else { if (!out2) return; dst = out2 + (e - a); } }
   else {
     const int tap = e / a, ch = e - tap * a;
     if (tap < 49) { const int kh = tap / 7, kw = tap - kh * 7; dst = out + kh * b + kw * c + ch * d; }
