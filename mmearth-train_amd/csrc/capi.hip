@@ -10,7 +10,7 @@
 #include "dwconv3.cuh"
 #include "rows2.cuh"
 #include "rs.cuh"
-#include "dwconv5.cuh"
+#include "dwconv6.cuh"
 #include "gemm_tn2.cuh"
 #include "rsc.cuh"
 
@@ -359,9 +359,40 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
   return true;
 }
 
+static int dw6_threads(int S) {     // waves per workgroup (each wave walks two patches at a time)
+  static int t8 = -1, t4 = -1, t2 = -1;
+  if (t8 < 0) { const char* e = getenv("MPMAE_DW6_T8"); t8 = e ? atoi(e) : 320; }
+  if (t4 < 0) { const char* e = getenv("MPMAE_DW6_T4"); t4 = e ? atoi(e) : 320; }
+  if (t2 < 0) { const char* e = getenv("MPMAE_DW6_T2"); t2 = e ? atoi(e) : 320; }
+  return S == 8 ? t8 : S == 4 ? t4 : t2;
+}
+
+template <int S>
+static bool launch_dw_v6(const MpmaeDwArgs& a, hipStream_t st) {
+  constexpr int CW = 64 / S;
+  const size_t lds = dw5_map_bytes<bf16_t, S>(a.g.grid) + 49 * CW * sizeof(float);
+  if (lds > 64 * 1024) return false;
+  dim3 g(a.g.N, a.C / CW);
+  LAUNCH((dwconv7_v6_kernel<S>), g, dim3(dw6_threads(S)), lds, st, a);
+  return true;
+}
+
+template <int S>
+static bool launch_dwwg_v6(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
+  constexpr int CW = 64 / S;
+  const int nthreads = dw6_threads(S);
+  size_t lds = dw5_map_bytes<bf16_t, S>(a.g.grid);
+  const size_t red = (size_t)(nthreads / 64) * 50 * CW * sizeof(float);
+  if (red > lds) lds = red;
+  if (lds > 64 * 1024) return false;
+  dim3 g(nblocks, a.C / CW);
+  LAUNCH((dwconv7_wgrad_v6_kernel<S>), g, dim3(nthreads), lds, st, a);
+  return true;
+}
+
 static int dw_variant() {      // MPMAE_DW=4 forces the per-patch kernels (A/B measurements)
   static int v = -1;
-  if (v < 0) { const char* e = getenv("MPMAE_DW"); v = e ? atoi(e) : 5; }
+  if (v < 0) { const char* e = getenv("MPMAE_DW"); v = e ? atoi(e) : 6; }
   return v;
 }
 
@@ -374,8 +405,19 @@ static bool dw_v4_ok(int C, int S) {
 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
+      (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->out | (uintptr_t)a->add) & 3) == 0) {
+    dim3 g(a->g.N, cdiv(a->C, 64));
+    LAUNCH((dwconv7_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a);
+    RET();
+  }
   if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
     bool ok = false;
+    if (dt == 1 && dw_variant() >= 6 && (a->C & 1) == 0 && (((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->add) & 3) == 0) {
+      switch (a->g.S) { case 8: ok = launch_dw_v6<8>(*a, S_(s)); break; case 4: ok = launch_dw_v6<4>(*a, S_(s)); break;
+                        default: ok = launch_dw_v6<2>(*a, S_(s)); }
+      if (ok) RET();
+    }
 #define DW5(TT) do { switch (a->g.S) { case 8: ok = launch_dw_v5<TT, 8>(*a, S_(s)); break; case 4: ok = launch_dw_v5<TT, 4>(*a, S_(s)); break; \
                                       default: ok = launch_dw_v5<TT, 2>(*a, S_(s)); } } while (0)
     if (dt == 0) DW5(float); else DW5(bf16_t);
@@ -424,10 +466,20 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     int nb = a->g.N < 128 ? a->g.N : 128;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     bool ok = false;
+    // the packed weight-gradient kernel needs 98 accumulator VGPRs per lane and measured slower than v5
+    // (62 vs 45 us at stage 1); it stays available for experiments (MPMAE_DWW=6)
+    static int wg6 = -1;
+    if (wg6 < 0) { const char* e = getenv("MPMAE_DWW"); wg6 = (e && atoi(e) >= 6) ? 1 : 0; }
+    if (wg6 && dt == 1 && (a->C & 1) == 0 && (((uintptr_t)a->x | (uintptr_t)a->dd) & 3) == 0) {
+      switch (a->g.S) { case 8: ok = launch_dwwg_v6<8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v6<4>(*a, nb, S_(s)); break;
+                        default: ok = launch_dwwg_v6<2>(*a, nb, S_(s)); }
+    }
+    if (!ok) {
 #define DWW5(TT) do { switch (a->g.S) { case 8: ok = launch_dwwg_v5<TT, 8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v5<TT, 4>(*a, nb, S_(s)); break; \
                                        default: ok = launch_dwwg_v5<TT, 2>(*a, nb, S_(s)); } } while (0)
     if (dt == 0) DWW5(float); else DWW5(bf16_t);
 #undef DWW5
+    }
     if (ok) {
       launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
       RET();

@@ -28,16 +28,28 @@ __host__ __device__ inline size_t dw5_map_bytes(int grid) {
 template <typename T, int S, bool CLEAR>
 __device__ __forceinline__ void dw5_scatter(const Geom& g, int n, const T* __restrict__ x, T* map, int MS, int C, int c0) {
   using D = Dw5<T, S>;
+  constexpr int U = 4;      // rows in flight per thread: the table lookup and the row load of U items overlap
   const int items = g.keep * S * S * D::VPL;
-  for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    const int v = it % D::VPL, pt = it / D::VPL;
-    const int slot = pt / (S * S), q = pt - slot * (S * S);
-    const int iy = q / S, ix = q - iy * S;
-    const int patch = g.vis ? g.vis[n * g.keep + slot] : slot;
-    const int py = patch / g.grid, px = patch - py * g.grid;
-    uint4 val = make_uint4(0u, 0u, 0u, 0u);
-    if (!CLEAR) val = *reinterpret_cast<const uint4*>(x + ((size_t)(n * g.keep + slot) * (S * S) + q) * C + c0 + v * D::EPV);
-    *reinterpret_cast<uint4*>(map + ((size_t)(py * S + iy + 3) * MS + px * S + ix + 3) * D::CW + v * D::EPV) = val;
+  for (int base = threadIdx.x; base < items; base += blockDim.x * U) {
+    uint4 val[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int it = base + u * blockDim.x;
+      const bool ok = it < items;
+      const int itc = ok ? it : 0;
+      const int v = itc % D::VPL, pt = itc / D::VPL;
+      const int slot = pt / (S * S), q = pt - slot * (S * S);
+      const int iy = q / S, ix = q - iy * S;
+      const int patch = g.vis ? g.vis[n * g.keep + slot] : slot;
+      const int py = patch / g.grid, px = patch - py * g.grid;
+      val[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (!CLEAR) val[u] = *reinterpret_cast<const uint4*>(x + ((size_t)(n * g.keep + slot) * (S * S) + q) * C + c0 + v * D::EPV);
+      dst[u] = ok ? (((py * S + iy + 3) * MS + px * S + ix + 3) * D::CW + v * D::EPV) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) *reinterpret_cast<uint4*>(map + dst[u]) = val[u];
   }
 }
 

@@ -1,0 +1,272 @@
+// Per-sample LDS-resident depthwise 7x7, packed-math variant (bf16 storage only), v6.
+//
+// Same staging as v5 (dwconv5.cuh): one sample's padded map for CW = 64/S channels in LDS. The
+// inner loop of v5 spends 1.6-2.6 VALU/LDS instructions per multiply-add (a 2-byte LDS read and a
+// shift per input value, scalar FMAs). Here a lane owns TWO adjacent channels:
+//   lane = (cp, ox, sub): channel pair cp of the chunk, column ox of a patch, and the wave works on
+//   two visible patches at once (sub = lane / 32);
+//   one ds_read_b32 brings both channels' bf16 values, one ds_read_b64 both channels' tap weights,
+//   and every multiply-add is half of a v_pk_fma_f32 -> 0.9-1.6 instructions per multiply-add.
+#pragma once
+#include "dwconv5.cuh"
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2_t bf2x2_to_f2(uint32_t raw) {
+  f32x2_t v;
+  v.x = __uint_as_float(raw << 16);
+  v.y = __uint_as_float(raw & 0xffff0000u);
+  return v;
+}
+
+// grid = (N samples, C / CW); block = 64 * NW
+template <int S>
+__global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
+  using T = bf16_t;
+  constexpr int CW = 64 / S, CP = CW / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
+  const int MS = p.g.grid * S + 6;
+  T* map = reinterpret_cast<T*>(dw5_smem);
+  float* wl = reinterpret_cast<float*>(dw5_smem + dw5_map_bytes<T, S>(p.g.grid));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
+  const int C = p.C, n = blockIdx.x, c0 = blockIdx.y * CW;
+  {
+    uint4* m4 = reinterpret_cast<uint4*>(dw5_smem);
+    const int nvec = (int)(dw5_map_bytes<T, S>(p.g.grid) / 16);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < nvec; i += blockDim.x) m4[i] = z;
+  }
+  for (int i = tid; i < 49 * CW; i += blockDim.x) {
+    const int k = i / CW, cc = i - k * CW;
+    int kh = k / 7, kw = k - kh * 7;
+    if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
+    wl[i] = p.w[kh * p.s_kh + kw * p.s_kw + (c0 + cc) * p.s_c];
+  }
+  __syncthreads();
+  dw5_scatter<T, S, false>(p.g, n, reinterpret_cast<const T*>(p.x), map, MS, C, c0);
+  __syncthreads();
+
+  const int cp = lane % CP, ox = (lane / CP) % S, sub = lane / (CP * S);      // CP * S == 32
+  const int c = c0 + 2 * cp;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* add = reinterpret_cast<const T*>(p.add);
+  f32x2_t b2 = {0.f, 0.f};
+  if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
+
+  for (int slot = wave * 2 + sub; slot < p.g.keep; slot += NW * 2) {
+    const int nk = n * p.g.keep + slot;
+    const int patch = p.g.vis ? p.g.vis[nk] : slot;
+    const int py = patch / p.g.grid, px = patch - py * p.g.grid;
+    const T* tile = map + ((size_t)(py * S) * MS + px * S + ox) * CW + 2 * cp;     // halo origin + this lane's column
+    const size_t r0 = (size_t)nk * (S * S) + ox;
+    f32x2_t acc[S];
+    uint32_t addraw[S];
+    uint8_t live[S];
+#pragma unroll
+    for (int o = 0; o < S; ++o) {
+      addraw[o] = add ? *reinterpret_cast<const uint32_t*>(add + (r0 + o * S) * C + c) : 0u;
+      live[o] = p.act ? p.act[r0 + o * S] : 1;
+      acc[o] = b2;
+    }
+#pragma unroll 1
+    for (int kx = 0; kx < 7; ++kx) {
+      f32x2_t w7[7];
+#pragma unroll
+      for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
+#pragma unroll
+      for (int y = 0; y < S + 6; ++y) {
+        const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW));
+#pragma unroll
+        for (int o = 0; o < S; ++o) {
+          const int ky = y - o;
+          if (ky >= 0 && ky < 7) acc[o] = w7[ky] * v + acc[o];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < S; ++o) {
+      const f32x2_t a = bf2x2_to_f2(addraw[o]);
+      const f32x2_t r = acc[o] + a;
+      *reinterpret_cast<uint32_t*>(out + (r0 + o * S) * C + c) = live[o] ? f2bf2(r.x, r.y) : 0u;
+    }
+  }
+}
+
+// weight / bias gradient: persistent workgroups over samples; grid = (nblocks, C/CW); slab ws[blockIdx.x][50][C]
+template <int S>
+__global__ __launch_bounds__(512) void dwconv7_wgrad_v6_kernel(const DwWgP q) {
+  using T = bf16_t;
+  constexpr int CW = 64 / S, CP = CW / 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
+  const int MS = q.g.grid * S + 6;
+  T* map = reinterpret_cast<T*>(dw5_smem);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
+  const int C = q.C, c0 = blockIdx.y * CW;
+  const int cp = lane % CP, ox = (lane / CP) % S, sub = lane / (CP * S);
+  const int c = c0 + 2 * cp;
+  const T* dd = reinterpret_cast<const T*>(q.dd);
+  const T* x = reinterpret_cast<const T*>(q.x);
+  {
+    uint4* m4 = reinterpret_cast<uint4*>(dw5_smem);
+    const int nvec = (int)(dw5_map_bytes<T, S>(q.g.grid) / 16);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = tid; i < nvec; i += blockDim.x) m4[i] = z;
+  }
+  f32x2_t adw[49], adb = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 49; ++k) adw[k] = (f32x2_t){0.f, 0.f};
+
+  for (int n = blockIdx.x; n < q.g.N; n += gridDim.x) {
+    __syncthreads();
+    dw5_scatter<T, S, false>(q.g, n, x, map, MS, C, c0);
+    __syncthreads();
+    for (int slot = wave * 2 + sub; slot < q.g.keep; slot += NW * 2) {
+      const int nk = n * q.g.keep + slot;
+      const int patch = q.g.vis ? q.g.vis[nk] : slot;
+      const int py = patch / q.g.grid, px = patch - py * q.g.grid;
+      const T* tile = map + ((size_t)(py * S) * MS + px * S + ox) * CW + 2 * cp;
+      const size_t r0 = (size_t)nk * (S * S) + ox;
+      f32x2_t g[S];
+#pragma unroll
+      for (int o = 0; o < S; ++o) {
+        g[o] = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(dd + (r0 + o * S) * C + c));
+        adb += g[o];
+      }
+      int toff = 0;     // data dependence between kx-slabs: stops hipcc hoisting all LDS reads (see dwconv3.cuh)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        if (kx > 0)
+          asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
+                       "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
+#pragma unroll
+        for (int y = 0; y < S + 6; ++y) {
+          const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW));
+#pragma unroll
+          for (int o = 0; o < S; ++o) {
+            const int ky = y - o;
+            if (ky >= 0 && ky < 7) adw[ky * 7 + kx] = g[o] * v + adw[ky * 7 + kx];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    dw5_scatter<T, S, true>(q.g, n, x, map, MS, C, c0);      // clear only what was written
+  }
+  // fold lanes that share a channel pair (lane bits above log2(CP)), then the NW waves through LDS
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(dw5_smem);           // [NW][50][CW]
+#pragma unroll
+  for (int k = 0; k < 50; ++k) {
+    f32x2_t v = (k < 49) ? adw[k < 49 ? k : 0] : adb;
+#pragma unroll
+    for (int o = CP; o < 64; o <<= 1) { v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); }
+    if (lane < CP) *reinterpret_cast<f32x2_t*>(red + (wave * 50 + k) * CW + 2 * cp) = v;
+  }
+  __syncthreads();
+  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
+  for (int i = tid; i < 50 * CW; i += blockDim.x) {
+    float v = 0.f;
+    for (int w = 0; w < NW; ++w) v += red[w * 50 * CW + i];
+    const int k = i / CW, cc = i - k * CW;
+    slab[k * C + c0 + cc] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S = 1 (stage 3: 19 of the GxG positions visible; dense decoder: all of them), G = 7:
+// one wave = one sample x 16 channels; the whole (G+6)^2 padded map is 5.4 KB of LDS per wave.
+// lane = (cp 0..7, ox 0..G-1): a lane produces the full output COLUMN ox (G outputs) for two
+// channels, so every input value read from LDS feeds up to 7 packed FMAs; outputs of masked
+// positions are simply not stored. grid = (N, C/64), block = 256 (4 independent channel chunks).
+// ---------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
+  using T = bf16_t;
+  constexpr int CW = 16, MS = G + 6, MAPB = ((MS * MS * CW * 2 + 15) / 16) * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * (MAPB + 49 * CW * 4)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  T* map = reinterpret_cast<T*>(smem + wave * (MAPB + 49 * CW * 4));
+  float* wl = reinterpret_cast<float*>(smem + wave * (MAPB + 49 * CW * 4) + MAPB);
+  const int C = p.C, n = blockIdx.x, c0 = (blockIdx.y * 4 + wave) * CW;
+  const bool chunk_ok = c0 < C;
+  const int cc0 = chunk_ok ? c0 : 0;
+  {
+    uint4* m4 = reinterpret_cast<uint4*>(map);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < MAPB / 16; i += 64) m4[i] = z;
+  }
+  {
+    float wv[13];                      // 49*16 = 784 taps: 13 loads per lane, all in flight together
+#pragma unroll
+    for (int u = 0; u < 13; ++u) {
+      const int i = lane + 64 * u, ic = i < 49 * CW ? i : 0;
+      const int k = ic / CW, cc = ic - k * CW;
+      int kh = k / 7, kw = k - kh * 7;
+      if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
+      wv[u] = p.w[kh * p.s_kh + kw * p.s_kw + (cc0 + cc) * p.s_c];
+    }
+#pragma unroll
+    for (int u = 0; u < 13; ++u) if (lane + 64 * u < 49 * CW) wl[lane + 64 * u] = wv[u];
+  }
+  __syncthreads();
+  {
+    const T* x = reinterpret_cast<const T*>(p.x);
+    const int items = p.g.keep * 2;
+    uint4 val[2];
+    int dst[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {                 // G*G*2 <= 128 items: at most 2 per lane
+      const int it = lane + 64 * u;
+      const bool ok = it < items;
+      const int v = it & 1, slot = ok ? it >> 1 : 0;
+      const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
+      const int py = patch / G, px = patch - py * G;
+      val[u] = *reinterpret_cast<const uint4*>(x + (size_t)(n * p.g.keep + slot) * C + cc0 + v * 8);
+      dst[u] = ok ? ((py + 3) * MS + px + 3) * CW + v * 8 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (dst[u] >= 0) *reinterpret_cast<uint4*>(map + dst[u]) = val[u];
+  }
+  __syncthreads();
+  const int cp = lane & 7, ox = lane >> 3;
+  if (ox >= G || !chunk_ok) return;
+  const int c = c0 + 2 * cp;
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* add = reinterpret_cast<const T*>(p.add);
+  f32x2_t b2 = {0.f, 0.f};
+  if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
+  int rows[G];
+  uint32_t addraw[G];
+  f32x2_t acc[G];
+#pragma unroll
+  for (int o = 0; o < G; ++o) {
+    const int patch = o * G + ox;
+    const int slot = p.g.inv ? p.g.inv[n * G * G + patch] : patch;
+    rows[o] = slot >= 0 ? n * p.g.keep + slot : -1;
+    addraw[o] = (add && rows[o] >= 0) ? *reinterpret_cast<const uint32_t*>(add + (size_t)rows[o] * C + c) : 0u;
+    acc[o] = b2;
+  }
+  const T* tile = map + ox * CW + 2 * cp;
+#pragma unroll 1
+  for (int kx = 0; kx < 7; ++kx) {
+    f32x2_t w7[7];
+#pragma unroll
+    for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
+#pragma unroll
+    for (int y = 0; y < G + 6; ++y) {
+      const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW));
+#pragma unroll
+      for (int o = 0; o < G; ++o) {
+        const int ky = y - o;
+        if (ky >= 0 && ky < 7) acc[o] = w7[ky] * v + acc[o];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < G; ++o) {
+    if (rows[o] < 0) continue;
+    const bool live = !p.act || p.act[rows[o]];
+    const f32x2_t r = acc[o] + bf2x2_to_f2(addraw[o]);
+    *reinterpret_cast<uint32_t*>(out + (size_t)rows[o] * C + c) = live ? f2bf2(r.x, r.y) : 0u;
+  }
+}
