@@ -463,7 +463,9 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
   if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    int nb = a->g.N < 128 ? a->g.N : 128;
+    static int nbmax = -1;
+    if (nbmax < 0) { const char* e = getenv("MPMAE_DWW_NB"); nbmax = e ? atoi(e) : 128; }
+    int nb = a->g.N < nbmax ? a->g.N : nbmax;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     bool ok = false;
     // the packed weight-gradient kernel needs 98 accumulator VGPRs per lane and measured slower than v5
@@ -883,7 +885,7 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
 // chunked variants (rsc.cuh): weights streamed through LDS, any M
 static int rsc_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-template <int KC, int RT, int NC, int KCH>
+template <int KC, int RT, int NC, int KCH, int RTN = RT>
 static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   RsP p;
   p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
@@ -899,7 +901,8 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     int nsplit = 1;
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
-    const size_t lds = (size_t)2 * NC * (KC + 8) * 2 + (size_t)2 * cps * 4;
+    constexpr int KP = ((KC + 31) / 32) * 32;
+    const size_t lds = (size_t)2 * NC * (KP + 8) * 2 + (size_t)2 * cps * 4;
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
     if (!a.ws || a.ws_floats < need || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
     dim3 g(rowblocks, nsplit);
@@ -917,17 +920,19 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     }
   } else if (which == 4 || which == 5) {
     const int rpg = a.rpg > 0 ? a.rpg : a.M;
-    const size_t lds = (size_t)2 * KC * (KCH + 8) * 2 + (size_t)2 * KC * 4;
+    const int rowblocks = cdiv(a.M, 64 * RTN);
+    constexpr int NP = ((KC + 15) / 16) * 16;
+    const size_t lds = (size_t)2 * NP * (KCH + 8) * 2 + (size_t)2 * KC * 4;
     if (lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
     if (which == 4) {
       static size_t cur = 64 * 1024;
-      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 0, RT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
-      LAUNCH((rsc_narrow_kernel<KC, 0, RT, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 0, RTN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_narrow_kernel<KC, 0, RTN, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
     } else {
       if (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC) return (int)hipErrorInvalidValue;
       static size_t cur = 64 * 1024;
-      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 1, RT, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
-      LAUNCH((rsc_narrow_kernel<KC, 1, RT, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 1, RTN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_narrow_kernel<KC, 1, RTN, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
       const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
       if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
       launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
@@ -942,6 +947,21 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
+  static int small = rsc_env("MPMAE_RSC_SMALL", 1);      // 0: keep the LDS-resident-weights kernels for which 0-3
+  if (which > 3 || (small && which < 2)) {
+    static int v40 = rsc_env("MPMAE_RSC_N40", 2), v80 = rsc_env("MPMAE_RSC_N80", 1);
+    if (a->C == 40 && a->H == 160) {
+      if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2>(which, *a, S_(s));
+      if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1>(which, *a, S_(s));
+      if (v40 == 3) return launch_rsc<40, 4, 160, 160, 1>(which, *a, S_(s));
+      return launch_rsc<40, 4, 160, 160, 2>(which, *a, S_(s));
+    }
+    if (a->C == 80 && a->H == 320) {
+      if (v80 == 1) return launch_rsc<80, 2, 64, 64, 1>(which, *a, S_(s));
+      if (v80 == 2) return launch_rsc<80, 2, 64, 32, 1>(which, *a, S_(s));
+      return launch_rsc<80, 2, 64, 64, 2>(which, *a, S_(s));
+    }
+  }
   if (which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;
   if (a->C == 40 && a->H == 160) return launch_rs<40, 160>(which, *a, S_(s));
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));

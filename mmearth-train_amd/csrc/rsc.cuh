@@ -37,8 +37,9 @@ __device__ __forceinline__ void unpack4(const uint2& a, float (&o)[4]) {
 template <int KC, int MODE, int RT, int NC>
 __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int cols_per_split) {
   using T = bf16_t;
-  constexpr int KS = KC / 32, LDW = KC + 8, VPR = KC / 8, WV = (NC * VPR + 255) / 256;
-  static_assert(KC % 32 == 0 && ((KC / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
+  constexpr int KS = (KC + 31) / 32, KP = KS * 32, LDW = KP + 8, VPR = KP / 8, WV = (NC * VPR + 255) / 256;
+  constexpr bool PAD = KP != KC;                 // K padded with zero columns (C = 40 / 80)
+  static_assert(KC % 8 == 0 && ((KP / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
   bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][NC][LDW]
   float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NC * LDW * sizeof(bf16_t));   // [2][cols_per_split]
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
-      wr[i] = (v < NC * VPR) ? *reinterpret_cast<const uint4*>(p.W + (size_t)(n_begin + c * NC + n) * p.ldw + k)
-                             : make_uint4(0u, 0u, 0u, 0u);
+      wr[i] = (v < NC * VPR && (!PAD || k < KC)) ? *reinterpret_cast<const uint4*>(p.W + (size_t)(n_begin + c * NC + n) * p.ldw + k)
+                                                 : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto wstore = [&](int buf) {
@@ -78,7 +79,8 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
     uint4 raw[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      raw[s] = inb ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * KC + s * 32 + lg * 8) : make_uint4(0u, 0u, 0u, 0u);
+      raw[s] = (inb && (!PAD || s * 32 + lg * 8 < KC)) ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * KC + s * 32 + lg * 8)
+                                                     : make_uint4(0u, 0u, 0u, 0u);
     if (MODE == 0) {
       float v[KS][8];
       float s1 = 0.f;
@@ -94,7 +96,10 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
 #pragma unroll
       for (int s = 0; s < KS; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = v[s][e] - mean; s2 += d * d; }
+        for (int e = 0; e < 8; ++e) {
+          const float d = (!PAD || s * 32 + lg * 8 < KC) ? v[s][e] - mean : 0.f;
+          s2 += d * d;
+        }
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       const float rstd = rsqrtf(s2 / KC + 1e-6f);
       const bool wr_side = inb && blockIdx.y == 0;
@@ -102,19 +107,21 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int k = s * 32 + lg * 8;
-        const float4 g0 = *reinterpret_cast<const float4*>(p.v0 + k), g1 = *reinterpret_cast<const float4*>(p.v0 + k + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(p.v1 + k), b1 = *reinterpret_cast<const float4*>(p.v1 + k + 4);
+        const bool kin = !PAD || k < KC;
+        const int kc_ = kin ? k : 0;
+        const float4 g0 = *reinterpret_cast<const float4*>(p.v0 + kc_), g1 = *reinterpret_cast<const float4*>(p.v0 + kc_ + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.v1 + kc_), b1 = *reinterpret_cast<const float4*>(p.v1 + kc_ + 4);
         const float ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         float xh[8], xn[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[e] = live[rt] ? (v[s][e] - mean) * rstd : 0.f;
+          xh[e] = (live[rt] && kin) ? (v[s][e] - mean) * rstd : 0.f;
           xh[e] = bf2f(f2bf(xh[e]));                          // consumers (and backward) see the stored value
-          xn[e] = live[rt] ? xh[e] * ga[e] + be[e] : 0.f;
+          xn[e] = (live[rt] && kin) ? xh[e] * ga[e] + be[e] : 0.f;
         }
         af[rt][s] = pack_bf16x8(xn);
-        if (wr_side) {
+        if (wr_side && kin) {
           st8<T>(p.xhat + (size_t)row * KC + k, xh);
           if (p.xn) *reinterpret_cast<uint4*>(p.xn + (size_t)row * KC + k) = __builtin_bit_cast(uint4, af[rt][s]);
         }
@@ -203,11 +210,12 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
 template <int KC, int MODE, int RT, int KCH>
 __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, int rpg) {
   using T = bf16_t;
-  constexpr int NT = KC / 16, KSC = KCH / 32, LDW = KCH + 8, VPR = KCH / 8, WV = (KC * VPR + 255) / 256;
-  static_assert(KC % 16 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
+  constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + 8, VPR = KCH / 8, WV = (NP * VPR + 255) / 256;
+  constexpr bool PAD = NP != KC;                 // output columns padded to whole 16-wide tiles (C = 40)
+  static_assert(KC % 8 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
-  bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][KC][LDW]
-  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * KC * LDW * sizeof(bf16_t));   // [2][KC] (MODE 1)
+  bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][NP][LDW]
+  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NP * LDW * sizeof(bf16_t));   // [2][KC] (MODE 1)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
@@ -219,14 +227,15 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, in
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
-      wr[i] = (v < KC * VPR) ? *reinterpret_cast<const uint4*>(p.W + (size_t)n * p.ldw + kc * KCH + k) : make_uint4(0u, 0u, 0u, 0u);
+      wr[i] = (v < NP * VPR && (!PAD || n < KC)) ? *reinterpret_cast<const uint4*>(p.W + (size_t)n * p.ldw + kc * KCH + k)
+                                                 : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto wstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
-      if (v < KC * VPR) *reinterpret_cast<uint4*>(Wc + (size_t)buf * KC * LDW + n * LDW + k) = wr[i];
+      if (v < NP * VPR) *reinterpret_cast<uint4*>(Wc + (size_t)buf * NP * LDW + n * LDW + k) = wr[i];
     }
   };
 
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, in
         }
       }
     if (kc + 1 < nkc) { wload(kc + 1); aload(kc + 1); }
-    const bf16_t* wb = Wc + (size_t)(kc & 1) * KC * LDW;
+    const bf16_t* wb = Wc + (size_t)(kc & 1) * NP * LDW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       bf16x8_t wf[KSC];
@@ -323,14 +332,15 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, in
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
+        const bool nin = !PAD || n4 < KC;
         float x[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-        if (inb[rt] && p.R) unpack4(*reinterpret_cast<const uint2*>(p.R + (size_t)row * KC + n4), x);
+        if (inb[rt] && nin && p.R) unpack4(*reinterpret_cast<const uint2*>(p.R + (size_t)row * KC + n4), x);
         float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) b = *reinterpret_cast<const float4*>(p.bias + n4);
+        if (p.bias && nin) b = *reinterpret_cast<const float4*>(p.bias + n4);
         const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = live[rt] ? acc[rt][j][r] + bb[r] + x[r] : 0.f;
-        if (inb[rt]) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+        if (inb[rt] && nin) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
       }
     } else {
       // LayerNorm backward: row sums are lane-local over (j, r) plus the 4 lane groups
@@ -339,16 +349,17 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, in
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
-        xraw[j] = inb[rt] ? *reinterpret_cast<const uint2*>(p.xhat + (size_t)row * KC + n4) : make_uint2(0u, 0u);
+        const bool nin = !PAD || n4 < KC;
+        xraw[j] = (inb[rt] && nin) ? *reinterpret_cast<const uint2*>(p.xhat + (size_t)row * KC + n4) : make_uint2(0u, 0u);
         float xh[4];
         unpack4(xraw[j], xh);
-        const float4 g = *reinterpret_cast<const float4*>(p.lng + n4);
+        const float4 g = nin ? *reinterpret_cast<const float4*>(p.lng + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float gg[4] = {g.x, g.y, g.z, g.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float dxn = live[rt] ? bf2f(f2bf(acc[rt][j][r])) : 0.f;      // bf16 like the unfused path
           const float ga = sum16(dxn * xh[r]), gb = sum16(dxn);
-          if (lr == 0) { atomicAdd(&red[n4 + r], ga); atomicAdd(&red[KC + n4 + r], gb); }
+          if (lr == 0 && nin) { atomicAdd(&red[n4 + r], ga); atomicAdd(&red[KC + n4 + r], gb); }
           const float gq = dxn * gg[r];
           acc[rt][j][r] = gq;
           s1 += gq;
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, in
         unpack4(xraw[j], xh);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = live[rt] ? rs * (acc[rt][j][r] - s1 - xh[r] * s2) : 0.f;
-        if (inb[rt]) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+        if (inb[rt] && (!PAD || n4 < KC)) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
       }
     }
   }

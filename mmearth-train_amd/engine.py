@@ -53,6 +53,7 @@ class Engine:
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.disable_rsc = os.environ.get("MPMAE_RSC", "1") == "0"
+        self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
                            and (lanes is None or bool(lanes)))
@@ -434,14 +435,29 @@ class Engine:
     def _rs_ok(self, blk):
         if self.dt != BF16 or not blk["sparse"] or self.disable_rs:
             return False
+        if self._rsc_ok(blk):
+            return True
         if (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384)):     # whole weight matrix in LDS (rs.cuh)
             return blk["M"] % 16 == 0
-        return self._rsc_ok(blk)
+        return False
+
+    def _rs_plan(self, blk):
+        """(wide, narrow): which row-streaming kernels a block uses. wide: LN+pw1 / pw2.dgrad fused with
+        their GRN statistics (which 0/1); narrow: None (tiled GEMMs + element-wise kernels), "plain" (which
+        2/3 on materialised z / dh) or "fused" (which 4/5, GRN application and its backward in the operand
+        prologue). Measured on MI355X at bs 256: fused wins for C <= 160; at C = 320 (M = 4864 rows, 76
+        workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
+        if not self._rs_ok(blk):
+            return False, None
+        if self._rsc_ok(blk):
+            return True, ("fused" if blk["C"] <= 160 else None)
+        return True, "plain"
 
     def _rsc_ok(self, blk):
         """chunked row-streaming kernels (rsc.cuh) with the GRN application / its backward fused in"""
+        shapes = ((160, 640), (320, 1280)) + (((40, 160), (80, 320)) if self.rsc_small else ())
         return (self.dt == BF16 and blk["sparse"] and not self.disable_rs and not self.disable_rsc
-                and (blk["C"], blk["H"]) in ((160, 640), (320, 1280)))
+                and (blk["C"], blk["H"]) in shapes)
 
     def _rs(self, lst, name, which, blk, nbytes, flops, **kw):
         a = _lib.RsArgs()
@@ -538,8 +554,8 @@ class Engine:
             blk["xn"] = self._t(M, Cc)
             blk["z"] = self._t(M, H)
         self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
-        rs = self._rs_ok(blk)
-        blk["rs"] = rs
+        rs, rs_n = self._rs_plan(blk)
+        blk["rs"], blk["rs_n"] = rs, rs_n
         if rs:   # LN + pwconv1 + GELU^2 column sums in one row-streaming kernel
             self._rs(lst, tag + ":ln+pw1", 0, blk, (3 * M * Cc + M * H) * esz, 2 * M * Cc * H, A=blk["d"],
                      W=self.w[tag + ".W1"]["t"], ldw=self.w[tag + ".W1"]["ld"], bias=P[nm["b1"]], v0=P[nm["ln_w"]],
@@ -562,14 +578,14 @@ class Engine:
                      rpg, kind="colstats", nbytes=M * H * esz)
         self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                  _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
-        if rs and self._rsc_ok(blk):   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
+        if rs_n == "fused":   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
             self._rs(lst, tag + ":grn.apply+pw2", 4, blk, (2 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["h"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
                      v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0)
             return blk["out"]
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                  _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
-        if rs:
+        if rs_n == "plain":
             self._rs(lst, tag + ":pw2", 2, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["z"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], out=blk["out"], R=x,
                      act=act)
@@ -591,7 +607,7 @@ class Engine:
         dxn = self.scr_dxn[:M * Cc]
         dd = self.scr_dd2[t & 1][:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
-        rs = blk.get("rs", False)
+        rs, rs_n = blk.get("rs", False), blk.get("rs_n")
         if rs:
             self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + 2 * M * H) * esz, 2 * M * Cc * H, A=dout, W=w2t["t"],
                      ldw=w2t["ld"], out=dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
@@ -609,7 +625,7 @@ class Engine:
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                  _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
-        rsc = rs and self._rsc_ok(blk)
+        rsc = rs_n == "fused"
         if not rsc:
             self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
                      _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
@@ -618,7 +634,7 @@ class Engine:
                      A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
                      xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act, s0=Gd[nm["ln_w"]],
                      s1=Gd[nm["ln_b"]], rpg=0)
-        elif rs:   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
+        elif rs_n == "plain":   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
             self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
                      W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
                      s0=Gd[nm["ln_w"]], s1=Gd[nm["ln_b"]])
@@ -628,7 +644,7 @@ class Engine:
         self._guard(lst, dd)
         self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
                     dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        if not rs:
+        if rs_n is None:
             self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)

@@ -98,7 +98,8 @@ def run(M, Cc, timing):
             print(f"    which {w}: {timeit(lambda: lib.mpmae_rs(w, C.byref(a), st)):7.1f} us")
 
 
-cases = [(1000, 160, False), (76, 160, False), (19456, 160, True), (304, 320, False), (4864, 320, True)]
+cases = [(1000, 160, False), (76, 160, False), (19456, 160, True), (304, 320, False), (4864, 320, True),
+         (1000, 40, False), (311296, 40, True), (77, 80, False), (77824, 80, True)]
 if os.environ.get("RS_ONLY"):
     cases = [c for c in cases if c[2] and c[1] == int(os.environ["RS_ONLY"])]
 for M, Cc, tm in cases:
