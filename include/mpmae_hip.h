@@ -164,8 +164,9 @@ int mpmae_activity_pool(const uint8_t* act_in, uint8_t* act_out, int Mout, int S
 
 /* ---- weight staging ------------------------------------------------------------------------ */
 /* casts / transposes fp32 master weights into the [N][K] compute-type layouts the GEMMs read;
- * `table` is a device array of ndesc descriptors. */
-int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_elems,
+ * `table` is a device array of ndesc descriptors; max_tiles = max over the views of
+ * ceil(rows/64)*ceil(cols/64) (each view is moved in 64x64 tiles through LDS). */
+int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_tiles,
                        mpmae_stream_t stream);
 
 /* ---- MFMA GEMMs ---------------------------------------------------------------------------- */

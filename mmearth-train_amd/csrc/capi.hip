@@ -98,10 +98,12 @@ int mpmae_activity_pool(const uint8_t* in, uint8_t* out, int Mout, int S, int k,
   RET();
 }
 
-int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_elems, mpmae_stream_t s) {
-  dim3 g(grid1d(max_elems, 256, 64), ndesc);
-  if (dt == 0) LAUNCH(prep_kernel<float>, g, dim3(256), 0, S_(s), table);
-  else LAUNCH(prep_kernel<bf16_t>, g, dim3(256), 0, S_(s), table);
+int mpmae_prep_weights(int dt, const MpmaePrepDesc* table, int ndesc, int max_tiles, mpmae_stream_t s) {
+  if (!table || ndesc < 1 || max_tiles < 1 || max_tiles > 65535) return (int)hipErrorInvalidValue;
+  const int tiles = max_tiles;
+  dim3 g((unsigned)tiles, ndesc);
+  if (dt == 0) LAUNCH(prep_tiled_kernel<float>, g, dim3(256), 0, S_(s), table);
+  else LAUNCH(prep_tiled_kernel<bf16_t>, g, dim3(256), 0, S_(s), table);
   RET();
 }
 
@@ -567,9 +569,13 @@ int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv
 }
 
 int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, mpmae_stream_t s) {
-  dim3 g(cdiv(D, 256), 64);
-  if (dt == 0) LAUNCH(mask_token_bwd_kernel<float>, g, dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
-  else LAUNCH(mask_token_bwd_kernel<bf16_t>, g, dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
+  if ((D & 7) || D / 8 > 256) return (int)hipErrorInvalidValue;
+  const int rl_n = 256 / (D / 8);
+  int blocks = cdiv(rows, rl_n * 8);             // ~8 rows per thread
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  if (dt == 0) LAUNCH(mask_token_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
+  else LAUNCH(mask_token_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
   RET();
 }
 
@@ -582,7 +588,7 @@ int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mp
 
 // ------------------------------------------------------------------------------------------
 int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
-  dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
+  dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 1024);   // forward: one 16-wave block per sample
   if (dt == 0) { if (bwd) LAUNCH((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
                  else LAUNCH((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
   else { if (bwd) LAUNCH((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
@@ -592,7 +598,7 @@ int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches
 
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* a, int npatches, mpmae_stream_t s) {
   if (a->K > 16) return (int)hipErrorInvalidValue;
-  dim3 g(bwd ? npatches : npatches / a->L), b(256);   // forward: one block per sample
+  dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 1024);   // forward: one 16-wave block per sample
   if (dt == 0) { if (bwd) LAUNCH((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
                  else LAUNCH((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
   else { if (bwd) LAUNCH((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);

@@ -90,6 +90,59 @@ __device__ __forceinline__ void loss_pix_cont_patch(const PixContP& q, int b, fl
   }
 }
 
+// register-cached patch (J <= 64*NCACHE elements): returns through acc_s / acc_c
+template <typename T, int NCACHE>
+__device__ __forceinline__ void loss_pix_cont_patch_cached(const PixContP& q, int b, const T* pred, const float* tg,
+                                                           int lane, int p, int C, int PP, int J, float& acc_s, float& acc_c) {
+    // register-cached form: every target / prediction element of the patch is loaded exactly once and
+    // all loads of the patch are in flight together (one memory latency per patch instead of one per pass)
+    float tv[NCACHE], pv[NCACHE];
+    bool ok[NCACHE];
+#pragma unroll
+    for (int u = 0; u < NCACHE; ++u) {
+      const int i = lane + 64 * u;
+      ok[u] = i < J;
+      const int ic = ok[u] ? i : 0;
+      const int c = ic / PP, r = ic - c * PP, ph = r / p, pw = r - ph * p;
+      tv[u] = tg[((size_t)c * q.H + ph) * q.H + pw];          // clamped index, unconditional: a load under a
+      pv[u] = ldf<T>(pred + r * C + c);                      // per-lane branch is serialised with a wait each
+    }
+#pragma unroll
+    for (int u = 0; u < NCACHE; ++u) {
+      tv[u] = ok[u] ? nan_to_num0(tv[u]) : 0.f;
+      pv[u] = ok[u] ? pv[u] : 0.f;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (q.norm_pix) {
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < NCACHE; ++u) s += tv[u];
+      mean = wave_sum(s) / J;
+      float v = 0.f;
+#pragma unroll
+      for (int u = 0; u < NCACHE; ++u) { const float d = ok[u] ? tv[u] - mean : 0.f; v += d * d; }
+      v = wave_sum(v);
+      rstd = 1.f / sqrtf(v / (J - 1) + 1.0e-6f);
+    }
+    float se = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int u = 0; u < NCACHE; ++u) {
+      const float d = pv[u] - (tv[u] - mean) * rstd;
+      const float e = d * d;
+      if (ok[u] && !isnan(e)) { se += e; cnt += 1.f; }
+    }
+    se = wave_sum(se); cnt = wave_sum(cnt);
+    const float lp = se / cnt;
+    const float qv = lp * q.mask[b];
+    const bool counted = !isnan(qv) && qv != 0.f;
+    if (lane == 0) {
+      q.patch_l[b] = counted ? lp : 0.f;
+      q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
+    }
+    if (counted) { acc_s += qv; acc_c += 1.f; }
+
+}
+
 // forward, wave-granular: each of the 4 waves of a sample's block walks patches l = wave, wave+4, ...
 // with wave-level reductions only; the block combines the four partials once at the end.
 template <typename T>
@@ -104,6 +157,12 @@ __device__ __forceinline__ void loss_pix_cont_patch_wave(const PixContP& q, int 
     return;
   }
   const float* tg = q.target + ((size_t)n * C * q.H + py * p) * q.H + px * p;
+  if (J <= 64 * 16) {
+    if (J <= 64 * 2) loss_pix_cont_patch_cached<T, 2>(q, b, pred, tg, lane, p, C, PP, J, acc_s, acc_c);
+    else if (J <= 64 * 8) loss_pix_cont_patch_cached<T, 8>(q, b, pred, tg, lane, p, C, PP, J, acc_s, acc_c);
+    else loss_pix_cont_patch_cached<T, 16>(q, b, pred, tg, lane, p, C, PP, J, acc_s, acc_c);
+    return;
+  }
   float mean = 0.f, rstd = 1.f;
   if (q.norm_pix) {
     float s = 0.f, s2 = 0.f;
@@ -145,20 +204,22 @@ __device__ __forceinline__ void loss_pix_cont_patch_wave(const PixContP& q, int 
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void loss_pix_cont_kernel(const PixContP q) {
+__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cont_kernel(const PixContP q) {
   __shared__ float sh[4];
-  __shared__ float part[4][2];
+  __shared__ float part[16][2];
   float as = 0.f, ac = 0.f;
   if constexpr (BWD) {
     loss_pix_cont_patch<T, true>(q, blockIdx.x, sh, as, ac);
   } else {
-    const int n = blockIdx.x, wave = threadIdx.x >> 6;
-    for (int l = wave; l < q.L; l += 4) loss_pix_cont_patch_wave<T>(q, n * q.L + l, as, ac);
+    const int n = blockIdx.x, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;      // NW <= 16
+    for (int l = wave; l < q.L; l += NW) loss_pix_cont_patch_wave<T>(q, n * q.L + l, as, ac);
     if ((threadIdx.x & 63) == 0) { part[wave][0] = as; part[wave][1] = ac; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      q.acc[2 * n] = part[0][0] + part[1][0] + part[2][0] + part[3][0];
-      q.acc[2 * n + 1] = part[0][1] + part[1][1] + part[2][1] + part[3][1];
+      float ts = 0.f, tc = 0.f;
+      for (int w = 0; w < NW; ++w) { ts += part[w][0]; tc += part[w][1]; }     // fixed order: deterministic
+      q.acc[2 * n] = ts;
+      q.acc[2 * n + 1] = tc;
     }
   }
 }
@@ -201,7 +262,7 @@ __device__ __forceinline__ void loss_pix_cat_patch(const PixCatP& q, int b, floa
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
+__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_kernel(const PixCatP q) {
   __shared__ float sh[4];
   float se = 0.f, cnt = 0.f;
   if constexpr (BWD) {
@@ -224,9 +285,16 @@ __global__ __launch_bounds__(256) void loss_pix_cat_kernel(const PixCatP q) {
       se += mx + __logf(sm) - z[(int)t];
       cnt += 1.f;
     }
-    se = block_sum256(se, sh);
-    cnt = block_sum256(cnt, sh);
-    if (threadIdx.x == 0) { q.acc[2 * n] = se; q.acc[2 * n + 1] = cnt; }
+    // any block size up to 16 waves: wave sums, then a fixed-order fold
+    __shared__ float part[16][2];
+    se = wave_sum(se); cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6][0] = se; part[threadIdx.x >> 6][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ts = 0.f, tc = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { ts += part[w][0]; tc += part[w][1]; }
+      q.acc[2 * n] = ts; q.acc[2 * n + 1] = tc;
+    }
   }
 }
 

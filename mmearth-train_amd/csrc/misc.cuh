@@ -81,6 +81,39 @@ __global__ __launch_bounds__(256) void prep_kernel(const PrepDesc* __restrict__ 
   }
 }
 
+// Tiled form: a workgroup moves one 64x64 tile through LDS so that the fp32 reads run along
+// whichever source dimension is contiguous (plain copies: columns; transposed copies W^T: rows) and
+// the compute-type writes always run along destination rows. grid = (max tiles, ndesc).
+template <typename T>
+__global__ __launch_bounds__(256) void prep_tiled_kernel(const PrepDesc* __restrict__ table) {
+  __shared__ float tile[64][65];
+  const PrepDesc d = table[blockIdx.y];
+  const int tc = (d.cols + 63) / 64, tr = (d.rows + 63) / 64;
+  if ((int)blockIdx.x >= tc * tr) return;
+  const int r0 = (blockIdx.x / tc) * 64, c0 = (blockIdx.x % tc) * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (d.sc == 1 || d.sr != 1) {                  // source contiguous along columns (or fully strided)
+#pragma unroll 4
+    for (int rr = ty; rr < 64; rr += 4) {
+      const int r = r0 + rr, c = c0 + tx;
+      tile[rr][tx] = (r < d.rows && c < d.cols) ? d.src[(size_t)r * d.sr + (size_t)c * d.sc] : 0.f;
+    }
+  } else {                                       // source contiguous along rows: read transposed
+#pragma unroll 4
+    for (int cc = ty; cc < 64; cc += 4) {
+      const int r = r0 + tx, c = c0 + cc;
+      tile[tx][cc] = (r < d.rows && c < d.cols) ? d.src[(size_t)r + (size_t)c * d.sc] : 0.f;
+    }
+  }
+  __syncthreads();
+  T* dst = reinterpret_cast<T*>(d.dst);
+#pragma unroll 4
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    if (r < d.rows && c < d.cols) stf<T>(dst + (size_t)r * d.dst_ld + c, tile[rr][tx]);
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // AdamW over the flat fp32 parameter buffer (reference: main_pretrain.py:312-320, betas
 // (0.9, 0.95), timm weight-decay grouping: decay[i] != 0 marks decayed elements).

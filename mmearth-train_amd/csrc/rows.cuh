@@ -268,15 +268,32 @@ __global__ __launch_bounds__(256) void fill_mask_token_kernel(T* __restrict__ xd
 }
 
 // d(mask_token)[c] += sum over masked rows of dxdec[r, c]
+// block = 256 threads = RL row lanes x D/8 column vectors (16-byte loads); grid strides over rows
 template <typename T>
 __global__ __launch_bounds__(256) void mask_token_bwd_kernel(const T* __restrict__ dxdec, const int* __restrict__ inv,
                                                              float* __restrict__ dtoken, int rows, int D) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
-  float a = 0.f;
-  for (int r = blockIdx.y; r < rows; r += gridDim.y)
-    if (inv[r] < 0) a += ldf<T>(dxdec + (size_t)r * D + c);
-  atomicAdd(dtoken + c, a);
+  __shared__ float red[256 * 8];
+  const int vpr = D / 8;                         // D % 8 == 0 and vpr <= 256 checked by the launcher
+  const int rl_n = 256 / vpr;
+  const int v = threadIdx.x % vpr, rl = threadIdx.x / vpr;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (rl < rl_n) {
+    for (int r = blockIdx.x * rl_n + rl; r < rows; r += gridDim.x * rl_n) {
+      if (inv[r] >= 0) continue;
+      float x[8];
+      ld8<T>(dxdec + (size_t)r * D + v * 8, x);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += x[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = a[e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float t = 0.f;
+    for (int q = 0; q < rl_n; ++q) t += red[(q * vpr + c / 8) * 8 + (c & 7)];
+    atomicAdd(dtoken + c, t);
+  }
 }
 
 // pooled[n, c] = mean over L rows ; bwd handled by ln_bwd's dy_div/dy_scale broadcast

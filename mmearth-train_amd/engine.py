@@ -332,7 +332,7 @@ class Engine:
             table[i].dst = self.warena.data_ptr() + (dst["off"] + coloff) * esz
             table[i].rows, table[i].cols, table[i].sr, table[i].sc = rows, cols, sr, sc
             table[i].dst_ld = dst["ld"]
-            mx = max(mx, rows * cols)
+            mx = max(mx, ((rows + 63) // 64) * ((cols + 63) // 64))      # 64x64 tiles of the largest view
         raw = bytes(table)
         self.prep_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
         self.prep_n, self.prep_max = len(descs), mx
