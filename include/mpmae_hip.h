@@ -150,6 +150,22 @@ typedef struct MpmaeRsArgs {
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 
+/* Fused tail of the sparse stem when the stem depthwise kernel is 1x1 (patch size 8):
+ * out = LN2(act_out * (w * GELU(LN1(x)) + wb)) with both LayerNorms' x-hat / rstd saved, and the
+ * whole backward (dx, and d{g1,b1,w,wb,g2,b2} accumulated) in one pass. Replaces
+ * convnextv2_sparse.py:113-127 minus the 3x3 convolution, and their autograd. */
+typedef struct MpmaeStemTailArgs {
+  const void* x;            /* fwd: conv output [M,C]; bwd: gradient wrt the stem output [M,C] */
+  void* xhat1; float* rstd1; void* xhat2; float* rstd2;
+  void* out;                /* fwd: stem output; bwd: gradient wrt the conv output */
+  const float* g1; const float* b1; const float* w; const float* wb; const float* g2; const float* b2;
+  const uint8_t* act_in; const uint8_t* act_out;
+  float* dg1; float* db1; float* dw; float* dwb; float* dg2; float* db2;   /* bwd only */
+  float* ws; size_t ws_floats;
+  int M, C;
+} MpmaeStemTailArgs;
+int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* args, mpmae_stream_t stream);
+
 /* ---- masks / activity --------------------------------------------------------------------- */
 /* FCMAE.gen_random_mask (models/fcmae.py:214-231) on explicit noise [N,L]: mask f32 [N,L]
  * (1 = removed), vis [N,keep], inv [N,L]. */

@@ -101,6 +101,14 @@ class RsArgs(C.Structure):
                 ("rpg", c_int)]
 
 
+class StemTailArgs(C.Structure):
+    _fields_ = [("x", c_void_p), ("xhat1", c_void_p), ("rstd1", c_void_p), ("xhat2", c_void_p), ("rstd2", c_void_p),
+                ("out", c_void_p), ("g1", c_void_p), ("b1", c_void_p), ("w", c_void_p), ("wb", c_void_p),
+                ("g2", c_void_p), ("b2", c_void_p), ("act_in", c_void_p), ("act_out", c_void_p),
+                ("dg1", c_void_p), ("db1", c_void_p), ("dw", c_void_p), ("dwb", c_void_p), ("dg2", c_void_p),
+                ("db2", c_void_p), ("ws", c_void_p), ("ws_floats", c_size_t), ("M", c_int), ("C", c_int)]
+
+
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 
@@ -143,6 +151,7 @@ SYMBOLS = {
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
+    "mpmae_stem_tail": [c_int, c_int, P(StemTailArgs), c_void_p],
     "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],
     "mpmae_program_end": [c_void_p],

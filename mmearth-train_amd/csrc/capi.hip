@@ -13,6 +13,7 @@
 #include "dwconv6.cuh"
 #include "gemm_tn2.cuh"
 #include "rsc.cuh"
+#include "stemtail.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -551,6 +552,15 @@ int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, cons
   const int cpb = C < 256 ? C : 256;
   const int rows_par = 256 / cpb > 0 ? 256 / cpb : 1;
   const size_t per = (size_t)(k * k + 1) * C;
+  if (k == 1 && (C & 7) == 0 && C / 8 <= 256 && ws && ws_floats >= per) {
+    int g1 = cdiv(Mout, (256 / (C / 8)) * 8);              // ~8 rows per thread
+    if (g1 > 2048) g1 = 2048;
+    while ((size_t)g1 * per > ws_floats && g1 > 1) g1 /= 2;
+    if (dt == 0) LAUNCH(dwstride1_bwd_kernel<float>, dim3(g1), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, ws, Mout, C, act_in);
+    else LAUNCH(dwstride1_bwd_kernel<bf16_t>, dim3(g1), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, act_in);
+    launch_reduce(3, ws, g1, (int)per, dw, db, C, 0, 0, 0, S_(s));
+    RET();
+  }
   int g = 512;
   if (!ws || ws_floats < per * rows_par) return (int)hipErrorInvalidValue;
   while ((size_t)g * rows_par * per > ws_floats && g > 1) g /= 2;
@@ -973,6 +983,39 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
   if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));
   return (int)hipErrorInvalidValue;
+}
+
+int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t s) {
+  if (!a || (a->C & 7) || a->C > 512 || a->M < 1) return (int)hipErrorInvalidValue;
+  const int nvec = a->C / 8;
+  const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
+  const int rpw = 64 / G;
+  StemTailP p;
+  p.x = a->x; p.xhat1 = a->xhat1; p.rstd1 = a->rstd1; p.xhat2 = a->xhat2; p.rstd2 = a->rstd2; p.out = a->out;
+  p.g1 = a->g1; p.b1 = a->b1; p.w = a->w; p.wb = a->wb; p.g2 = a->g2; p.b2 = a->b2;
+  p.act_in = a->act_in; p.act_out = a->act_out; p.ws = a->ws; p.M = a->M; p.C = a->C;
+  int blocks = grid1d((long long)cdiv(a->M, rpw) * 64, 256, bwd ? 512 : 4096);
+  if (bwd) {
+    if (!a->ws || !a->dg1 || !a->db1 || !a->dw || !a->dwb || !a->dg2 || !a->db2) return (int)hipErrorInvalidValue;
+    while ((size_t)blocks * 4 * 6 * a->C > a->ws_floats && blocks > 1) blocks /= 2;
+    if ((size_t)blocks * 4 * 6 * a->C > a->ws_floats) return (int)hipErrorInvalidValue;
+  }
+#define ST(TT, GG) do { if (bwd) LAUNCH((stem_tail_bwd_kernel<TT, GG>), dim3(blocks), dim3(256), 0, S_(s), p); \
+                        else LAUNCH((stem_tail_fwd_kernel<TT, GG>), dim3(blocks), dim3(256), 0, S_(s), p); } while (0)
+#define ST_T(TT) do { if (G == 8) ST(TT, 8); else if (G == 16) ST(TT, 16); else if (G == 32) ST(TT, 32); else ST(TT, 64); } while (0)
+  if (dt == 0) ST_T(float); else ST_T(bf16_t);
+#undef ST_T
+#undef ST
+  if (bwd) {
+    const int nw = blocks * 4;
+    float* outs[3][2] = {{a->dg2, a->db2}, {a->dw, a->dwb}, {a->dg1, a->db1}};
+    for (int k = 0; k < 3; ++k) {      // slabs [k][wave][2][C]: e = n*C + c -> n == 0 ? first[c] : second[c]
+      const long long delta = outs[k][1] - outs[k][0];
+      if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+      launch_reduce(1, a->ws + (size_t)k * nw * 2 * a->C, nw, 2 * a->C, outs[k][0], nullptr, a->C, (int)delta, 1, 0, S_(s));
+    }
+  }
+  RET();
 }
 
 // ------------------------------------------------------------------------------------------

@@ -253,6 +253,45 @@ __global__ __launch_bounds__(256) void dwstride_bwd_kernel(const T* __restrict__
   }
 }
 
+// k == 1 (patch 8: the "depthwise stem" is a per-channel affine), C % 8 == 0: 16-byte accesses,
+// thread = (row lane, 8-channel vector), block partials folded through LDS -> slab ws[block][2][C]
+template <typename T>
+__global__ __launch_bounds__(256) void dwstride1_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ in,
+                                                            T* __restrict__ din, const float* __restrict__ w,
+                                                            float* __restrict__ ws, int Mout, int C,
+                                                            const uint8_t* __restrict__ act_in) {
+  __shared__ float red[256 * 16];
+  const int vpr = C / 8, rl_n = 256 / vpr;
+  const int v = threadIdx.x % vpr, rl = threadIdx.x / vpr;
+  float adw[8], adb[8], wv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { adw[e] = 0.f; adb[e] = 0.f; wv[e] = (rl < rl_n) ? w[v * 8 + e] : 0.f; }
+  if (rl < rl_n) {
+    for (int m = blockIdx.x * rl_n + rl; m < Mout; m += gridDim.x * rl_n) {
+      float g[8], x[8], o[8];
+      ld8<T>(dout + (size_t)m * C + v * 8, g);
+      ld8<T>(in + (size_t)m * C + v * 8, x);
+      const bool live = !act_in || act_in[m];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        adb[e] += g[e];
+        o[e] = live ? g[e] * wv[e] : 0.f;
+        adw[e] += live ? g[e] * x[e] : 0.f;
+      }
+      st8<T>(din + (size_t)m * C + v * 8, o);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = adw[e]; red[threadIdx.x * 16 + 8 + e] = adb[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i - which * C;
+    float t = 0.f;
+    for (int q = 0; q < rl_n; ++q) t += red[(q * vpr + c / 8) * 16 + which * 8 + (c & 7)];
+    ws[(size_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // decoder input: rows of masked patches take the mask token (fcmae.py:253-255); rows of
 // visible patches were written by the proj GEMM (EPI_SCATTER_ROWS).

@@ -723,12 +723,28 @@ class Engine:
                    C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
                    vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
                    grid=self.grid, H=cfg.img_size)
-        self._op(f, "stem:ln1", lib.mpmae_ln_fwd, dt, _p(self.c1), _p(self.c1hat), _p(self.rstd1), _p(self.a1),
+        self.stem_fused = (k == 1 and C0 % 8 == 0 and os.environ.get("MPMAE_STEM_FUSED", "1") != "0")
+        if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
+            a = _lib.StemTailArgs()
+            a.x, a.out = self.c1.data_ptr(), self.x0.data_ptr()
+            a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (self.c1hat, self.rstd1, self.s0hat, self.rstd2))
+            a.g1, a.b1 = P["encoder.initial_conv.1.ln.weight"].data_ptr(), P["encoder.initial_conv.1.ln.bias"].data_ptr()
+            a.w, a.wb = P["encoder.stem.0.kernel"].data_ptr(), P["encoder.stem.0.bias"].data_ptr()
+            a.g2, a.b2 = P["encoder.stem.1.ln.weight"].data_ptr(), P["encoder.stem.1.ln.bias"].data_ptr()
+            a.act_in = self.act_full.data_ptr() if self.act_full is not None else 0
+            a.act_out = self.act[0].data_ptr() if self.act[0] is not None else 0
+            a.M, a.C = self.Mfull, C0
+            self._keepalive.append(a)
+            esz = 4 if dt == F32 else 2
+            self._op(f, "stem:ln+gelu+dw+ln", lib.mpmae_stem_tail, dt, 0, C.byref(a), kind="stem_tail_fwd",
+                     nbytes=4 * self.Mfull * C0 * esz)
+        else:
+          self._op(f, "stem:ln1", lib.mpmae_ln_fwd, dt, _p(self.c1), _p(self.c1hat), _p(self.rstd1), _p(self.a1),
                  _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, 1e-6,
                  self.Mfull, C0, _p(self.act_full))
-        self._op(f, "stem:dw", lib.mpmae_dwstride_fwd, dt, _p(self.a1), _p(self.s0), _p(P["encoder.stem.0.kernel"]),
+          self._op(f, "stem:dw", lib.mpmae_dwstride_fwd, dt, _p(self.a1), _p(self.s0), _p(P["encoder.stem.0.kernel"]),
                  _p(P["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full), _p(self.act[0]))
-        self._op(f, "stem:ln2", lib.mpmae_ln_fwd, dt, _p(self.s0), _p(self.s0hat), _p(self.rstd2), _p(self.x0),
+          self._op(f, "stem:ln2", lib.mpmae_ln_fwd, dt, _p(self.s0), _p(self.s0hat), _p(self.rstd2), _p(self.x0),
                  _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, 1e-6, self.M[0], C0,
                  _p(self.act[0]))
         x = self.x0
@@ -943,20 +959,39 @@ class Engine:
                 cur = nxt
         # stem
         C0, k = dims[0], cfg.stem_k
-        ds = self.scr_dd[:self.M[0] * C0]
-        self._op(b, "stem:ln2.bwd", self._ln_bwd_fn, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
-                 _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, _p(ds), 0,
-                 _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
-        self._guard(b, ds)
-        da1 = self.scr_dxn[:self.Mfull * C0]
-        self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
-                 _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full),
-                 _p(self.ws), self.ws_floats)
         dc1 = other[:self.Mfull * C0]
-        self._op(b, "stem:ln1.bwd", self._ln_bwd_fn, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
-                 _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
-                 _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
-                 _p(self.act_full))
+        if self.stem_fused:
+            a = _lib.StemTailArgs()
+            a.x, a.out = cur.data_ptr(), dc1.data_ptr()
+            a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (self.c1hat, self.rstd1, self.s0hat, self.rstd2))
+            a.g1, a.b1 = P["encoder.initial_conv.1.ln.weight"].data_ptr(), P["encoder.initial_conv.1.ln.bias"].data_ptr()
+            a.w, a.wb = P["encoder.stem.0.kernel"].data_ptr(), P["encoder.stem.0.bias"].data_ptr()
+            a.g2, a.b2 = P["encoder.stem.1.ln.weight"].data_ptr(), P["encoder.stem.1.ln.bias"].data_ptr()
+            a.act_in = self.act_full.data_ptr() if self.act_full is not None else 0
+            a.act_out = self.act[0].data_ptr() if self.act[0] is not None else 0
+            a.dg1, a.db1 = Gd["encoder.initial_conv.1.ln.weight"].data_ptr(), Gd["encoder.initial_conv.1.ln.bias"].data_ptr()
+            a.dw, a.dwb = Gd["encoder.stem.0.kernel"].data_ptr(), Gd["encoder.stem.0.bias"].data_ptr()
+            a.dg2, a.db2 = Gd["encoder.stem.1.ln.weight"].data_ptr(), Gd["encoder.stem.1.ln.bias"].data_ptr()
+            a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+            a.M, a.C = self.Mfull, C0
+            self._keepalive.append(a)
+            self._op(b, "stem:ln+gelu+dw+ln.bwd", lib.mpmae_stem_tail, dt, 1, C.byref(a), kind="stem_tail_bwd",
+                     nbytes=5 * self.Mfull * C0 * (4 if dt == F32 else 2))
+        else:
+          ds = self.scr_dd[:self.M[0] * C0]
+          self._op(b, "stem:ln2.bwd", self._ln_bwd_fn, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
+                   _p(P["encoder.stem.1.ln.weight"]), _p(P["encoder.stem.1.ln.bias"]), 0, _p(ds), 0,
+                   _p(Gd["encoder.stem.1.ln.weight"]), _p(Gd["encoder.stem.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
+          self._guard(b, ds)
+          da1 = self.scr_dxn[:self.Mfull * C0]
+          self._op(b, "stem:dw.bwd", lib.mpmae_dwstride_bwd, dt, _p(ds), _p(self.a1), _p(da1), _p(P["encoder.stem.0.kernel"]),
+                   _p(Gd["encoder.stem.0.kernel"]), _p(Gd["encoder.stem.0.bias"]), self.M[0], C0, 8, k, _p(self.act_full),
+                   _p(self.ws), self.ws_floats)
+          dc1 = other[:self.Mfull * C0]
+          self._op(b, "stem:ln1.bwd", self._ln_bwd_fn, dt, _p(da1), 1, 1.0, _p(self.c1hat), _p(self.rstd1),
+                   _p(P["encoder.initial_conv.1.ln.weight"]), _p(P["encoder.initial_conv.1.ln.bias"]), 1, _p(dc1), 0,
+                   _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
+                   _p(self.act_full))
         self._guard(b, dc1)
         self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,
                     Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,

@@ -37,7 +37,7 @@ def test_struct_layouts_match_header(tmp_path):
     names = dict(MpmaeGeom=_lib.Geom, MpmaeGemmArgs=_lib.GemmArgs, MpmaeWgradArgs=_lib.WgradArgs,
                  MpmaeDwArgs=_lib.DwArgs, MpmaeDwWgArgs=_lib.DwWgArgs, MpmaePrepDesc=_lib.PrepDesc,
                  MpmaePixContArgs=_lib.PixContArgs, MpmaePixCatArgs=_lib.PixCatArgs, MpmaeImgArgs=_lib.ImgArgs,
-                 MpmaeRsArgs=_lib.RsArgs)
+                 MpmaeRsArgs=_lib.RsArgs, MpmaeStemTailArgs=_lib.StemTailArgs)
     src = tmp_path / "sz.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "mpmae_hip.h"\nint main(void) {{\n{body}\n  return 0;\n}}\n')
