@@ -150,6 +150,17 @@ typedef struct MpmaeRsArgs {
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 
+/* im2col of the masked fp32 NCHW image for the sparse 3x3 stem convolution (MinkowskiConvolution
+ * 3x3 of convnextv2_sparse.py:113-117): out[(n*keep+slot)*S*S + iy*S + ix][k], k = (kw*3+kh)*Cseg + cin
+ * (taps outside the image / in masked patches are zero), row stride ldo >= 9*Cseg (padding columns
+ * are written as zeros). The plain GEMM / weight-gradient entry points then run on `out`. */
+int mpmae_im2col3(int dt, const float* img, const int* vis, const int* inv, void* out, int ldo, int N,
+                  int keep, int grid, int S, int Cseg, int H, mpmae_stream_t stream);
+/* dst[r*dst_sr + c*dst_sc] += src[r*src_ld + c]: folds a padded contiguous gradient into a strided
+ * parameter layout (e.g. ME's (9, Cin, Cout) convolution kernel). */
+int mpmae_strided_add(float* dst, const float* src, int rows, int cols, int src_ld, int dst_sr,
+                      int dst_sc, mpmae_stream_t stream);
+
 /* Fused tail of the sparse stem when the stem depthwise kernel is 1x1 (patch size 8):
  * out = LN2(act_out * (w * GELU(LN1(x)) + wb)) with both LayerNorms' x-hat / rstd saved, and the
  * whole backward (dx, and d{g1,b1,w,wb,g2,b2} accumulated) in one pass. Replaces

@@ -151,6 +151,9 @@ SYMBOLS = {
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
+    "mpmae_im2col3": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                      c_void_p],
+    "mpmae_strided_add": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_stem_tail": [c_int, c_int, P(StemTailArgs), c_void_p],
     "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
     "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],

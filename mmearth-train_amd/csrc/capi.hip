@@ -985,6 +985,23 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   return (int)hipErrorInvalidValue;
 }
 
+int mpmae_im2col3(int dt, const float* img, const int* vis, const int* inv, void* out, int ldo, int N, int keep, int grid,
+                  int S, int Cseg, int H, mpmae_stream_t s) {
+  const int epv = dt == 0 ? 4 : 8;
+  if (!img || !vis || !inv || !out || ldo < 9 * Cseg || (ldo % epv) || S < 1 || S > 16) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)(S + 2) * (S + 2) * Cseg * sizeof(float);
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  if (dt == 0) LAUNCH(im2col3_kernel<float>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (float*)out, ldo, keep, grid, S, Cseg, H);
+  else LAUNCH(im2col3_kernel<bf16_t>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (bf16_t*)out, ldo, keep, grid, S, Cseg, H);
+  RET();
+}
+
+int mpmae_strided_add(float* dst, const float* src, int rows, int cols, int src_ld, int dst_sr, int dst_sc, mpmae_stream_t s) {
+  if (!dst || !src || rows < 1 || cols < 1) return (int)hipErrorInvalidValue;
+  LAUNCH(strided_add_kernel, dim3(grid1d((long long)rows * cols, 256, 256)), dim3(256), 0, S_(s), dst, src, rows, cols, src_ld, dst_sr, dst_sc);
+  RET();
+}
+
 int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t s) {
   if (!a || (a->C & 7) || a->C > 512 || a->M < 1) return (int)hipErrorInvalidValue;
   const int nvec = a->C / 8;

@@ -137,6 +137,67 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   }
 }
 
+// ---------------------------------------------------------------------------------
+// im2col of the masked image for the sparse 3x3 stem convolution (convnextv2_sparse.py:113-117 on
+// MinkowskiOps.to_sparse input): row m = (n, slot, iy, ix) of a visible patch gets the 9 x Cseg taps
+// k = (kw*3 + kh)*Cseg + cin of its 3x3 neighbourhood; taps outside the image or inside masked
+// patches are absent (zero). One workgroup per visible patch: the (S+2)^2 x Cseg window is staged in
+// LDS with row-contiguous reads of the fp32 NCHW image, rows leave as 16-byte vectors. The matrix is
+// written once per step and feeds both the forward GEMM and the weight-gradient GEMM.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ img, const int* __restrict__ vis,
+                                                      const int* __restrict__ inv, T* __restrict__ out, int ldo,
+                                                      int keep, int grid, int S, int Cseg, int H) {
+  extern __shared__ float win[];                  // [(S+2)*(S+2)][Cseg]
+  const int nk = blockIdx.x, n = nk / keep;
+  const int patch = vis[nk];
+  const int py = patch / grid, px = patch - py * grid;
+  const int W2 = S + 2, L = grid * grid;
+  for (int i = threadIdx.x; i < W2 * W2 * Cseg; i += blockDim.x) {
+    const int wx = i % W2, r = i / W2, wy = r % W2, cin = r / W2;       // x fastest: contiguous image reads
+    const int gy = py * S + wy - 1, gx = px * S + wx - 1;
+    float v = 0.f;
+    if (gy >= 0 && gx >= 0 && gy < H && gx < H) {
+      const int pp = (gy / S) * grid + gx / S;
+      if (inv[n * L + pp] >= 0) v = img[((size_t)(n * Cseg + cin) * H + gy) * H + gx];
+    }
+    win[(wy * W2 + wx) * Cseg + cin] = v;
+  }
+  __syncthreads();
+  constexpr int EPV = 16 / sizeof(T);
+  const int K = 9 * Cseg, vpr = ldo / EPV;
+  for (int i = threadIdx.x; i < S * S * vpr; i += blockDim.x) {
+    const int q = i / vpr, v = i - q * vpr;
+    const int iy = q / S, ix = q - iy * S;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+      const int k = v * EPV + e;
+      float x = 0.f;
+      if (k < K) {
+        const int tap = k / Cseg, cin = k - tap * Cseg;
+        const int kh = tap % 3, kw = tap / 3;
+        x = win[((iy + kh) * W2 + ix + kw) * Cseg + cin];
+      }
+      o[e] = x;
+    }
+    T* dst = out + ((size_t)nk * S * S + q) * ldo + v * EPV;
+    if (sizeof(T) == 2) st8<T>(dst, o);
+    else *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dst[r*dsr + c*dsc] += src[r*sld + c]   (fold a padded, contiguous gradient into a strided parameter layout)
+__global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows,
+                                                          int cols, int sld, int dsr, int dsc) {
+  const int total = rows * cols;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / cols, c = i - r * cols;
+    dst[(size_t)r * dsr + (size_t)c * dsc] += src[(size_t)r * sld + c];
+  }
+}
+
 // Hyper-parameter hand-over for replayed steps: the host writes record t into slot t % R of a pinned
 // ring; this kernel (one per optimizer step, in stream order) copies the slot its device-side
 // counter points at into `hp` and advances the counter. A plain async H2D copy would read the

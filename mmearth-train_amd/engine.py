@@ -719,10 +719,20 @@ class Engine:
             for i in range(1, 4):
                 self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2)
         wt = self.w["stem.Wt"]
-        self._gemm(f, "stem:conv", "IM2COL3", "STORE", A=img, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
-                   C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
-                   vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
-                   grid=self.grid, H=cfg.img_size)
+        self.stem_im2col = os.environ.get("MPMAE_STEM_IM2COL", "1") != "0"
+        if self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
+            self.ldk = _rup(9 * cfg.in_chans, 8)
+            self.col = self._t(self.Mfull * self.ldk)
+            self._op(f, "stem:im2col", lib.mpmae_im2col3, dt, _p(img), _p(self.vis), _p(self.inv), _p(self.col), self.ldk,
+                     N, self.keep, self.grid, p, cfg.in_chans, cfg.img_size, kind="im2col3",
+                     nbytes=self.Mfull * self.ldk * (4 if dt == F32 else 2) + img.numel() * 4)
+            self._gemm(f, "stem:conv", "NONE", "STORE", A=self.col, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
+                       C=self.c1, M=self.Mfull, N=C0, K=self.ldk, lda=self.ldk, ldb=wt["ld"], ldc=C0, act=self.act_full)
+        else:
+            self._gemm(f, "stem:conv", "IM2COL3", "STORE", A=img, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
+                       C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
+                       vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
+                       grid=self.grid, H=cfg.img_size)
         self.stem_fused = (k == 1 and C0 % 8 == 0 and os.environ.get("MPMAE_STEM_FUSED", "1") != "0")
         if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
@@ -993,10 +1003,20 @@ class Engine:
                    _p(Gd["encoder.initial_conv.1.ln.weight"]), _p(Gd["encoder.initial_conv.1.ln.bias"]), self.Mfull, C0,
                    _p(self.act_full))
         self._guard(b, dc1)
-        self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,
-                    Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,
-                    db=Gd["encoder.initial_conv.0.bias"], vis=self.vis, inv=self.inv, keep=self.keep, L=L, S=self.p,
-                    Cseg=cfg.in_chans, grid=self.grid, H=cfg.img_size)
+        if self.stem_im2col:
+            Kc = 9 * cfg.in_chans
+            self.dw_stem_pad = torch.zeros(C0 * self.ldk, dtype=torch.float32, device=self.device)
+            self._op(b, "stem:conv.dWpad.zero", lib.mpmae_memset_async, _p(self.dw_stem_pad), 0, C0 * self.ldk * 4)
+            self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", P=dc1, Q=self.col, M=self.Mfull, Nn=C0, Kk=self.ldk, ldp=C0,
+                        ldq=self.ldk, dW=self.dw_stem_pad, sn=self.ldk, sk=1, db=Gd["encoder.initial_conv.0.bias"])
+            # (C0, 9*Cin) padded row-major -> ME kernel layout (9, Cin, C0)
+            self._op(b, "stem:conv.dW.fold", lib.mpmae_strided_add, _p(Gd["encoder.initial_conv.0.kernel"]),
+                     _p(self.dw_stem_pad), C0, Kc, self.ldk, 1, C0)
+        else:
+            self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,
+                        Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,
+                        db=Gd["encoder.initial_conv.0.bias"], vis=self.vis, inv=self.inv, keep=self.keep, L=L, S=self.p,
+                        Cseg=cfg.in_chans, grid=self.grid, H=cfg.img_size)
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
