@@ -216,6 +216,17 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
                  const float* rstd, const float* gamma, const float* beta, int act, void* dx,
                  int accumulate, float* dgamma, float* dbeta, int M, int C, const uint8_t* rowmask,
                  float* ws, size_t ws_floats, mpmae_stream_t stream);
+/* LayerNorm in front of a 2x2-stride-2 downsample convolution (convnextv2_sparse.py:131-137): the
+ * affine output of child row (patch, cy, cx) of a stage with S points per patch side is written to
+ * y_grouped[parent (patch, cy/2, cx/2)][(cx&1)*2 + (cy&1)][C], i.e. directly in the [M/4][4C] operand
+ * layout of the convolution-as-GEMM (k = kidx*C + c, ME kernel order); inactive rows write zeros.
+ * The backward reads dy from the same grouped layout. */
+int mpmae_ln_fwd_down(int dt, const void* x, void* xhat, float* rstd, void* y_grouped, const float* gamma,
+                      const float* beta, float eps, int M, int C, int S, const uint8_t* rowmask,
+                      mpmae_stream_t stream);
+int mpmae_ln_bwd_down(int dt, const void* dy_grouped, const void* xhat, const float* rstd,
+                      const float* gamma, void* dx, float* dgamma, float* dbeta, int M, int C, int S,
+                      const uint8_t* rowmask, float* ws, size_t ws_floats, mpmae_stream_t stream);
 /* MinkowskiGRN (batch-global, eps 1e-6; sparse_norm_layers.py:24-33) and GRN (per-sample,
  * eps 1e-4; norm_layers.py:41-44): statistics finalisation for G groups of H channels. */
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx,

@@ -203,16 +203,17 @@ static void launch_ln_fwd(const void* x, void* xhat, float* rstd, void* y, const
                      act, eps, M, C, rowmask);
 }
 
-int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
-                 float eps, int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
+static int ln_fwd_impl(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
+                       float eps, int M, int C, const uint8_t* rowmask, int down_S, mpmae_stream_t s) {
   if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if (down_S && ((C & 7) || C > 1024 || (down_S & 1))) return (int)hipErrorInvalidValue;
   if ((C & 7) == 0 && C <= 1024) {
     const int nvec = C / 8;
     const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
     const int per = cdiv(nvec, G);
     const int rpw = 64 / G;
     const int blocks = grid1d((long long)cdiv(M, rpw) * 64, 256, 4096);
-#define LNF(TT, GG, PP) LAUNCH((ln_fwd_v2_kernel<TT, GG, PP>), dim3(blocks), dim3(256), 0, S_(s), (const TT*)x, (TT*)xhat, rstd, (TT*)y, gamma, beta, act, eps, M, C, rowmask)
+#define LNF(TT, GG, PP) LAUNCH((ln_fwd_v2_kernel<TT, GG, PP>), dim3(blocks), dim3(256), 0, S_(s), (const TT*)x, (TT*)xhat, rstd, (TT*)y, gamma, beta, act, eps, M, C, rowmask, down_S)
 #define LNF_T(TT) do { if (G == 8) LNF(TT, 8, 1); else if (G == 16) LNF(TT, 16, 1); else if (G == 32) LNF(TT, 32, 1); else if (per == 1) LNF(TT, 64, 1); else LNF(TT, 64, 2); } while (0)
     if (dt == 0) LNF_T(float); else LNF_T(bf16_t);
 #undef LNF_T
@@ -224,10 +225,22 @@ int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const 
   RET();
 }
 
-int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
-                 const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
-                 int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, mpmae_stream_t s) {
+int mpmae_ln_fwd(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
+                 float eps, int M, int C, const uint8_t* rowmask, mpmae_stream_t s) {
+  return ln_fwd_impl(dt, x, xhat, rstd, y, gamma, beta, act, eps, M, C, rowmask, 0, s);
+}
+
+int mpmae_ln_fwd_down(int dt, const void* x, void* xhat, float* rstd, void* y_grouped, const float* gamma, const float* beta,
+                      float eps, int M, int C, int S, const uint8_t* rowmask, mpmae_stream_t s) {
+  if (S < 2 || !y_grouped) return (int)hipErrorInvalidValue;
+  return ln_fwd_impl(dt, x, xhat, rstd, y_grouped, gamma, beta, 0, eps, M, C, rowmask, S, s);
+}
+
+static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
+                       const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
+                       int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, int down_S, mpmae_stream_t s) {
   if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if (down_S && ((C & 7) || C > 1024 || (down_S & 1))) return (int)hipErrorInvalidValue;
   int blocks = grid1d((long long)M * 64, 256, 1024);
   if (!ws || ws_floats < (size_t)2 * C) return (int)hipErrorInvalidValue;
   if ((size_t)blocks * 2 * C > ws_floats) blocks = (int)(ws_floats / ((size_t)2 * C));
@@ -238,7 +251,7 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
     const int rpw = 64 / G;
     int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, 512);          // <= 2048 waves -> slab rows
     while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
-#define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask)
+#define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask, down_S)
 #define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
     if (dt == 0) LNB_T(float); else LNB_T(bf16_t);
 #undef LNB_T
@@ -259,6 +272,21 @@ int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void*
     return (int)hipErrorInvalidValue;     // both or neither
   }
   RET();
+}
+
+int mpmae_ln_bwd(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
+                 const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
+                 int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, mpmae_stream_t s) {
+  return ln_bwd_impl(dt, dy, dy_div, dy_scale, xhat, rstd, gamma, beta, act, dx, accumulate, dgamma, dbeta, M, C, rowmask,
+                     ws, ws_floats, 0, s);
+}
+
+int mpmae_ln_bwd_down(int dt, const void* dy_grouped, const void* xhat, const float* rstd, const float* gamma, void* dx,
+                      float* dgamma, float* dbeta, int M, int C, int S, const uint8_t* rowmask, float* ws, size_t ws_floats,
+                      mpmae_stream_t s) {
+  if (S < 2 || !dy_grouped) return (int)hipErrorInvalidValue;
+  return ln_bwd_impl(dt, dy_grouped, 1, 1.0f, xhat, rstd, gamma, nullptr, 0, dx, 0, dgamma, dbeta, M, C, rowmask, ws,
+                     ws_floats, S, s);
 }
 
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx, float* Ainv,

@@ -13,12 +13,22 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Element offset of row m of a stage with S points per patch side inside the "grouped" matrix
+// [parent rows][4][C] that the 2x2-stride-2 downsample convolution reads as a plain GEMM operand:
+// parent = (patch, iy/2, ix/2), group kidx = (ix&1)*2 + (iy&1) (k = kidx*C + c, gemm.cuh down_child_row).
+__device__ __forceinline__ size_t down_group_off(int m, int S, int C) {
+  const int P = S * S, nk = m / P, q = m - nk * P, cy = q / S, cx = q - cy * S;
+  const int Sp = S >> 1;
+  const int parent = nk * (Sp * Sp) + (cy >> 1) * Sp + (cx >> 1);
+  return ((size_t)parent * 4 + ((cx & 1) * 2 + (cy & 1))) * C;
+}
+
 template <typename T, int G, int PER>
 __global__ __launch_bounds__(256) void ln_fwd_v2_kernel(const T* __restrict__ x, T* __restrict__ xhat,
                                                         float* __restrict__ rstd_out, T* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int act, float eps, int M, int C,
-                                                        const uint8_t* __restrict__ rowmask) {
+                                                        const uint8_t* __restrict__ rowmask, int down_S) {
   constexpr int RPW = 64 / G;                      // rows per wave
   const int lane = threadIdx.x & 63;
   const int gl = lane % G, rl = lane / G;
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(256) void ln_fwd_v2_kernel(const T* __restrict__ x,
             if (act == 1) u[e] = gelu_t<T>(u[e]);
             if (!live) u[e] = 0.f;
           }
-          st8<T>(y + (size_t)m * C + vi * 8, u);
+          st8<T>(y + (down_S ? down_group_off(m, down_S, C) : (size_t)m * C) + vi * 8, u);
         }
       }
     }
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         int act, T* __restrict__ dx, int accumulate,
                                                         float* __restrict__ ws, int M, int C,
-                                                        const uint8_t* __restrict__ rowmask) {
+                                                        const uint8_t* __restrict__ rowmask, int down_S) {
   constexpr int RPW = 64 / G;
   const int lane = threadIdx.x & 63;
   const int gl = lane % G, rl = lane / G;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
       if (live && vi < nvec) {
         float d[8];
         ld8<T>(xhat + (size_t)m * C + vi * 8, xh[p]);
-        ld8<T>(dy + (size_t)(m / dy_div) * C + vi * 8, d);
+        ld8<T>(dy + (down_S ? down_group_off(m, down_S, C) : (size_t)(m / dy_div) * C) + vi * 8, d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float dd = d[e] * dy_scale;

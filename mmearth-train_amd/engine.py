@@ -53,6 +53,7 @@ class Engine:
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.disable_rsc = os.environ.get("MPMAE_RSC", "1") == "0"
+        self.down_grouped = os.environ.get("MPMAE_DOWN_GROUPED", "1") != "0"
         self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
@@ -341,6 +342,10 @@ class Engine:
     def _ln_bwd_fn(self, *args):
         *a, stream = args
         return self.lib.mpmae_ln_bwd(*a, _p(self.ws), self.ws_floats, stream)
+
+    def _ln_bwd_down_fn(self, *args):
+        *a, stream = args
+        return self.lib.mpmae_ln_bwd_down(*a, _p(self.ws), self.ws_floats, stream)
 
     def _colstats_fn(self, *args):
         *a, stream = args
@@ -764,13 +769,26 @@ class Engine:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
                 dn["x"] = x
-                self._op(f, pre + ":ln", lib.mpmae_ln_fwd, dt, _p(x), _p(dn["xhat"]), _p(dn["rstd"]), None, None, None,
-                         0, 1e-6, self.M[i - 1], dims[i - 1], _p(self.act[i - 1]))
+                Ci = dims[i - 1]
                 wd = self.w[f"down{i - 1}.Wt"]
-                self._gemm(f, pre + ":conv", "DOWN_GATHER", "STORE", A=dn["xhat"], B=wd["t"], bias=P[pre + ".1.bias"],
-                           C=dn["out"], M=self.M[i], N=dims[i], K=4 * dims[i - 1], lda=dims[i - 1], ldb=wd["ld"],
-                           ldc=dims[i], p0=P[pre + ".0.ln.weight"], p1=P[pre + ".0.ln.bias"], S=self.S[i],
-                           Cseg=dims[i - 1], act=self.act[i], act_src=self.act[i - 1])
+                dn["grouped"] = (self.down_grouped and Ci % 8 == 0 and self.S[i - 1] % 2 == 0)
+                if dn["grouped"]:
+                    # LN writes its affine output straight into the [M_i][4*Ci] operand layout of the 2x2/2 convolution,
+                    # which then is a plain GEMM (and its weight gradient a plain TN product)
+                    if "yg" not in dn:
+                        dn["yg"] = self._t(self.M[i] * 4 * Ci)
+                    self._op(f, pre + ":ln", lib.mpmae_ln_fwd_down, dt, _p(x), _p(dn["xhat"]), _p(dn["rstd"]), _p(dn["yg"]),
+                             _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 1e-6, self.M[i - 1], Ci, self.S[i - 1],
+                             _p(self.act[i - 1]), kind="ln_fwd_down", nbytes=3 * self.M[i - 1] * Ci * (4 if dt == F32 else 2))
+                    self._gemm(f, pre + ":conv", "NONE", "STORE", A=dn["yg"], B=wd["t"], bias=P[pre + ".1.bias"], C=dn["out"],
+                               M=self.M[i], N=dims[i], K=4 * Ci, lda=4 * Ci, ldb=wd["ld"], ldc=dims[i], act=self.act[i])
+                else:
+                    self._op(f, pre + ":ln", lib.mpmae_ln_fwd, dt, _p(x), _p(dn["xhat"]), _p(dn["rstd"]), None, None, None,
+                             0, 1e-6, self.M[i - 1], dims[i - 1], _p(self.act[i - 1]))
+                    self._gemm(f, pre + ":conv", "DOWN_GATHER", "STORE", A=dn["xhat"], B=wd["t"], bias=P[pre + ".1.bias"],
+                               C=dn["out"], M=self.M[i], N=dims[i], K=4 * dims[i - 1], lda=dims[i - 1], ldb=wd["ld"],
+                               ldc=dims[i], p0=P[pre + ".0.ln.weight"], p1=P[pre + ".0.ln.bias"], S=self.S[i],
+                               Cseg=dims[i - 1], act=self.act[i], act_src=self.act[i - 1])
                 x = dn["out"]
             for j in range(cfg.depths[i]):
                 x = self._block_fwd(f, self.blocks[bi], x)
@@ -952,18 +970,29 @@ class Engine:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
                 Ci, Co = dims[i - 1], dims[i]
-                self._side_wgrad(b, pre + ":wgrad", "NONE", "DOWN_GATHER", [cur], P=cur, Q=dn["xhat"], M=self.M[i], Nn=Co, Kk=4 * Ci,
-                            ldp=Co, ldq=Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"],
-                            qp0=P[pre + ".0.ln.weight"], qp1=P[pre + ".0.ln.bias"], S=self.S[i], Cseg=Ci,
-                            act_src=self.act[i - 1])
                 wd = self.w[f"down{i - 1}.W"]
-                dxn = self.scr_dxn[:self.M[i - 1] * Ci]
-                self._gemm(b, pre + ":dgrad", "NONE", "DOWN_DGRAD", A=cur, B=wd["t"], C=dxn, M=self.M[i], N=4 * Ci, K=Co,
-                           lda=Co, ldb=wd["ld"], ldc=Ci, S=self.S[i], Cseg=Ci, act_src=self.act[i - 1])
                 nxt = other[:self.M[i - 1] * Ci]
-                self._op(b, pre + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
-                         _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
-                         _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
+                if dn["grouped"]:
+                    self._side_wgrad(b, pre + ":wgrad", "NONE", "NONE", [cur], P=cur, Q=dn["yg"], M=self.M[i], Nn=Co, Kk=4 * Ci,
+                                     ldp=Co, ldq=4 * Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"])
+                    dyg = self.scr_dxn[:self.M[i] * 4 * Ci]
+                    self._gemm(b, pre + ":dgrad", "NONE", "STORE", A=cur, B=wd["t"], C=dyg, M=self.M[i], N=4 * Ci, K=Co,
+                               lda=Co, ldb=wd["ld"], ldc=4 * Ci)
+                    self._op(b, pre + ":ln.bwd", self._ln_bwd_down_fn, dt, _p(dyg), _p(dn["xhat"]), _p(dn["rstd"]),
+                             _p(P[pre + ".0.ln.weight"]), _p(nxt), _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]),
+                             self.M[i - 1], Ci, self.S[i - 1], _p(self.act[i - 1]), kind="ln_bwd_down",
+                             nbytes=3 * self.M[i - 1] * Ci * (4 if dt == F32 else 2))
+                else:
+                    self._side_wgrad(b, pre + ":wgrad", "NONE", "DOWN_GATHER", [cur], P=cur, Q=dn["xhat"], M=self.M[i], Nn=Co,
+                                     Kk=4 * Ci, ldp=Co, ldq=Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"],
+                                     qp0=P[pre + ".0.ln.weight"], qp1=P[pre + ".0.ln.bias"], S=self.S[i], Cseg=Ci,
+                                     act_src=self.act[i - 1])
+                    dxn = self.scr_dxn[:self.M[i - 1] * Ci]
+                    self._gemm(b, pre + ":dgrad", "NONE", "DOWN_DGRAD", A=cur, B=wd["t"], C=dxn, M=self.M[i], N=4 * Ci, K=Co,
+                               lda=Co, ldb=wd["ld"], ldc=Ci, S=self.S[i], Cseg=Ci, act_src=self.act[i - 1])
+                    self._op(b, pre + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(dn["xhat"]), _p(dn["rstd"]),
+                             _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
+                             _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
                 self._guard(b, nxt)
                 other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
                 cur = nxt
