@@ -93,11 +93,16 @@ def per_kernel_times(eng, reps=3, by_name=False, split_lanes=False):
 
 # bench "kind" -> HIP kernel symbol (as rocprofv3 prints it) of the launch that moves the data
 KIND_TO_KERNEL = {
-    "wgrad<NONE,NONE>": "gemm_tn_bf16_kernel",
-    "dwconv7": "dwconv7_v5_kernel",
+    "wgrad<NONE,NONE>": "gemm_tn2_kernel",
+    "dwconv7": "dwconv7_v6",
     "dwconv7_wgrad": "dwconv7_wgrad_v5_kernel",
     "grn_apply": "grn_apply_kernel",
     "grn_bwd_apply": "grn_bwd_apply_kernel",
+    "rs<0>": "rsc_wide_kernel",
+    "rs<1>": "rsc_wide_kernel",
+    "rs<4>": "rsc_narrow_kernel",
+    "rs<5>": "rsc_narrow_kernel",
+    "gemm<NONE,STORE>": "gemm_nt_bf16_kernel",
 }
 
 

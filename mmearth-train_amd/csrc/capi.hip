@@ -626,7 +626,7 @@ int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mp
 
 // ------------------------------------------------------------------------------------------
 int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
-  dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 1024);   // forward: one 16-wave block per sample
+  dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 512) ;   // forward: one 16-wave block per sample
   if (dt == 0) { if (bwd) LAUNCH((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
                  else LAUNCH((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
   else { if (bwd) LAUNCH((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);

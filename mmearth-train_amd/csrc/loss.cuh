@@ -92,25 +92,31 @@ __device__ __forceinline__ void loss_pix_cont_patch(const PixContP& q, int b, fl
 
 // register-cached patch (J <= 64*NCACHE elements): returns through acc_s / acc_c
 template <typename T, int NCACHE>
-__device__ __forceinline__ void loss_pix_cont_patch_cached(const PixContP& q, int b, const T* pred, const float* tg,
+__device__ __noinline__ void loss_pix_cont_patch_cached(const PixContP& q, int b, const T* pred, const float* tg,
                                                            int lane, int p, int C, int PP, int J, float& acc_s, float& acc_c) {
     // register-cached form: every target / prediction element of the patch is loaded exactly once and
     // all loads of the patch are in flight together (one memory latency per patch instead of one per pass)
     float tv[NCACHE], pv[NCACHE];
-    bool ok[NCACHE];
+    // loads go out in groups of 4 (x2 arrays): enough in flight to hide the latency, and the 64-bit
+    // addresses of one group are dead before the next is formed (16 at once spilled 141 VGPRs)
 #pragma unroll
-    for (int u = 0; u < NCACHE; ++u) {
-      const int i = lane + 64 * u;
-      ok[u] = i < J;
-      const int ic = ok[u] ? i : 0;
-      const int c = ic / PP, r = ic - c * PP, ph = r / p, pw = r - ph * p;
-      tv[u] = tg[((size_t)c * q.H + ph) * q.H + pw];          // clamped index, unconditional: a load under a
-      pv[u] = ldf<T>(pred + r * C + c);                      // per-lane branch is serialised with a wait each
+    for (int ub = 0; ub < NCACHE; ub += 4) {
+#pragma unroll
+      for (int uu = 0; uu < 4 && ub + uu < NCACHE; ++uu) {
+        const int u = ub + uu;
+        const int i = lane + 64 * u;
+        const int ic = i < J ? i : 0;
+        const int c = ic / PP, r = ic - c * PP, ph = r / p, pw = r - ph * p;
+        tv[u] = tg[((size_t)c * q.H + ph) * q.H + pw];          // clamped index, unconditional: a load under a
+        pv[u] = ldf<T>(pred + r * C + c);                      // per-lane branch is serialised with a wait each
+      }
+      asm volatile("" ::: "memory");
     }
 #pragma unroll
     for (int u = 0; u < NCACHE; ++u) {
-      tv[u] = ok[u] ? nan_to_num0(tv[u]) : 0.f;
-      pv[u] = ok[u] ? pv[u] : 0.f;
+      const bool okk = lane + 64 * u < J;
+      tv[u] = okk ? nan_to_num0(tv[u]) : 0.f;
+      pv[u] = okk ? pv[u] : 0.f;
     }
     float mean = 0.f, rstd = 1.f;
     if (q.norm_pix) {
@@ -120,7 +126,7 @@ __device__ __forceinline__ void loss_pix_cont_patch_cached(const PixContP& q, in
       mean = wave_sum(s) / J;
       float v = 0.f;
 #pragma unroll
-      for (int u = 0; u < NCACHE; ++u) { const float d = ok[u] ? tv[u] - mean : 0.f; v += d * d; }
+      for (int u = 0; u < NCACHE; ++u) { const float d = (lane + 64 * u < J) ? tv[u] - mean : 0.f; v += d * d; }
       v = wave_sum(v);
       rstd = 1.f / sqrtf(v / (J - 1) + 1.0e-6f);
     }
@@ -129,7 +135,7 @@ __device__ __forceinline__ void loss_pix_cont_patch_cached(const PixContP& q, in
     for (int u = 0; u < NCACHE; ++u) {
       const float d = pv[u] - (tv[u] - mean) * rstd;
       const float e = d * d;
-      if (ok[u] && !isnan(e)) { se += e; cnt += 1.f; }
+      if (lane + 64 * u < J && !isnan(e)) { se += e; cnt += 1.f; }
     }
     se = wave_sum(se); cnt = wave_sum(cnt);
     const float lp = se / cnt;
@@ -204,7 +210,7 @@ __device__ __forceinline__ void loss_pix_cont_patch_wave(const PixContP& q, int 
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cont_kernel(const PixContP q) {
+__global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_kernel(const PixContP q) {
   __shared__ float sh[4];
   __shared__ float part[16][2];
   float as = 0.f, ac = 0.f;
