@@ -491,6 +491,20 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
+      (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->dd) & 3) == 0) {
+    const size_t per = (size_t)50 * a->C;
+    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
+    static int nbs1 = -1;
+    if (nbs1 < 0) { const char* e = getenv("MPMAE_DWW_S1_NB"); nbs1 = e ? atoi(e) : 0; }
+    const int want = nbs1 > 0 ? nbs1 : (cdiv(a->C, 64) <= 5 ? 128 : 64);      // ~512-640 workgroups in total (measured)
+    int nb = a->g.N < want ? a->g.N : want;
+    if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
+    dim3 g(nb, cdiv(a->C, 64));
+    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a);
+    launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
+    RET();
+  }
   if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;

@@ -270,3 +270,110 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
     *reinterpret_cast<uint32_t*>(out + (size_t)rows[o] * C + c) = live ? f2bf2(r.x, r.y) : 0u;
   }
 }
+
+// S = 1 weight / bias gradient, same mapping as dwconv7_v6s1_kernel: wave = 16 channels, lane = (cp, ox);
+// persistent over samples (n = blockIdx.x, += gridDim.x), 49 packed tap accumulators per lane, the 7 column
+// lanes of a channel pair folded through LDS at the end -> slab ws[blockIdx.x][50][C].
+// grid = (nblocks, C/64), block = 256 (4 independent channel chunks).
+template <int G>
+__global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q) {
+  using T = bf16_t;
+  constexpr int CW = 16, MS = G + 6, MAPB = ((MS * MS * CW * 2 + 15) / 16) * 16;
+  constexpr int REDB = 8 * 10 * CW * 4;             // fold buffer per wave: [8 ox lanes][10 taps][16] floats, 5 passes
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * (MAPB > REDB ? MAPB : REDB)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  unsigned char* wbase = smem + wave * (MAPB > REDB ? MAPB : REDB);
+  T* map = reinterpret_cast<T*>(wbase);
+  const int C = q.C, c0 = (blockIdx.y * 4 + wave) * CW;
+  const bool chunk_ok = c0 < C;
+  const int cc0 = chunk_ok ? c0 : 0;
+  const int cp = lane & 7, ox = lane >> 3;
+  const bool col_ok = ox < G;
+  const int c = cc0 + 2 * cp;
+  const T* x = reinterpret_cast<const T*>(q.x);
+  const T* dd = reinterpret_cast<const T*>(q.dd);
+  {
+    uint4* m4 = reinterpret_cast<uint4*>(map);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < MAPB / 16; i += 64) m4[i] = z;
+  }
+  f32x2_t adw[49], adb = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 49; ++k) adw[k] = (f32x2_t){0.f, 0.f};
+  const int items = q.g.keep * 2;
+  for (int n = blockIdx.x; n < q.g.N; n += gridDim.x) {
+    // stage this sample's visible rows (each wave its own 16 channels): wave-private LDS, no block barrier needed
+    int dst[2];
+    uint4 val[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int it = lane + 64 * u;
+      const bool ok = it < items;
+      const int v = it & 1, slot = ok ? it >> 1 : 0;
+      const int patch = q.g.vis ? q.g.vis[n * q.g.keep + slot] : slot;
+      const int py = patch / G, px = patch - py * G;
+      val[u] = *reinterpret_cast<const uint4*>(x + (size_t)(n * q.g.keep + slot) * C + cc0 + v * 8);
+      dst[u] = ok ? ((py + 3) * MS + px + 3) * CW + v * 8 : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (dst[u] >= 0) *reinterpret_cast<uint4*>(map + dst[u]) = val[u];
+    __builtin_amdgcn_s_waitcnt(0);                 // the wave's LDS writes are complete before its own reads
+    __builtin_amdgcn_wave_barrier();
+    f32x2_t g[G];
+#pragma unroll
+    for (int o = 0; o < G; ++o) {
+      const int patch = o * G + (col_ok ? ox : 0);
+      const int slot = q.g.inv ? q.g.inv[n * G * G + patch] : patch;
+      const int row = slot >= 0 ? n * q.g.keep + slot : 0;
+      const uint32_t raw = *reinterpret_cast<const uint32_t*>(dd + (size_t)row * C + c);
+      g[o] = (slot >= 0 && col_ok) ? bf2x2_to_f2(raw) : (f32x2_t){0.f, 0.f};
+      adb += g[o];
+    }
+    const T* tile = map + (col_ok ? ox : 0) * CW + 2 * cp;
+    int toff = 0;
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) {
+      if (kx > 0)
+        asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
+                     "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
+#pragma unroll
+      for (int y = 0; y < G + 6; ++y) {
+        const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW));
+#pragma unroll
+        for (int o = 0; o < G; ++o) {
+          const int ky = y - o;
+          if (ky >= 0 && ky < 7) adw[ky * 7 + kx] = g[o] * v + adw[ky * 7 + kx];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) if (dst[u] >= 0) *reinterpret_cast<uint4*>(map + dst[u]) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  // fold the G column lanes of every channel pair through the wave's LDS region
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+  float* red = reinterpret_cast<float*>(wbase);           // [8][10][16]
+  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
+#pragma unroll
+  for (int kb = 0; kb < 5; ++kb) {
+#pragma unroll
+    for (int kk = 0; kk < 10; ++kk) {
+      const int k = kb * 10 + kk;
+      *reinterpret_cast<f32x2_t*>(red + (ox * 10 + kk) * CW + 2 * cp) = (k < 49) ? adw[k < 49 ? k : 0] : adb;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (chunk_ok) {
+      for (int i = lane; i < 10 * CW; i += 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int o = 0; o < G; ++o) v += red[o * 10 * CW + i];
+        const int kk = i / CW, cc = i - kk * CW;
+        slab[(kb * 10 + kk) * C + c0 + cc] = v;
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
