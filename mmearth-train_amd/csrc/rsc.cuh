@@ -37,6 +37,7 @@ __device__ __forceinline__ void unpack4(const uint2& a, float (&o)[4]) {
 template <int KC, int MODE, int RT, int NC>
 __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int cols_per_split) {
   using T = bf16_t;
+  static_assert(NC % 32 == 0, "chunks are whole tile pairs");
   constexpr int KS = (KC + 31) / 32, KP = KS * 32, LDW = KP + 8, VPR = KP / 8, WV = (NC * VPR + 255) / 256;
   constexpr bool PAD = KP != KC;                 // K padded with zero columns (C = 40 / 80)
   static_assert(KC % 8 == 0 && ((KP / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
@@ -137,62 +138,73 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
   for (int c = 0; c < nch; ++c) {
     if (c + 1 < nch) wload(c + 1);
     const bf16_t* wb = Wc + (size_t)(c & 1) * NC * LDW;
+    // tile PAIRS: the weight rows of two 16-wide tiles are interleaved so that a lane's 2 x 4 accumulator
+    // rows are 8 CONSECUTIVE output columns (tile 0 <- columns lg*8 + r, tile 1 <- columns lg*8 + 4 + r):
+    // one 16-byte store / load per row and pair instead of two 8-byte ones
 #pragma unroll
-    for (int j = 0; j < NC / 16; ++j) {
-      const int nl = c * NC + j * 16 + lg * 4;            // first of this lane's 4 columns, relative to n_begin
-      const int n4 = n_begin + nl;
-      uint2 hraw[RT];
+    for (int jp = 0; jp < NC / 32; ++jp) {
+      const int nl = c * NC + jp * 32 + lg * 8;            // first of this lane's 8 columns, relative to n_begin
+      const int n8 = n_begin + nl;
+      uint4 hraw[RT];
       if (MODE == 1) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = rbase + rt * 16 + lr;
-          hraw[rt] = (row < p.M) ? *reinterpret_cast<const uint2*>(p.R + (size_t)row * HN + n4) : make_uint2(0u, 0u);
+          hraw[rt] = (row < p.M) ? *reinterpret_cast<const uint4*>(p.R + (size_t)row * HN + n8) : make_uint4(0u, 0u, 0u, 0u);
         }
       }
-      bf16x8_t wf[KS];
+      bf16x8_t wf[2][KS];
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        wf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wb + (j * 16 + lr) * LDW + s * 32 + lg * 8));
-      float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
-      float bias[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+          wf[t][s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(
+              wb + (jp * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * LDW + s * 32 + lg * 8));
+      float cs0[8], cs1[8], bias[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { cs0[e] = 0.f; cs1[e] = 0.f; bias[e] = 0.f; }
       if (MODE == 0 && p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n4);
-        bias[0] = b.x; bias[1] = b.y; bias[2] = b.z; bias[3] = b.w;
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n8), b1 = *reinterpret_cast<const float4*>(p.bias + n8 + 4);
+        bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t acc[2];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[rt][s], acc, 0, 0, 0);
+        for (int t = 0; t < 2; ++t) {
+          acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[t][s], af[rt][s], acc[t], 0, 0, 0);
+        }
         const int row = rbase + rt * 16 + lr;
-        float o[4];
+        float o[8];
         if (MODE == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float v = live[rt] ? acc[r] + bias[r] : 0.f;
-            o[r] = bf2f(f2bf(v));                               // statistics on the value as stored
-            const float gl = gelu_t<T>(o[r]);
-            cs0[r] += gl * gl;
+          for (int e = 0; e < 8; ++e) {
+            const float v = live[rt] ? acc[e >> 2][e & 3] + bias[e] : 0.f;
+            o[e] = bf2f(f2bf(v));                               // statistics on the value as stored
+            const float gl = gelu_t<T>(o[e]);
+            cs0[e] += gl * gl;
           }
         } else {
-          float hv[4];
-          unpack4(hraw[rt], hv);
+          float hv[8];
+          unpack8(hraw[rt], hv);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            o[r] = bf2f(f2bf(acc[r]));
-            cs0[r] += o[r];
-            cs1[r] += o[r] * gelu_t<T>(hv[r]);
+          for (int e = 0; e < 8; ++e) {
+            o[e] = bf2f(f2bf(acc[e >> 2][e & 3]));
+            cs0[e] += o[e];
+            cs1[e] += o[e] * gelu_t<T>(hv[e]);
           }
         }
-        if (row < p.M) *reinterpret_cast<uint2*>(p.out + (size_t)row * HN + n4) = pack_bf16x4(o);
+        if (row < p.M) st8<T>(p.out + (size_t)row * HN + n8, o);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float a = sum16(cs0[r]);
-        if (lr == 0) atomicAdd(&red[nl + r], a);
+      for (int e = 0; e < 8; ++e) {
+        const float a = sum16(cs0[e]);
+        if (lr == 0) atomicAdd(&red[nl + e], a);
         if (MODE == 1) {
-          const float b = sum16(cs1[r]);
-          if (lr == 0) atomicAdd(&red[cols_per_split + nl + r], b);
+          const float b = sum16(cs1[e]);
+          if (lr == 0) atomicAdd(&red[cols_per_split + nl + e], b);
         }
       }
     }
