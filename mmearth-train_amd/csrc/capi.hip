@@ -973,8 +973,13 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       static size_t cur = 64 * 1024;
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 1, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
       LAUNCH((rsc_wide_kernel<KC, 1, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
-      launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
-      launch_reduce(0, a.ws + (size_t)rowblocks * HN, rowblocks, HN, a.s1, nullptr, 0, 0, 0, 0, st);
+      if (a.s1 == a.s0 + HN) {        // adjacent outputs (the engine's layout): one launch over [2*HN]
+        launch_reduce(0, a.ws, rowblocks, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
+      } else {                        // e = which*HN + j -> which == 0 ? s0[j] : s1[j]
+        const long long delta = a.s1 - a.s0;
+        if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+        launch_reduce(1, a.ws, rowblocks, 2 * HN, a.s0, nullptr, HN, (int)delta, 1, 0, st);
+      }
     }
   } else if (which == 4 || which == 5) {
     const int rpg = a.rpg > 0 ? a.rpg : a.M;

@@ -211,9 +211,13 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
     if (c + 1 < nch) wstore((c + 1) & 1);
     __syncthreads();
   }
+  // slab row of a workgroup: MODE 0 [HN]; MODE 1 [2][HN] (sum dz | sum dz*gelu(h)) so ONE second-stage launch folds both
   for (int i = tid; i < cols_per_split; i += 256) {
-    p.ws[(size_t)blockIdx.x * HN + n_begin + i] = red[i];
-    if (MODE == 1) p.ws[((size_t)gridDim.x + blockIdx.x) * HN + n_begin + i] = red[cols_per_split + i];
+    if (MODE == 0) p.ws[(size_t)blockIdx.x * HN + n_begin + i] = red[i];
+    else {
+      p.ws[(size_t)blockIdx.x * 2 * HN + n_begin + i] = red[i];
+      p.ws[(size_t)blockIdx.x * 2 * HN + HN + n_begin + i] = red[cols_per_split + i];
+    }
   }
 }
 
