@@ -270,6 +270,12 @@ int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* args, int npatc
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* args, int npatches,
                        mpmae_stream_t stream);
 int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* args, mpmae_stream_t stream);
+/* The same three kernels over SEVERAL modalities in one launch: dev_args is a device-resident array of
+ * `count` argument records of the kind (0: MpmaePixContArgs, 1: MpmaePixCatArgs, 2: MpmaeImgArgs), gridx
+ * the x extent the single-modality entry point would use (forward: samples; backward: patches for the
+ * pixel kinds, samples for the image kind). All records of a call must share p / L / K-limits. */
+int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count, int gridx,
+                     mpmae_stream_t stream);
 /* acc: per-sample partial {sum, count} pairs laid out [T][N][2] (written by the loss kernels:
  * args->acc points at modality t's [N][2] block). */
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale,

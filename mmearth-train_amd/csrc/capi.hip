@@ -667,6 +667,21 @@ int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* a, mpmae_stream_t s) {
   RET();
 }
 
+int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count, int gridx, mpmae_stream_t s) {
+  if (!dev_args || count < 1 || gridx < 1 || kind < 0 || kind > 2) return (int)hipErrorInvalidValue;
+  dim3 g(gridx, count);
+#define LM(KERN, ARGT, TH) do { \
+    if (dt == 0) { if (bwd) LAUNCH((KERN<float, true>), g, dim3(256), 0, S_(s), (const ARGT*)dev_args); \
+                   else LAUNCH((KERN<float, false>), g, dim3(TH), 0, S_(s), (const ARGT*)dev_args); } \
+    else { if (bwd) LAUNCH((KERN<bf16_t, true>), g, dim3(256), 0, S_(s), (const ARGT*)dev_args); \
+           else LAUNCH((KERN<bf16_t, false>), g, dim3(TH), 0, S_(s), (const ARGT*)dev_args); } } while (0)
+  if (kind == 0) LM(loss_pix_cont_multi_kernel, MpmaePixContArgs, 512);
+  else if (kind == 1) LM(loss_pix_cat_multi_kernel, MpmaePixCatArgs, 1024);
+  else LM(loss_img_multi_kernel, MpmaeImgArgs, 256);
+#undef LM
+  RET();
+}
+
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
                         float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
   if (T > 64) return (int)hipErrorInvalidValue;

@@ -210,14 +210,14 @@ __device__ __forceinline__ void loss_pix_cont_patch_wave(const PixContP& q, int 
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_kernel(const PixContP q) {
+__device__ __forceinline__ void loss_pix_cont_body(const PixContP& q, const int bx) {
   __shared__ float sh[4];
   __shared__ float part[16][2];
   float as = 0.f, ac = 0.f;
   if constexpr (BWD) {
-    loss_pix_cont_patch<T, true>(q, blockIdx.x, sh, as, ac);
+    loss_pix_cont_patch<T, true>(q, bx, sh, as, ac);
   } else {
-    const int n = blockIdx.x, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;      // NW <= 16
+    const int n = bx, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;      // NW <= 16
     for (int l = wave; l < q.L; l += NW) loss_pix_cont_patch_wave<T>(q, n * q.L + l, as, ac);
     if ((threadIdx.x & 63) == 0) { part[wave][0] = as; part[wave][1] = ac; }
     __syncthreads();
@@ -228,6 +228,18 @@ __global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_kernel(const Pi
       q.acc[2 * n + 1] = tc;
     }
   }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_kernel(const PixContP q) {
+  loss_pix_cont_body<T, BWD>(q, blockIdx.x);
+}
+
+// several modalities in one launch: blockIdx.y selects the argument record of a device-resident table
+template <typename T, bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_multi_kernel(const PixContP* __restrict__ tab) {
+  const PixContP q = tab[blockIdx.y];
+  loss_pix_cont_body<T, BWD>(q, blockIdx.x);
 }
 
 typedef MpmaePixCatArgs PixCatP;
@@ -268,13 +280,13 @@ __device__ __forceinline__ void loss_pix_cat_patch(const PixCatP& q, int b, floa
 }
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_kernel(const PixCatP q) {
+__device__ __forceinline__ void loss_pix_cat_body(const PixCatP& q, const int bx) {
   __shared__ float sh[4];
   float se = 0.f, cnt = 0.f;
   if constexpr (BWD) {
-    loss_pix_cat_patch<T, true>(q, blockIdx.x, se, cnt);
+    loss_pix_cat_patch<T, true>(q, bx, se, cnt);
   } else {
-    const int n = blockIdx.x;
+    const int n = bx;
     const int p = q.p, K = q.K, PP = p * p;
     for (int idx = threadIdx.x; idx < q.L * PP; idx += blockDim.x) {      // all pixels of all patches
       const int l = idx / PP, pix = idx - l * PP;
@@ -304,13 +316,25 @@ __global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_kernel(const Pi
   }
 }
 
+template <typename T, bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_kernel(const PixCatP q) {
+  loss_pix_cat_body<T, BWD>(q, blockIdx.x);
+}
+
+// several modalities in one launch: blockIdx.y selects the argument record of a device-resident table
+template <typename T, bool BWD>
+__global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_multi_kernel(const PixCatP* __restrict__ tab) {
+  const PixCatP q = tab[blockIdx.y];
+  loss_pix_cat_body<T, BWD>(q, blockIdx.x);
+}
+
 typedef MpmaeImgArgs ImgP;
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
+__device__ __forceinline__ void loss_img_body(const ImgP& q, const int bx) {
   __shared__ float sh[4];
   __shared__ int shi[4];
-  const int n = blockIdx.x, K = q.K;
+  const int n = bx, K = q.K;
   const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)n * q.ld + q.coff;
   T* dp = BWD ? reinterpret_cast<T*>(q.dpred) + (size_t)n * q.ld + q.coff : nullptr;
   if (q.kind == 1) {
@@ -363,6 +387,18 @@ __global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
     q.acc[2 * n] = lse - ldf<T>(pred + besti);
     q.acc[2 * n + 1] = 1.f;
   }
+}
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_img_kernel(const ImgP q) {
+  loss_img_body<T, BWD>(q, blockIdx.x);
+}
+
+// several modalities in one launch: blockIdx.y selects the argument record of a device-resident table
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void loss_img_multi_kernel(const ImgP* __restrict__ tab) {
+  const ImgP q = tab[blockIdx.y];
+  loss_img_body<T, BWD>(q, blockIdx.x);
 }
 
 // L_i = sum_i / count_i ; uncertainty: w_i = (exp(-s_i) L_i + s_i) [L_i != 0] (custom_loss.py:19-30)

@@ -865,6 +865,22 @@ class Engine:
                 self._keepalive.append(a)
                 self.loss_args[om.name] = a
                 self._op(f, f"loss:{om.name}", lib.mpmae_loss_img, dt, 0, C.byref(a))
+        # one launch per loss KIND instead of one per modality (12 small latency-bound kernels -> 3)
+        self.loss_multi = os.environ.get("MPMAE_LOSS_MULTI", "1") != "0"
+        if self.loss_multi:
+            while f and f[-1][0].startswith("loss:"):
+                f.pop()
+            self._loss_tabs = {}
+            for kind_id, kind, typ in ((0, "pix_cont", _lib.PixContArgs), (1, "pix_cat", _lib.PixCatArgs), (2, "img", None)):
+                mods = [om for om in cfg.out_mods if (om.kind == kind if typ else om.kind.startswith("img"))]
+                if not mods:
+                    continue
+                typ = typ or _lib.ImgArgs
+                arr = (typ * len(mods))(*[self.loss_args[om.name] for om in mods])
+                tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+                self._loss_tabs[kind] = (kind_id, tab, len(mods))
+                self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_multi, dt, 0, kind_id, _p(tab), len(mods), N,
+                         kind=f"loss_{kind}_fwd")
         self.loss_scale = 1.0
         lv = P.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
         glv = self.grads.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
@@ -914,7 +930,11 @@ class Engine:
         dims = cfg.dims
         y = self.dec_out
         # loss gradients w.r.t. predictions
-        for om in cfg.out_mods:
+        if self.loss_multi:
+            for kind, (kind_id, tab, cnt) in self._loss_tabs.items():
+                self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_multi, dt, 1, kind_id, _p(tab), cnt,
+                         N if kind == "img" else N * L, kind=f"loss_{kind}_bwd")
+        for om in ([] if self.loss_multi else cfg.out_mods):
             a = self.loss_args[om.name]
             if om.kind == "pix_cont":
                 self._op(b, f"dloss:{om.name}", lib.mpmae_loss_pix_cont, dt, 1, C.byref(a), N * L)
