@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from ._lib import EPI, PRO
 from .config import ModelCfg
-from .synth import state_dict_spec
+from .synth import flat_param_spec, state_dict_spec
 
 F32, BF16 = 0, 1
 
@@ -83,7 +83,7 @@ class Engine:
 
     # ------------------------------------------------------------------ params
     def _build_params(self):
-        spec = state_dict_spec(self.cfg)
+        spec = flat_param_spec(self.cfg)      # state-dict order with the prediction heads regrouped (see synth.py)
         total = sum(math.prod(s) for _, s, _ in spec)
         dev = self.device
         if self._ext_buffers is not None:
@@ -317,6 +317,17 @@ class Engine:
                 else:
                     add("head.imgT", wsrc, D, om.head_out, 1, D, dst=imgT, coloff=coff_i)
                 coff_i += om.head_out
+        # all heads of a family as ONE [W, D] matrix (the flat buffer keeps their weights contiguous in column order)
+        self.heads_merged = {}
+        for fam, mods in (("pix", cfg.pix_mods), ("img", cfg.img_mods)):
+            ws_ = [P[f"pred_dict.{m.name}.weight"] for m in mods]
+            bs_ = [P[f"pred_dict.{m.name}.bias"] for m in mods]
+            ok = bool(mods) and os.environ.get("MPMAE_HEADS_MERGED", "1") != "0"
+            for ts in (ws_, bs_):
+                ok = ok and all(a.data_ptr() + a.numel() * 4 == b_.data_ptr() for a, b_ in zip(ts, ts[1:]))
+            self.heads_merged[fam] = ok
+            if ok:
+                add(f"head.{fam}.W", ws_[0], sum(m.head_out for m in mods), D, D, 1)
         # lay the arena out
         total = 0
         for _, dst in chunks:
@@ -803,11 +814,16 @@ class Engine:
         # heads
         coff = 0
         self.head_cols = {}
+        if self.heads_merged.get("pix"):
+            wh = self.w["head.pix.W"]
+            self._gemm(f, "head:pix", "NONE", "STORE", A=y, B=wh["t"], bias=P[f"pred_dict.{cfg.pix_mods[0].name}.bias"],
+                       C=self.pred_pix, M=N * L, N=self.Wpix, K=D, lda=D, ldb=wh["ld"], ldc=self.pred_pix.shape[1])
         for om in cfg.pix_mods:
-            wh = self.w[f"head.{om.name}.W"]
-            cview = self.pred_pix.view(-1)[coff:]
-            self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=y, B=wh["t"], bias=P[f"pred_dict.{om.name}.bias"],
-                       C=cview, M=N * L, N=om.head_out, K=D, lda=D, ldb=wh["ld"], ldc=self.pred_pix.shape[1])
+            if not self.heads_merged.get("pix"):
+                wh = self.w[f"head.{om.name}.W"]
+                cview = self.pred_pix.view(-1)[coff:]
+                self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=y, B=wh["t"], bias=P[f"pred_dict.{om.name}.bias"],
+                           C=cview, M=N * L, N=om.head_out, K=D, lda=D, ldb=wh["ld"], ldc=self.pred_pix.shape[1])
             self.head_cols[om.name] = coff
             coff += om.head_out
         if cfg.img_mods:
@@ -815,12 +831,18 @@ class Engine:
                      _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, 1e-6, N * L, D, None)
             self._op(f, "head:pool", lib.mpmae_pool_rows, dt, _p(self.yln), _p(self.pooled), N, L, D)
             coff = 0
-            for om in cfg.img_mods:
-                wh = self.w[f"head.{om.name}.W"]
-                cview = self.pred_img.view(-1)[coff:]
-                self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=self.pooled, B=wh["t"],
-                           bias=P[f"pred_dict.{om.name}.bias"], C=cview, M=N, N=om.head_out, K=D, lda=D,
+            if self.heads_merged.get("img"):
+                wh = self.w["head.img.W"]
+                self._gemm(f, "head:img", "NONE", "STORE", A=self.pooled, B=wh["t"],
+                           bias=P[f"pred_dict.{cfg.img_mods[0].name}.bias"], C=self.pred_img, M=N, N=self.Wimg, K=D, lda=D,
                            ldb=wh["ld"], ldc=self.ldimg)
+            for om in cfg.img_mods:
+                if not self.heads_merged.get("img"):
+                    wh = self.w[f"head.{om.name}.W"]
+                    cview = self.pred_img.view(-1)[coff:]
+                    self._gemm(f, f"head:{om.name}", "NONE", "STORE", A=self.pooled, B=wh["t"],
+                               bias=P[f"pred_dict.{om.name}.bias"], C=cview, M=N, N=om.head_out, K=D, lda=D,
+                               ldb=wh["ld"], ldc=self.ldimg)
                 self.head_cols[om.name] = coff
                 coff += om.head_out
         # losses
@@ -943,7 +965,18 @@ class Engine:
             else:
                 self._op(b, f"dloss:{om.name}", lib.mpmae_loss_img, dt, 1, C.byref(a))
         ldp = self.pred_pix.shape[1]
-        for om in cfg.pix_mods:
+
+        def contiguous(mods, suffix):
+            ts = [Gd[f"pred_dict.{m.name}.{suffix}"] for m in mods]
+            return all(a.data_ptr() + a.numel() * 4 == b_.data_ptr() for a, b_ in zip(ts, ts[1:]))
+
+        if cfg.pix_mods and contiguous(cfg.pix_mods, "weight") and contiguous(cfg.pix_mods, "bias"):
+            m0 = cfg.pix_mods[0]        # all pixel heads at once: dW [Wpix, D] and db [Wpix] are contiguous (see _build_params)
+            self._side_wgrad(b, "head:pix.wgrad", "NONE", "NONE", [], P=self.dpred_pix, Q=y, M=N * L, Nn=self.Wpix, Kk=D,
+                             ldp=ldp, ldq=D, dW=Gd[f"pred_dict.{m0.name}.weight"], sn=D, sk=1,
+                             db=Gd[f"pred_dict.{m0.name}.bias"])
+        else:
+          for om in cfg.pix_mods:
             pv = self.dpred_pix.view(-1)[self.head_cols[om.name]:]
             self._side_wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", [], P=pv, Q=y, M=N * L, Nn=om.head_out, Kk=D, ldp=ldp,
                         ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1, db=Gd[f"pred_dict.{om.name}.bias"])
@@ -953,7 +986,13 @@ class Engine:
             self._gemm(b, "head:pix.dgrad", "NONE", "STORE", A=self.dpred_pix, B=wt["t"], C=self.dy, M=N * L, N=D,
                        K=self.Wpix, lda=ldp, ldb=wt["ld"], ldc=D)
         if cfg.img_mods:
-            for om in cfg.img_mods:
+            if contiguous(cfg.img_mods, "weight") and contiguous(cfg.img_mods, "bias"):
+                m0 = cfg.img_mods[0]
+                self._side_wgrad(b, "head:img.wgrad", "NONE", "NONE", [], P=self.dpred_img, Q=self.pooled, M=N, Nn=self.Wimg, Kk=D,
+                                 ldp=self.ldimg, ldq=D, dW=Gd[f"pred_dict.{m0.name}.weight"], sn=D, sk=1,
+                                 db=Gd[f"pred_dict.{m0.name}.bias"])
+            else:
+              for om in cfg.img_mods:
                 pv = self.dpred_img.view(-1)[self.head_cols[om.name]:]
                 self._side_wgrad(b, f"head:{om.name}.wgrad", "NONE", "NONE", [], P=pv, Q=self.pooled, M=N, Nn=om.head_out, Kk=D,
                             ldp=self.ldimg, ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1,

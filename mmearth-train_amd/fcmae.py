@@ -26,7 +26,7 @@ from torch import Tensor
 from .MODALITIES import PIXEL_WISE_MODALITIES
 from .config import SIZES, cfg_from_args
 from .engine import Engine
-from .synth import state_dict_spec
+from .synth import flat_param_spec, state_dict_spec
 
 
 def _trunc_normal_(t, std, gen=None):
@@ -119,15 +119,17 @@ class FCMAE(nn.Module):
         self._pflat = torch.zeros(total, dtype=torch.float32, device=self._device)
         self._gflat = torch.zeros(total, dtype=torch.float32, device=self._device)
         self._plist, self._poffs, views = [], [], OrderedDict()
-        off = 0
         first = self.cfg.out_mods[0].name
-        for key, shape, _ in spec:
-            n = math.prod(shape)
+        offs, off = {}, 0
+        for key, shape, _ in flat_param_spec(self.cfg):      # the engine's layout of the flat buffers
+            offs[key] = off
+            off += math.prod(shape)
+        for key, shape, _ in spec:                            # registration (state-dict) order = the reference's
+            n, off = math.prod(shape), offs[key]
             p = nn.Parameter(self._pflat[off:off + n].view(shape))
             views[key] = p
             self._plist.append(p)
             self._poffs.append((off, n))
-            off += n
         init_reference_(OrderedDict((k, p.data) for k, p in views.items()))
         # module tree with the reference's names
         self.loss_fn = loss_fn

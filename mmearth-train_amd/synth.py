@@ -174,3 +174,24 @@ def make_inputs(cfg: ModelCfg, N: int, seed: int = 1000, clean: bool = False):
     order = ["sentinel2"] + [m.name for m in cfg.out_mods if m.name != "sentinel2"]
     d = OrderedDict((k, d[k]) for k in order)
     return d, noise
+
+
+def flat_param_spec(cfg):
+    """Order of the tensors inside the flat fp32 parameter / gradient buffers: state-dict order, except that
+    the prediction heads are regrouped as [pixel weights][pixel biases][image weights][image biases] in
+    prediction-column order, so that the weight gradient of ALL pixel heads (and of all image heads) is one
+    contiguous [W, D] matrix = one weight-gradient launch instead of one per modality. Everything else
+    addresses parameters by key (state dicts keep the reference's order)."""
+    spec = state_dict_spec(cfg)
+    pred = [e for e in spec if e[0].startswith("pred_dict.")]
+    if not pred:
+        return spec
+    by_key = {e[0]: e for e in pred}
+    grouped = []
+    for mods in (cfg.pix_mods, cfg.img_mods):
+        for suffix in ("weight", "bias"):
+            grouped += [by_key.pop(f"pred_dict.{m.name}.{suffix}") for m in mods if f"pred_dict.{m.name}.{suffix}" in by_key]
+    grouped += list(by_key.values())
+    first = next(i for i, e in enumerate(spec) if e[0].startswith("pred_dict."))
+    rest = [e for e in spec if not e[0].startswith("pred_dict.")]
+    return rest[:first] + grouped + rest[first:]
