@@ -998,8 +998,10 @@ class Engine:
                             ldp=self.ldimg, ldq=D, dW=Gd[f"pred_dict.{om.name}.weight"], sn=D, sk=1,
                             db=Gd[f"pred_dict.{om.name}.bias"])
             wt = self.w["head.imgT"]
+            # K = the padded width: dpred_img's and the staged weights' padding columns are zero, and a multiple of 8
+            # keeps this tiny GEMM on the fast kernel
             self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
-                       K=self.Wimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
+                       K=self.ldimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
             self._op(b, "head:ln.bwd", self._ln_bwd_fn, dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
                      _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, _p(self.dy), 1 if have_pix else 0,
                      _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
