@@ -722,6 +722,15 @@ template <int BN>
 static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
   dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
+  static int bk32 = -1;
+  if (bk32 < 0) { const char* e = getenv("MPMAE_NT_BK32"); bk32 = e ? atoi(e) : 1; }
+  if (bk32 && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K <= 512) {
+    // short K, wide N (decoder pw1 / pw2.dgrad, pixel heads): half-depth K slabs, 41 KB of LDS instead of 74 KB ->
+    // 3-4 workgroups per CU (measured 84 -> 67, 72 -> 58, 85 -> 77 us; for K = 2048 the 64-deep slabs stay faster)
+    const size_t lds32 = (size_t)(2 * FBM * 40 + 2 * BN * 40) * sizeof(bf16_t);
+    LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 32>), g, dim3(256), lds32, st, a);
+    return (int)hipGetLastError();
+  }
 #define FAST_CASE(E)                                                                                   \
   if (epi == E || (E == EPI_STORE && epi == EPI_RESID)) {                                              \
     static bool once = false;                                                                          \

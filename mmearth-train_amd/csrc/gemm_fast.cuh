@@ -25,14 +25,15 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 // EPI: EPI_STORE (bias, optional residual R, row mask) | EPI_GELU_SUMSQ (store h, per-block column
 // partials of gelu(h)^2 -> ws[blockIdx.x][N]) | EPI_DZ_STATS (store dz, partials of dz and
 // dz*gelu(R) -> ws[blockIdx.x][N], ws[gridDim.x + blockIdx.x][N]); statistics: single group only.
-template <int BN, int EPI>
+template <int BN, int EPI, int BK = FBK>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
+  constexpr int LDK = BK + 8, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
   using T = bf16_t;
   constexpr int NJ = BN / 32;                 // 16-wide N tiles per wave (wave tile 64 x BN/2)
-  constexpr int BCH = BN * 8 / 256;           // 16-byte chunks of the B tile per thread
+  constexpr int BCH = BN * CPR / 256;           // 16-byte chunks of the B tile per thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* As = reinterpret_cast<bf16_t*>(smem_raw);                 // [2][128][72]
-  bf16_t* Bs = As + 2 * FBM * FLD;                                  // [2][BN][72]
+  bf16_t* Bs = As + 2 * FBM * LDK;                                  // [2][BN][72]
   float* stage = reinterpret_cast<float*>(smem_raw);                // [128][68] fp32 (epilogue)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -48,49 +49,49 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[BCH];
+  uint4 ra[ACH], rb[BCH];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       const int c = tid + 256 * i;
-      ra[i] = ldg16_guard(A, m0 + (c >> 3), p.M, p.lda, k0 + (c & 7) * 8, p.K);
+      ra[i] = ldg16_guard(A, m0 + c / CPR, p.M, p.lda, k0 + (c % CPR) * 8, p.K);
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int c = tid + 256 * i;
-      rb[i] = ldg16_guard(B, n0 + (c >> 3), p.N, p.ldb, k0 + (c & 7) * 8, p.K);
+      rb[i] = ldg16_guard(B, n0 + c / CPR, p.N, p.ldb, k0 + (c % CPR) * 8, p.K);
     }
   };
   auto lstore = [&](int buf) {
-    bf16_t* a = As + buf * FBM * FLD;
-    bf16_t* b = Bs + buf * BN * FLD;
+    bf16_t* a = As + buf * FBM * LDK;
+    bf16_t* b = Bs + buf * BN * LDK;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ACH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<uint4*>(a + (c >> 3) * FLD + (c & 7) * 8) = ra[i];
+      *reinterpret_cast<uint4*>(a + (c / CPR) * LDK + (c % CPR) * 8) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < BCH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<uint4*>(b + (c >> 3) * FLD + (c & 7) * 8) = rb[i];
+      *reinterpret_cast<uint4*>(b + (c / CPR) * LDK + (c % CPR) * 8) = rb[i];
     }
   };
 
-  const int nk = (p.K + FBK - 1) / FBK;
+  const int nk = (p.K + BK - 1) / BK;
   gload(0);
   lstore(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) gload((kt + 1) * FBK);
-    const bf16_t* a = As + (kt & 1) * FBM * FLD + (wm * 64 + lr) * FLD + lg * 8;
-    const bf16_t* b = Bs + (kt & 1) * BN * FLD + (wn * (BN / 2) + lr) * FLD + lg * 8;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const bf16_t* a = As + (kt & 1) * FBM * LDK + (wm * 64 + lr) * LDK + lg * 8;
+    const bf16_t* b = Bs + (kt & 1) * BN * LDK + (wn * (BN / 2) + lr) * LDK + lg * 8;
 #pragma unroll
-    for (int ks = 0; ks < FBK; ks += 32) {
+    for (int ks = 0; ks < BK; ks += 32) {
       bf16x8_t af[4], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * FLD + ks));
+      for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * LDK + ks));
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * FLD + ks));
+      for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * LDK + ks));
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
