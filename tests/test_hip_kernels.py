@@ -1,0 +1,228 @@
+"""GPU unit tests of individual C-ABI entry points against plain torch fp32 references computed on
+the same (bf16-rounded) inputs. The step-level parity tests (test_hip_parity.py) already cover these
+kernels through the engine; here each fused kernel is pinned on its own, including ragged row counts,
+inactive rows and padded channel counts."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+
+
+def _lib():
+    from mmearth_train_amd import _lib
+    return _lib, _lib.load()
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def _dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("M,Cc", [(1000, 160), (76, 160), (304, 320), (1000, 40), (77, 80), (4864, 80)])
+def test_fused_block_kernels_match_torch(M, Cc):
+    """mpmae_rs which = 0, 4, 1, 5 (LN+pw1+GELU^2 sums; GRN apply+pw2+residual; pw2.dgrad+sums; dh+pw1.dgrad+LN bwd).
+    Tolerance = a couple of bf16 ulps on stored tensors, 1e-3 on fp32 sums (the bf16 path's GELU is a
+    2.6e-5-accurate fit, the reference below is the exact erf form)."""
+    L, lib = _lib()
+    dev, H = "cuda", 4 * Cc
+    torch.manual_seed(M + Cc)
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    live = act.bool()[:, None]
+    d = (torch.randn(M, Cc, device=dev) * 2 + 0.3).to(bf) * live
+    lnw = torch.rand(Cc, device=dev) + 0.5
+    lnb = torch.randn(Cc, device=dev) * 0.1
+    W1 = (torch.randn(H, Cc, device=dev) / math.sqrt(Cc)).to(bf)
+    b1 = torch.randn(H, device=dev) * 0.1
+    xhat = torch.empty(M, Cc, device=dev, dtype=bf)
+    xn = torch.empty_like(xhat)
+    rstd = torch.empty(M, device=dev)
+    h = torch.empty(M, H, device=dev, dtype=bf)
+    s0 = torch.zeros(H, device=dev)
+    assert lib.mpmae_rs(0, C.byref(args(A=d, W=W1, ldw=Cc, bias=b1, v0=lnw, v1=lnb, out=h, xhat=xhat, xn=xn, rstd=rstd,
+                                        act=act, s0=s0)), _st()) == 0
+    df = d.float()
+    mu = df.mean(1, keepdim=True)
+    r_rstd = torch.rsqrt(((df - mu) ** 2).mean(1, keepdim=True) + 1e-6)
+    r_xhat = (((df - mu) * r_rstd) * live).to(bf)
+    r_xn = ((r_xhat.float() * lnw + lnb) * live).to(bf)
+    r_h = ((r_xn.float() @ W1.float().t() + b1) * live).to(bf)
+    assert _rel(xhat, r_xhat) < 8e-3 and _rel(xn, r_xn) < 8e-3 and _rel(h, r_h) < 8e-3
+    assert _rel(rstd, r_rstd[:, 0] * live[:, 0]) < 1e-5
+    assert _rel(s0, (_gelu(h.float()) ** 2).sum(0)) < 1e-3
+
+    scale = torch.rand(H, device=dev) + 0.5
+    gbeta = torch.randn(H, device=dev) * 0.1
+    W2 = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    b2 = torch.randn(Cc, device=dev) * 0.1
+    x = torch.randn(M, Cc, device=dev).to(bf) * live
+    z = torch.empty(M, H, device=dev, dtype=bf)
+    o = torch.empty(M, Cc, device=dev, dtype=bf)
+    assert lib.mpmae_rs(4, C.byref(args(A=h, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=o, xn=z, R=x, act=act, rpg=0)),
+                        _st()) == 0
+    r_z = ((_gelu(h.float()) * scale + gbeta) * live).to(bf)
+    assert _rel(z, r_z) < 8e-3
+    assert _rel(o, ((x.float() + z.float() @ W2.float().t() + b2) * live).to(bf)) < 1e-2
+
+    dout = (torch.randn(M, Cc, device=dev) * 0.1).to(bf) * live
+    W2T = W2.t().contiguous()
+    dz = torch.empty(M, H, device=dev, dtype=bf)
+    t0 = torch.zeros(H, device=dev)
+    t1 = torch.zeros(H, device=dev)
+    assert lib.mpmae_rs(1, C.byref(args(A=dout, W=W2T, ldw=Cc, out=dz, R=h, s0=t0, s1=t1)), _st()) == 0
+    assert _rel(dz, (dout.float() @ W2T.float().t()).to(bf)) < 8e-3
+    assert _rel(t0, dz.float().sum(0)) < 1e-3 and _rel(t1, (dz.float() * _gelu(h.float())).sum(0)) < 1e-3
+
+    coef = torch.randn(H, device=dev) * 0.05
+    W1T = W1.t().contiguous()
+    dzc = dz.clone()
+    dd = torch.empty(M, Cc, device=dev, dtype=bf)
+    gbuf = torch.zeros(2 * Cc, device=dev)
+    assert lib.mpmae_rs(5, C.byref(args(A=dzc, A2=h, W=W1T, ldw=H, v0=scale, v1=coef, out=dd, xhat=xhat, rstd=rstd, lng=lnw,
+                                        act=act, s0=gbuf, s1=gbuf[Cc:], rpg=0)), _st()) == 0
+    hf = h.float()
+    r_dh = ((dz.float() * scale + coef * _gelu(hf)) * _dgelu(hf)).to(bf)
+    assert _rel(dzc, r_dh) < 1e-2
+    dxn = (dzc.float() @ W1T.float().t()).to(bf).float() * live          # from the kernel's own dh: isolates the LN part
+    xh = xhat.float()
+    gq = dxn * lnw
+    r_dd = ((rstd[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))) * live).to(bf)
+    assert _rel(dd, r_dd) < 2e-2
+    assert _rel(gbuf[:Cc], (dxn * xh).sum(0)) < 5e-3 and _rel(gbuf[Cc:], dxn.sum(0)) < 5e-3
+
+
+@pytest.mark.parametrize("dt,S", [(0, 8), (1, 8), (1, 16)])
+def test_im2col_of_masked_image_matches_unfold(dt, S):
+    L, lib = _lib()
+    dev, N, Cin, grid = "cuda", 3, 12, 7
+    Himg = grid * S
+    keep = 19
+    torch.manual_seed(S + dt)
+    img = torch.randn(N, Cin, Himg, Himg, device=dev)
+    noise = torch.rand(N, grid * grid, device=dev)
+    mask = torch.empty(N, grid * grid, device=dev)
+    vis = torch.empty(N, keep, dtype=torch.int32, device=dev)
+    inv = torch.empty(N, grid * grid, dtype=torch.int32, device=dev)
+    assert lib.mpmae_mask_gen(noise.data_ptr(), N, grid * grid, keep, mask.data_ptr(), vis.data_ptr(), inv.data_ptr(), _st()) == 0
+    ldo = 112
+    out = torch.full((N * keep * S * S, ldo), 7.0, device=dev, dtype=torch.float32 if dt == 0 else bf)
+    assert lib.mpmae_im2col3(dt, img.data_ptr(), vis.data_ptr(), inv.data_ptr(), out.data_ptr(), ldo, N, keep, grid, S, Cin,
+                             Himg, _st()) == 0
+    # reference: zero the masked patches, unfold 3x3 with zero padding, pick the visible patches' pixels
+    pm = (inv.view(N, 1, grid, grid) >= 0).float().repeat_interleave(S, 2).repeat_interleave(S, 3)
+    cols = torch.nn.functional.unfold(img * pm, 3, padding=1).view(N, Cin, 3, 3, Himg, Himg)      # [n, cin, kh, kw, y, x]
+    ref = torch.zeros(N * keep * S * S, ldo, device=dev)
+    v = vis.long()
+    for n in range(N):
+        for slot in range(keep):
+            py, px = int(v[n, slot]) // grid, int(v[n, slot]) % grid
+            blk = cols[n, :, :, :, py * S:(py + 1) * S, px * S:(px + 1) * S]                         # [cin, kh, kw, S, S]
+            r0 = (n * keep + slot) * S * S
+            ref[r0:r0 + S * S, :9 * Cin] = blk.permute(3, 4, 2, 1, 0).reshape(S * S, 9 * Cin)       # k = (kw*3+kh)*Cin + cin
+    assert _rel(out.float(), ref.to(out.dtype).float()) < 1e-6
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_stem_tail_forward_and_backward_match_autograd(dt):
+    L, lib = _lib()
+    dev, M, Cc = "cuda", 1000, 40
+    T = torch.float32 if dt == 0 else bf
+    torch.manual_seed(11 + dt)
+    act = (torch.rand(M, device=dev) > 0.15).to(torch.uint8)
+    live = act.bool()[:, None]
+    x = (torch.randn(M, Cc, device=dev) * 1.5).to(T) * live
+    p = {k: (torch.rand(Cc, device=dev) + 0.5) if k in ("g1", "w", "g2") else torch.randn(Cc, device=dev) * 0.1
+         for k in ("g1", "b1", "w", "wb", "g2", "b2")}
+    xhat1, xhat2, out = (torch.empty(M, Cc, device=dev, dtype=T) for _ in range(3))
+    rstd1, rstd2 = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ws = torch.empty(4 << 20, device=dev)
+    a = L.StemTailArgs()
+    a.x, a.out, a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (x, out, xhat1, rstd1, xhat2, rstd2))
+    for k in p:
+        setattr(a, k, p[k].data_ptr())
+    a.act_in = a.act_out = act.data_ptr()
+    a.M, a.C, a.ws, a.ws_floats = M, Cc, ws.data_ptr(), ws.numel()
+    assert lib.mpmae_stem_tail(dt, 0, C.byref(a), _st()) == 0
+
+    q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    xr = x.float().clone().requires_grad_(True)
+
+    def ln(v, g, b):
+        mu = v.mean(1, keepdim=True)
+        return (v - mu) * torch.rsqrt(((v - mu) ** 2).mean(1, keepdim=True) + 1e-6) * g + b
+    a1 = _gelu(ln(xr, q["g1"], q["b1"])) * live
+    s0 = (a1 * q["w"] + q["wb"]) * live
+    y = ln(s0, q["g2"], q["b2"]) * live
+    tol = 2e-5 if dt == 0 else 2e-2
+    assert _rel(out.float(), y) < tol
+    dy = (torch.randn(M, Cc, device=dev) * 0.1).to(T) * live
+    y.backward(dy.float())
+    dx = torch.empty(M, Cc, device=dev, dtype=T)
+    g = {k: torch.zeros(Cc, device=dev) for k in ("dg1", "db1", "dw", "dwb", "dg2", "db2")}
+    a.x, a.out = dy.data_ptr(), dx.data_ptr()
+    for k in g:
+        setattr(a, k, g[k].data_ptr())
+    assert lib.mpmae_stem_tail(dt, 1, C.byref(a), _st()) == 0
+    assert _rel(dx.float(), xr.grad * live) < (1e-4 if dt == 0 else 3e-2)
+    for k, r in (("dg1", "g1"), ("db1", "b1"), ("dw", "w"), ("dwb", "wb"), ("dg2", "g2"), ("db2", "b2")):
+        assert _rel(g[k], q[r].grad) < (1e-4 if dt == 0 else 3e-2), k
+
+
+def test_grouped_layernorm_feeds_the_downsample_gemm():
+    """mpmae_ln_fwd_down writes row (patch, cy, cx) to [parent][(cx&1)*2 + (cy&1)][C]; mpmae_ln_bwd_down reads dy from it."""
+    L, lib = _lib()
+    dev, NK, S, Cc = "cuda", 6, 4, 40
+    M = NK * S * S
+    torch.manual_seed(5)
+    act = (torch.rand(M, device=dev) > 0.2).to(torch.uint8)
+    live = act.bool()[:, None]
+    x = torch.randn(M, Cc, device=dev) * live
+    g = torch.rand(Cc, device=dev) + 0.5
+    b = torch.randn(Cc, device=dev) * 0.1
+    xhat = torch.empty_like(x)
+    rstd = torch.empty(M, device=dev)
+    yg = torch.full((M // 4, 4 * Cc), 9.0, device=dev)
+    assert lib.mpmae_ln_fwd_down(0, x.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), yg.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                 1e-6, M, Cc, S, act.data_ptr(), _st()) == 0
+    mu = x.mean(1, keepdim=True)
+    y = ((x - mu) * torch.rsqrt(((x - mu) ** 2).mean(1, keepdim=True) + 1e-6) * g + b) * live
+    yv = y.view(NK, S // 2, 2, S // 2, 2, Cc)                     # [nk, iy, a, ix, b, c]
+    ref = yv.permute(0, 1, 3, 4, 2, 5).reshape(M // 4, 4 * Cc)    # group index = b*2 + a
+    assert _rel(yg, ref) < 1e-5
+    dyg = torch.randn(M // 4, 4 * Cc, device=dev)
+    dx = torch.empty_like(x)
+    dg, db = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    ws = torch.empty(1 << 20, device=dev)
+    assert lib.mpmae_ln_bwd_down(0, dyg.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), g.data_ptr(), dx.data_ptr(),
+                                 dg.data_ptr(), db.data_ptr(), M, Cc, S, act.data_ptr(), ws.data_ptr(), ws.numel(), _st()) == 0
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    mu = xr.mean(1, keepdim=True)
+    yr = ((xr - mu) * torch.rsqrt(((xr - mu) ** 2).mean(1, keepdim=True) + 1e-6) * gr + br) * live
+    dy = dyg.view(NK, S // 2, S // 2, 2, 2, Cc).permute(0, 1, 4, 2, 3, 5).reshape(M, Cc)       # back to row order
+    yr.backward(dy)
+    assert _rel(dx, xr.grad * live) < 1e-4 and _rel(dg, gr.grad) < 1e-4 and _rel(db, br.grad) < 1e-4
