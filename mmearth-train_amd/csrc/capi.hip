@@ -249,7 +249,9 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
     const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
     const int per = cdiv(nvec, G);
     const int rpw = 64 / G;
-    int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, 512);          // <= 2048 waves -> slab rows
+    static int lncap = -1;
+    if (lncap < 0) { const char* e = getenv("MPMAE_LNB_BLOCKS"); lncap = e ? atoi(e) : 1024; }   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
+    int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, lncap);        // one slab row per wave; enough waves to hide the row latency
     while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
 #define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask, down_S)
 #define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
@@ -1086,7 +1088,9 @@ int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t 
   p.x = a->x; p.xhat1 = a->xhat1; p.rstd1 = a->rstd1; p.xhat2 = a->xhat2; p.rstd2 = a->rstd2; p.out = a->out;
   p.g1 = a->g1; p.b1 = a->b1; p.w = a->w; p.wb = a->wb; p.g2 = a->g2; p.b2 = a->b2;
   p.act_in = a->act_in; p.act_out = a->act_out; p.ws = a->ws; p.M = a->M; p.C = a->C;
-  int blocks = grid1d((long long)cdiv(a->M, rpw) * 64, 256, bwd ? 512 : 4096);
+  static int stcap = -1;
+  if (stcap < 0) { const char* e = getenv("MPMAE_STB_BLOCKS"); stcap = e ? atoi(e) : 512; }
+  int blocks = grid1d((long long)cdiv(a->M, rpw) * 64, 256, bwd ? stcap : 4096);
   if (bwd) {
     if (!a->ws || !a->dg1 || !a->db1 || !a->dw || !a->dwb || !a->dg2 || !a->db2) return (int)hipErrorInvalidValue;
     while ((size_t)blocks * 4 * 6 * a->C > a->ws_floats && blocks > 1) blocks /= 2;

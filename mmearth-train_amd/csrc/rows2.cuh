@@ -6,10 +6,17 @@
 #pragma once
 #include "rows.cuh"
 
+// sum over the G lanes of a row group (G = 8..64, groups are aligned): the first 8 / 16 lanes fold with DPP
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: one v_add_f32_dpp each), only the steps that cross a
+// 16-lane row go through ds_bpermute
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
+  v += dpp_mov<0xB1>(v);                       // xor 1
+  v += dpp_mov<0x4E>(v);                       // xor 2
+  v += dpp_mov<0x141>(v);                      // row_half_mirror: the other quad of the 8-lane half
+  if (G >= 16) v += dpp_mov<0x140>(v);         // row_mirror: the other half of the 16-lane row
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
 
