@@ -804,7 +804,11 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   static int target = -1, minrows = -1;
   if (target < 0) { const char* e = getenv("MPMAE_TN_BLOCKS"); target = e ? atoi(e) : 512; }
   if (minrows < 0) { const char* e = getenv("MPMAE_TN_MINROWS"); minrows = e ? atoi(e) : 256; }
-  int splits = cdiv(target, tiles);
+  static int bigt = -1;
+  if (bigt < 0) { const char* e = getenv("MPMAE_TN_BLOCKS_BIG"); bigt = e ? atoi(e) : 256; }   // measured in-step: 512 -> 5.59, 256 -> 5.54, 128 -> 5.86 ms
+  // large dW (stage 2+, decoder, heads): every split writes and the second stage re-reads a full fp32 copy of dW
+  const int tgt = (bigt > 0 && (size_t)a.Nn * a.Kk >= 65536) ? bigt : target;
+  int splits = cdiv(tgt, tiles);
   const int maxs = cdiv(a.M, minrows);
   if (splits > maxs) splits = maxs;
   if (splits > (int)(a.ws_floats / per)) splits = (int)(a.ws_floats / per);
