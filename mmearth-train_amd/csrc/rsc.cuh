@@ -181,9 +181,8 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
         if (MODE == 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float v = live[rt] ? acc[e >> 2][e & 3] + bias[e] : 0.f;
-            o[e] = bf2f(f2bf(v));                               // statistics on the value as stored
-            const float gl = gelu_t<T>(o[e]);
+            o[e] = live[rt] ? acc[e >> 2][e & 3] + bias[e] : 0.f;       // rounded to bf16 by the store; the GRN sums use the
+            const float gl = gelu_t<T>(o[e]);                            // fp32 value (what the fp32 reference sums)
             cs0[e] += gl * gl;
           }
         } else {
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
           unpack8(hraw[rt], hv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            o[e] = bf2f(f2bf(acc[e >> 2][e & 3]));
+            o[e] = acc[e >> 2][e & 3];
             cs0[e] += o[e];
             cs1[e] += o[e] * gelu_t<T>(hv[e]);
           }
