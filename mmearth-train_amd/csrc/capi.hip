@@ -381,14 +381,16 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
   if (lds > 160 * 1024 - 512) return false;
   static size_t cur = 64 * 1024;
   if (lds > cur) {
-    if (hipFuncSetAttribute((const void*)dwconv7_wgrad_v5_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)dwconv7_wgrad_v5_kernel<T, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)dwconv7_wgrad_v5_kernel<T, S, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
     cur = lds;
   }
   dim3 g(nblocks, a.C / CW);
-  LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(nthreads), lds, st, a);
+  if (a.g.grid == 7) LAUNCH((dwconv7_wgrad_v5_kernel<T, S, 7>), g, dim3(nthreads), lds, st, a);
+  else LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(nthreads), lds, st, a);
   return true;
 }
 
@@ -406,7 +408,12 @@ static bool launch_dw_v6(const MpmaeDwArgs& a, hipStream_t st) {
   const size_t lds = dw5_map_bytes<bf16_t, S>(a.g.grid) + 49 * CW * sizeof(float);
   if (lds > 64 * 1024) return false;
   dim3 g(a.g.N, a.C / CW);
-  LAUNCH((dwconv7_v6_kernel<S>), g, dim3(dw6_threads(S)), lds, st, a);
+  static int gc = -1;
+  if (gc < 0) { const char* e = getenv("MPMAE_DW6_GC"); gc = e ? atoi(e) : 1; }
+  // compile-time map pitch: measured faster only at S = 2 for the forward / data-gradient kernel (17.7 vs 18.8 us; slower at
+  // S = 4, 8), decisive for the weight-gradient kernel (220 -> 128 VGPRs)
+  if (gc && S == 2 && a.g.grid == 7) LAUNCH((dwconv7_v6_kernel<S, 7>), g, dim3(dw6_threads(S)), lds, st, a);
+  else LAUNCH((dwconv7_v6_kernel<S>), g, dim3(dw6_threads(S)), lds, st, a);
   return true;
 }
 

@@ -123,12 +123,15 @@ __global__ __launch_bounds__(512) void dwconv7_v5_kernel(const DwP p) {
 
 // weight / bias gradient: persistent workgroups over samples; grid = (nblocks, C/CW), block 256;
 // slab ws[blockIdx.x][50][C]
-template <typename T, int S>
+// GC = compile-time patch-grid side (0 = runtime): with a constant map pitch every LDS read of the tap loop is
+// base + immediate; with a runtime pitch hipcc hoisted the 98 loop-invariant offsets into VGPRs (220 VGPRs, one
+// workgroup per CU)
+template <typename T, int S, int GC = 0>
 __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
   using D = Dw5<T, S>;
   constexpr int CW = D::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
-  const int MS = q.g.grid * S + 6;
+  const int MS = (GC ? GC : q.g.grid) * S + 6;
   T* map = reinterpret_cast<T*>(dw5_smem);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
   const int C = q.C, c0 = blockIdx.y * CW;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
       for (int kx = 0; kx < 7; ++kx) {
         if (kx > 0)
           asm volatile("" : "+v"(toff) : "v"(adw[kx - 1]), "v"(adw[7 + kx - 1]), "v"(adw[14 + kx - 1]),
-                       "v"(adw[21 + kx - 1]), "v"(adw[28 + kx - 1]), "v"(adw[35 + kx - 1]), "v"(adw[42 + kx - 1]));
+                       "v"(adw[21 + kx - 1]), "v"(adw[28 + kx - 1]), "v"(adw[35 + kx - 1]), "v"(adw[42 + kx - 1]) : "memory");
 #pragma unroll
         for (int y = 0; y < S + 6; ++y) {
           const float v = ldf<T>(tile + toff + (y * MS + ox + kx) * CW + cw);

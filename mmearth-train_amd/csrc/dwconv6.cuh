@@ -20,12 +20,12 @@ __device__ __forceinline__ f32x2_t bf2x2_to_f2(uint32_t raw) {
 }
 
 // grid = (N samples, C / CW); block = 64 * NW
-template <int S>
+template <int S, int GC = 0>
 __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   using T = bf16_t;
   constexpr int CW = 64 / S, CP = CW / 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
-  const int MS = p.g.grid * S + 6;
+  const int MS = (GC ? GC : p.g.grid) * S + 6;      // GC = compile-time patch-grid side: LDS offsets become immediates
   T* map = reinterpret_cast<T*>(dw5_smem);
   float* wl = reinterpret_cast<float*>(dw5_smem + dw5_map_bytes<T, S>(p.g.grid));
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
