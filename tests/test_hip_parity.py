@@ -11,6 +11,8 @@ Tolerances (stated per BASELINE.json north_star):
 from collections import OrderedDict
 
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -301,3 +303,21 @@ def test_fcmae_module_dropin_api():
     before = model._pflat.clone()
     opt.step()
     assert not torch.equal(before, model._pflat)      # torch optimizers update the engine's flat buffer in place
+
+
+def test_two_rank_step_driver_on_one_gpu(tmp_path):
+    """world_size 2 through the real step driver (segmented launch program, bucketed all-reduce overlapped on a
+    communication stream, AdamW): two processes share cuda:0 and exchange gradients over gloo (RCCL refuses two
+    ranks per device). Both ranks must end with identical parameters and the all-reduced gradients must equal
+    the hand-averaged gradients of a single-process run."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_probe.py"), str(tmp_path)], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for mode in ("program", "eager"):
+        m = re.search(mode + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
+        assert m and float(m.group(1)) < 1e-5, r.stdout
+        assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
