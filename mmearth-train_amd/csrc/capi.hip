@@ -987,6 +987,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
   p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
   const int HN = a.H;
+  if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
   if ((a.ldw & 7) || HN % NC || HN % KCH) return (int)hipErrorInvalidValue;
   const int rowblocks = cdiv(a.M, 64 * RT);

@@ -35,8 +35,10 @@ __device__ __forceinline__ void unpack4(const uint2& a, float (&o)[4]) {
 // =====================================================================================
 // grid = (ceil(M / (64*RT)), HN / cols_per_split); block = 256
 template <int KC, int MODE, int RT, int NC>
-__global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int cols_per_split) {
+__global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, int cols_per_split) {
   using T = bf16_t;
+  constexpr int HN = 4 * KC;                    // compile-time row pitch of the hidden tensors (H = 4C)
+  (void)HN_rt;
   static_assert(NC % 32 == 0, "chunks are whole tile pairs");
   constexpr int KS = (KC + 31) / 32, KP = KS * 32, LDW = KP + 8, VPR = KP / 8, WV = (NC * VPR + 255) / 256;
   constexpr bool PAD = KP != KC;                 // K padded with zero columns (C = 40 / 80)
@@ -223,8 +225,10 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN, int 
 // =====================================================================================
 // grid = ceil(M / (64*RT)); block = 256. rpg = rows per GRN group (M for the batch-global sparse GRN).
 template <int KC, int MODE, int RT, int KCH>
-__global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN, int rpg) {
+__global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
   using T = bf16_t;
+  constexpr int HN = 4 * KC;                    // the ConvNeXt hidden width; a compile-time row pitch keeps address math out of VGPRs
+  (void)HN_rt;
   constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + 8, VPR = KCH / 8, WV = (NP * VPR + 255) / 256;
   constexpr bool PAD = NP != KC;                 // output columns padded to whole 16-wide tiles (C = 40)
   static_assert(KC % 8 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
