@@ -903,6 +903,24 @@ class Engine:
                 self._loss_tabs[kind] = (kind_id, tab, len(mods))
                 self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_multi, dt, 0, kind_id, _p(tab), len(mods), N,
                          kind=f"loss_{kind}_fwd")
+        # image-level head chain (LN, pooling, linear heads, their losses) on the side lane next to the pixel heads and
+        # their losses: both only read the decoder output
+        self._fwd_join_keys = []
+        if self.lanes and self.loss_multi and os.environ.get("MPMAE_IMG_SIDE", "1") != "0":
+            names = [op[0] for op in f]
+            side_names = {"head:ln", "head:pool", "head:img"} | {n for n in names if n.startswith("loss:img")}
+            idx = [i for i, n in enumerate(names) if n in side_names]
+            if idx and "head:pix" in names:
+                prod = f[names.index("head:pix") - 1][3]          # the op that completes the decoder output
+                if prod["signal"] is None:
+                    prod["signal"] = "dec_out"
+                for j, i in enumerate(idx):
+                    m = f[i][3]
+                    m["lane"] = 1
+                    if j == 0:
+                        m["wait"] = tuple(m["wait"]) + (prod["signal"],)
+                f[idx[-1]][3]["signal"] = "img_side_done"
+                self._fwd_join_keys = ["img_side_done"]
         self.loss_scale = 1.0
         lv = P.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
         glv = self.grads.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
@@ -1163,9 +1181,10 @@ class Engine:
         lib, a = self.lib, self._fin_args
         m0 = dict(lane=0, wait=(), signal=None)
 
-        def fin(dlv):
+        def fin(dlv):      # the forward finalisation also joins the image-head chain that ran on the side lane
+            m = dict(lane=0, wait=tuple(getattr(self, "_fwd_join_keys", ())) if not dlv else (), signal=None)
             return ("loss.finalize", lib.mpmae_loss_finalize,
-                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m0)
+                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
         first = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), m0)]
