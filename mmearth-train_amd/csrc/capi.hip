@@ -719,8 +719,9 @@ static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
   if (dt != 1 || pro != PRO_NONE) return false;
   const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);
   if (epi != EPI_STORE && epi != EPI_RESID && !stats) return false;
-  if (stats && a.rpg < a.M) return false;                 // grouped statistics: generic kernel
-  if (stats && (!a.ws || a.ws_floats < (size_t)((a.M + 127) / 128) * a.N * 2)) return false;
+  const bool grouped = stats && a.rpg > 0 && a.rpg < a.M;
+  if (grouped && (a.rpg < 43 || a.M % a.rpg)) return false;    // a 128-row tile may overlap at most 4 groups
+  if (stats && (!a.ws || a.ws_floats < (size_t)((a.M + 127) / 128) * a.N * 2 * (grouped ? 4 : 1))) return false;
   if (epi == EPI_DZ_STATS && (a.ldr & 7)) return false;
   if ((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) return false;
   if (epi == EPI_RESID && (a.ldr & 7)) return false;
@@ -729,7 +730,11 @@ static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
 
 template <int BN>
 static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
-  const size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
+  size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
+  if (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) {         // epilogue image: fp32 stage | h tile | colacc[4][2][BN] | activity
+    const size_t epi_lds = (size_t)128 * 68 * 4 + (size_t)128 * (BN + 8) * 2 + (size_t)8 * BN * 4 + 128;
+    if (epi_lds > lds) lds = epi_lds;
+  }
   dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
   static int bk32 = -1;
   if (bk32 < 0) { const char* e = getenv("MPMAE_NT_BK32"); bk32 = e ? atoi(e) : 1; }
@@ -765,6 +770,15 @@ static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   if (err) return err;
   if (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) {
     const int mblocks = cdiv(a.M, FBM);
+    if (a.rpg > 0 && a.rpg < a.M) {                            // per-group sums (dense decoder): fold the tiles' group slots
+      const int G = a.M / a.rpg;
+      const int rg = grid1d((long long)G * a.N, 256, 2048);
+      LAUNCH(reduce_tile_groups_kernel, dim3(rg), dim3(256), 0, st, (const float*)a.ws, mblocks, a.N, a.rpg, G, a.s0);
+      if (epi == EPI_DZ_STATS)
+        LAUNCH(reduce_tile_groups_kernel, dim3(rg), dim3(256), 0, st, (const float*)(a.ws + (size_t)mblocks * 4 * a.N), mblocks, a.N,
+               a.rpg, G, a.s1);
+      return (int)hipGetLastError();
+    }
     launch_reduce(0, a.ws, mblocks, a.N, a.s0, nullptr, 0, 0, 0, 0, st);
     if (epi == EPI_DZ_STATS) launch_reduce(0, a.ws + (size_t)mblocks * a.N, mblocks, a.N, a.s1, nullptr, 0, 0, 0, 0, st);
     err = (int)hipGetLastError();

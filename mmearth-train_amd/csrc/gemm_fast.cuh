@@ -113,9 +113,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
     // tile column): 16 in-register adds + 2 shuffles per column instead of a 64-lane butterfly.
     constexpr int HLD = BN + 8;
     bf16_t* htile = reinterpret_cast<bf16_t*>(smem_raw + 128 * SLD * sizeof(float));       // [128][BN+8] (DZ_STATS)
-    float* colacc = reinterpret_cast<float*>(smem_raw + 128 * SLD * sizeof(float) + 128 * HLD * sizeof(bf16_t));  // [2][BN]
-    uint8_t* actl = reinterpret_cast<uint8_t*>(colacc + 2 * BN);                            // [128] row activity
-    for (int i = tid; i < 2 * BN; i += 256) colacc[i] = 0.f;
+    // colacc[q][stat][BN]: q = row group inside the tile (one group for the batch-global sparse GRN; up to 4 for
+    // the per-sample GRN of the dense decoder, 49 rows per group against 128-row tiles)
+    float* colacc = reinterpret_cast<float*>(smem_raw + 128 * SLD * sizeof(float) + 128 * HLD * sizeof(bf16_t));  // [4][2][BN]
+    uint8_t* actl = reinterpret_cast<uint8_t*>(colacc + 8 * BN);                            // [128] row activity
+    const bool grouped = p.rpg > 0 && p.rpg < p.M;
+    const int g0 = grouped ? m0 / p.rpg : 0;
+    for (int i = tid; i < 8 * BN; i += 256) colacc[i] = 0.f;
     if (tid < 128) actl[tid] = (p.act && m0 + tid < p.M) ? p.act[m0 + tid] : 1;
     if constexpr (EPI == EPI_DZ_STATS) {
       for (int c = tid; c < 128 * (BN / 8); c += 256) {
@@ -125,13 +129,18 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
         *reinterpret_cast<uint4*>(htile + row * HLD + ch) = v;
       }
     }
+    int qrow[4][4];                                   // group slot of this lane's 16 rows (independent of the column tile)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qrow[i][r] = grouped ? (m0 + wm * 64 + i * 16 + lg * 4 + r) / p.rpg - g0 : 0;
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int cl = wn * (BN / 2) + j * 16 + lr;
       const int col = n0 + cl;
       const float bias = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-      float cs0 = 0.f, cs1 = 0.f;
+      float cs0[4] = {0.f, 0.f, 0.f, 0.f}, cs1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -142,22 +151,37 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
             float v = acc[i][j][r] + bias;
             if (!actl[rl]) v = 0.f;
             v = bf2f(f2bf(v));                       // statistics on the value as stored
-            if constexpr (EPI == EPI_GELU_SUMSQ) { const float g = gelu_t<T>(v); cs0 += g * g; }
-            else { cs0 += v; cs1 += v * gelu_t<T>(bf2f(htile[rl * HLD + cl])); }
+            float a0, a1 = 0.f;
+            if constexpr (EPI == EPI_GELU_SUMSQ) { const float g = gelu_t<T>(v); a0 = g * g; }
+            else { a0 = v; a1 = v * gelu_t<T>(bf2f(htile[rl * HLD + cl])); }
+            if (!grouped) { cs0[0] += a0; cs1[0] += a1; }
+            else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { cs0[q] += (qrow[i][r] == q) ? a0 : 0.f; cs1[q] += (qrow[i][r] == q) ? a1 : 0.f; }
+            }
           }
         }
-      cs0 += __shfl_xor(cs0, 16, 64); cs0 += __shfl_xor(cs0, 32, 64);
-      if (lg == 0) atomicAdd(&colacc[cl], cs0);
-      if constexpr (EPI == EPI_DZ_STATS) {
-        cs1 += __shfl_xor(cs1, 16, 64); cs1 += __shfl_xor(cs1, 32, 64);
-        if (lg == 0) atomicAdd(&colacc[BN + cl], cs1);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (q > 0 && !grouped) break;
+        float a = cs0[q];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        if (lg == 0) atomicAdd(&colacc[(q * 2 + 0) * BN + cl], a);
+        if constexpr (EPI == EPI_DZ_STATS) {
+          float b = cs1[q];
+          b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+          if (lg == 0) atomicAdd(&colacc[(q * 2 + 1) * BN + cl], b);
+        }
       }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
-      if (n0 + c < p.N) {
-        p.ws[(size_t)blockIdx.x * p.N + n0 + c] = colacc[c];
-        if (EPI == EPI_DZ_STATS) p.ws[((size_t)gridDim.x + blockIdx.x) * p.N + n0 + c] = colacc[BN + c];
+    // partial slabs: single group: ws[stat][tile][N]; grouped: ws[stat][tile][4][N] (folded by reduce_tile_groups_kernel)
+    const int nq = grouped ? 4 : 1;
+    for (int c = tid; c < nq * BN; c += 256) {
+      const int q = c / BN, cc = c - q * BN;
+      if (n0 + cc < p.N) {
+        p.ws[((size_t)blockIdx.x * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 0) * BN + cc];
+        if (EPI == EPI_DZ_STATS) p.ws[(((size_t)gridDim.x + blockIdx.x) * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 1) * BN + cc];
       }
     }
     __syncthreads();
@@ -414,5 +438,19 @@ __global__ __launch_bounds__(256) void colstats_kernel(const T* __restrict__ h, 
       ws[(size_t)blockIdx.y * H + c] = r0;
       if (mode == 1) ws[((size_t)gridDim.y + blockIdx.y) * H + c] = r1;
     }
+  }
+}
+
+// second stage of the per-group column statistics of 128-row GEMM tiles (see the STATS epilogue above):
+// out[g][n] += sum over the (at most 2) tiles that overlap group g of ws[tile][g - first_group(tile)][n]
+__global__ __launch_bounds__(256) void reduce_tile_groups_kernel(const float* __restrict__ ws, int mtiles, int N, int rpg, int G,
+                                                                 float* __restrict__ out) {
+  const size_t total = (size_t)G * N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = i / N, n = i - (size_t)g * N;
+    const int t0 = (g * rpg) / 128, t1 = ((g + 1) * rpg - 1) / 128;
+    float s = 0.f;
+    for (int t = t0; t <= t1 && t < mtiles; ++t) s += ws[((size_t)t * 4 + (g - (t * 128) / rpg)) * N + n];
+    out[i] += s;
   }
 }

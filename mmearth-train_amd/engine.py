@@ -54,6 +54,10 @@ class Engine:
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.disable_rsc = os.environ.get("MPMAE_RSC", "1") == "0"
         self.down_grouped = os.environ.get("MPMAE_DOWN_GROUPED", "1") != "0"
+        # per-sample GRN sums of the dense decoder block in the GEMM epilogues instead of separate colstats passes: works
+        # (parity-tested) but measured SLOWER, 5.50 vs 5.42 ms/step - the statistics epilogue costs the 1568-workgroup
+        # decoder GEMMs more than the two column passes it removes; off by default
+        self.grouped_epi = self.dt == BF16 and os.environ.get("MPMAE_GROUPED_EPI", "0") != "0" and cfg.num_patches >= 43
         self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
@@ -583,7 +587,7 @@ class Engine:
                      nbytes=3 * M * Cc * esz)
         if rs:
             pass
-        elif blk["sparse"]:      # single statistics group: column sums ride in the GEMM epilogue
+        elif blk["sparse"] or self.grouped_epi:      # column sums ride in the GEMM epilogue (per-sample groups: bf16 fast kernel)
             self._gemm(lst, tag + ":pw1", "NONE", "GELU_SUMSQ", A=blk["xn"], B=self.w[tag + ".W1"]["t"],
                        bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
                        rpg=rpg, s0=blk["G2"], act=act)
@@ -627,7 +631,7 @@ class Engine:
         if rs:
             self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + 2 * M * H) * esz, 2 * M * Cc * H, A=dout, W=w2t["t"],
                      ldw=w2t["ld"], out=dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
-        elif blk["sparse"]:
+        elif blk["sparse"] or self.grouped_epi:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
                        K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
         else:
@@ -636,7 +640,7 @@ class Engine:
         self._guard(lst, dz)
         self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
                     dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
-        if not blk["sparse"]:
+        if not blk["sparse"] and not self.grouped_epi:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
