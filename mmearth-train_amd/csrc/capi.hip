@@ -741,7 +741,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   if (bk32 && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K <= 512) {
     // short K, wide N (decoder pw1 / pw2.dgrad, pixel heads): half-depth K slabs, 41 KB of LDS instead of 74 KB ->
     // 3-4 workgroups per CU (measured 84 -> 67, 72 -> 58, 85 -> 77 us; for K = 2048 the 64-deep slabs stay faster)
-    const size_t lds32 = (size_t)(2 * FBM * 40 + 2 * BN * 40) * sizeof(bf16_t);
+    const size_t lds32 = (size_t)(2 * FBM * (32 + FPAD) + 2 * BN * (32 + FPAD)) * sizeof(bf16_t);
     LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 32>), g, dim3(256), lds32, st, a);
     return (int)hipGetLastError();
   }
@@ -994,7 +994,7 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
 // chunked variants (rsc.cuh): weights streamed through LDS, any M
 static int rsc_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-template <int KC, int RT, int NC, int KCH, int RTN = RT>
+template <int KC, int RT, int NC, int KCH, int RTN = RT, int PFN = 0>
 static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   RsP p;
   p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
@@ -1012,7 +1012,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
     constexpr int KP = ((KC + 31) / 32) * 32;
-    const size_t lds = (size_t)2 * NC * (KP + 8) * 2 + (size_t)2 * cps * 4;
+    const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)2 * cps * 4;
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
     if (!a.ws || a.ws_floats < need || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
     dim3 g(rowblocks, nsplit);
@@ -1037,21 +1037,23 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     const int rpg = a.rpg > 0 ? a.rpg : a.M;
     const int rowblocks = cdiv(a.M, 64 * RTN);
     constexpr int NP = ((KC + 15) / 16) * 16;
-    const size_t lds = (size_t)2 * NP * (KCH + 8) * 2 + (size_t)2 * KC * 4;
+    static int pf_on = rsc_env("MPMAE_RSC_PF", 1);
+    const bool pf = PFN && pf_on && rpg >= a.M;       // early-issue variant: single GRN group only
+    const size_t lds = (size_t)2 * NP * (KCH + RSC_PAD) * 2 + (size_t)2 * KC * 4 + (pf ? (size_t)2 * HN * 4 : 0);
     if (lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
-    if (which == 4) {
-      static size_t cur = 64 * 1024;
-      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 0, RTN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
-      LAUNCH((rsc_narrow_kernel<KC, 0, RTN, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
-    } else {
-      if (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC) return (int)hipErrorInvalidValue;
-      static size_t cur = 64 * 1024;
-      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, 1, RTN, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
-      LAUNCH((rsc_narrow_kernel<KC, 1, RTN, KCH>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg);
+    if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
+#define RSC_NARROW(MODE_, PF_) do { \
+      static size_t cur = 64 * 1024; \
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+      LAUNCH((rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg); } while (0)
+    if (which == 4) { if (pf) RSC_NARROW(0, PFN); else RSC_NARROW(0, 0); }
+    else {
+      if (pf) RSC_NARROW(1, PFN); else RSC_NARROW(1, 0);
       const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
       if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
       launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
     }
+#undef RSC_NARROW
   } else {
     return (int)hipErrorInvalidValue;
   }
@@ -1062,7 +1064,7 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) {
     static int nc32 = rsc_env("MPMAE_RSC_NC32", 1);     // 32-column chunks: the N range splits 4 ways (measured 27.7 -> 24.1 us)
-    if (nc32) return launch_rsc<160, 1, 32, 64>(which, *a, S_(s));
+    if (nc32) return launch_rsc<160, 1, 32, 64, 1, 1>(which, *a, S_(s));
     return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
   }
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));

@@ -10,7 +10,6 @@
 #pragma once
 #include "dwconv5.cuh"
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2_t bf2x2_to_f2(uint32_t raw) {
   f32x2_t v;

@@ -14,7 +14,8 @@
 #pragma once
 #include "gemm.cuh"
 
-constexpr int FBM = 128, FBK = 64, FLD = FBK + 8;   // LDS row = 72 bf16 = 144 B
+// (a 160-byte row stride = 32 mod 64, which the ds_read_b128 lane-group table suggests, measured SLOWER: 5.39 vs 5.32 ms/step)
+constexpr int FBM = 128, FBK = 64, FPAD = 8, FLD = FBK + FPAD;   // LDS row = 72 bf16 = 144 B
 
 __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nrows, int ld, int k, int K) {
   // 8 bf16 at (row, k..k+7); zero beyond the matrix. K % 8 == 0 is required by the dispatcher.
@@ -27,7 +28,7 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 // dz*gelu(R) -> ws[blockIdx.x][N], ws[gridDim.x + blockIdx.x][N]); statistics: single group only.
 template <int BN, int EPI, int BK = FBK>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
-  constexpr int LDK = BK + 8, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
+  constexpr int LDK = BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
   using T = bf16_t;
   constexpr int NJ = BN / 32;                 // 16-wide N tiles per wave (wave tile 64 x BN/2)
   constexpr int BCH = BN * CPR / 256;           // 16-byte chunks of the B tile per thread

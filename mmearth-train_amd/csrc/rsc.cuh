@@ -19,7 +19,11 @@
 //                                   MODE 1: dh = (dz*scale + coef*gelu(h))*gelu'(h) (stored over dz),
 //                                           dd = LayerNorm-backward(dh W1), dgamma, dbeta partials
 #pragma once
+#include <type_traits>
 #include "rs.cuh"
+
+// weight rows in LDS: odd multiple of 16 bytes (a 32 mod 64 byte stride made no difference here)
+constexpr int RSC_PAD = 8;
 
 __device__ __forceinline__ uint2 pack_bf16x4(const float (&v)[4]) {
   uint2 u;
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   constexpr int HN = 4 * KC;                    // compile-time row pitch of the hidden tensors (H = 4C)
   (void)HN_rt;
   static_assert(NC % 32 == 0, "chunks are whole tile pairs");
-  constexpr int KS = (KC + 31) / 32, KP = KS * 32, LDW = KP + 8, VPR = KP / 8, WV = (NC * VPR + 255) / 256;
+  constexpr int KS = (KC + 31) / 32, KP = KS * 32, LDW = KP + RSC_PAD, VPR = KP / 8, WV = (NC * VPR + 255) / 256;
   constexpr bool PAD = KP != KC;                 // K padded with zero columns (C = 40 / 80)
   static_assert(KC % 8 == 0 && ((KP / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
@@ -182,19 +186,20 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
         float o[8];
         if (MODE == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            o[e] = live[rt] ? acc[e >> 2][e & 3] + bias[e] : 0.f;       // rounded to bf16 by the store; the GRN sums use the
-            const float gl = gelu_t<T>(o[e]);                            // fp32 value (what the fp32 reference sums)
-            cs0[e] += gl * gl;
-          }
+          for (int e = 0; e < 8; ++e) o[e] = live[rt] ? acc[e >> 2][e & 3] + bias[e] : 0.f;
+          float gl[8];                      // o is rounded to bf16 by the store; the GRN sums use the fp32 value
+          gelu_n<T, 8>(o, gl);              // (what the fp32 reference sums)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs0[e] += gl[e] * gl[e];
         } else {
-          float hv[8];
+          float hv[8], gh[8];
           unpack8(hraw[rt], hv);
+          gelu_n<T, 8>(hv, gh);
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             o[e] = acc[e >> 2][e & 3];
             cs0[e] += o[e];
-            cs1[e] += o[e] * gelu_t<T>(hv[e]);
+            cs1[e] += o[e] * gh[e];
           }
         }
         if (row < p.M) st8<T>(p.out + (size_t)row * HN + n8, o);
@@ -224,22 +229,31 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 
 // =====================================================================================
 // grid = ceil(M / (64*RT)); block = 256. rpg = rows per GRN group (M for the batch-global sparse GRN).
-template <int KC, int MODE, int RT, int KCH>
+// PF = 1 (few, latency-bound workgroups: C = 160 has 1.25 workgroups per CU): the activation chunk kc+1 is requested at the
+// TOP of iteration kc into a second register set (a whole prologue + MFMA phase hides the HBM latency instead of the MFMA
+// phase alone) and the GRN scale / coef vectors are staged in LDS once instead of 4 dependent L2 loads per chunk. Needs a
+// single GRN group (rpg >= M).
+template <int KC, int MODE, int RT, int KCH, int PF = 0>
 __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
   using T = bf16_t;
   constexpr int HN = 4 * KC;                    // the ConvNeXt hidden width; a compile-time row pitch keeps address math out of VGPRs
   (void)HN_rt;
-  constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + 8, VPR = KCH / 8, WV = (NP * VPR + 255) / 256;
+  constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + RSC_PAD, VPR = KCH / 8, WV = (NP * VPR + 255) / 256;
   constexpr bool PAD = NP != KC;                 // output columns padded to whole 16-wide tiles (C = 40)
   static_assert(KC % 8 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
   bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][NP][LDW]
   float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NP * LDW * sizeof(bf16_t));   // [2][KC] (MODE 1)
+  float* vec = red + 2 * KC;                                                           // [2][HN] (PF): scale | beta or coef
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
-  const int nkc = HN / KCH;
+  constexpr int nkc = HN / KCH;
   if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
+  if (PF) for (int i = tid; i < HN / 4; i += 256) {
+    reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(p.v0)[i];
+    reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
+  }
 
   uint4 wr[WV];
   auto wload = [&](int kc) {
@@ -266,17 +280,19 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     rowv[rt] = rbase + rt * 16 + lr;
     inb[rt] = rowv[rt] < p.M;
     live[rt] = inb[rt] && (!p.act || p.act[rowv[rt]]);
-    goff[rt] = inb[rt] ? (size_t)(rowv[rt] / rpg) * HN : 0;
+    goff[rt] = (inb[rt] && !PF) ? (size_t)(rowv[rt] / rpg) * HN : 0;
   }
-  uint4 araw[RT][KSC], hraw[RT][KSC];
-  auto aload = [&](int kc) {
+  constexpr int NB = PF ? 2 : 1;
+  uint4 araw[NB][RT][KSC], hraw[NB][RT][KSC];
+  auto aload = [&](auto bsel, int kc) {
+    constexpr int B = decltype(bsel)::value;
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
         const size_t off = (size_t)rowv[rt] * HN + kc * KCH + s * 32 + lg * 8;
-        araw[rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
-        if (MODE == 1) hraw[rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
+        araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (MODE == 1) hraw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
       }
   };
 
@@ -286,11 +302,9 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[rt][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  wload(0);
-  aload(0);
-  wstore(0);
-  __syncthreads();
-  for (int kc = 0; kc < nkc; ++kc) {
+  auto step = [&](auto bsel, int kc) {
+    constexpr int B = decltype(bsel)::value;
+    if (PF && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, PF ? (B ^ 1) : 0>{}, kc + 1); }
     // ---- prologue on this chunk's activation fragments (registers), results stored once
     bf16x8_t af[RT][KSC];
 #pragma unroll
@@ -298,26 +312,25 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
         const int k = kc * KCH + s * 32 + lg * 8;
-        const float* sp = p.v0 + goff[rt] + k;
-        const float* tp = p.v1 + ((MODE == 0) ? 0 : goff[rt]) + k;       // grn beta is per channel, coef per group
+        const float* sp = PF ? vec + k : p.v0 + goff[rt] + k;
+        const float* tp = PF ? vec + HN + k : p.v1 + ((MODE == 0) ? 0 : goff[rt]) + k;       // grn beta is per channel, coef per group
         const float4 sa = *reinterpret_cast<const float4*>(sp), sb = *reinterpret_cast<const float4*>(sp + 4);
         const float4 ta = *reinterpret_cast<const float4*>(tp), tb = *reinterpret_cast<const float4*>(tp + 4);
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
         const float tc[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         float a[8], z[8];
-        unpack8(araw[rt][s], a);
+        unpack8(araw[B][rt][s], a);
         if (MODE == 0) {
+          float ga[8];
+          gelu_n<T, 8>(a, ga);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) z[e] = live[rt] ? gelu_t<T>(a[e]) * sc[e] + tc[e] : 0.f;      // GRN(gelu(h))
+          for (int e = 0; e < 8; ++e) z[e] = live[rt] ? ga[e] * sc[e] + tc[e] : 0.f;                 // GRN(gelu(h))
         } else {
-          float h[8];
-          unpack8(hraw[rt][s], h);
+          float h[8], gl[8], dg[8];
+          unpack8(hraw[B][rt][s], h);
+          gelu_both_n<T, 8>(h, gl, dg);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float gl, dg;
-            gelu_both_t<T>(h[e], gl, dg);
-            z[e] = (a[e] * sc[e] + tc[e] * gl) * dg;                                                 // dh
-          }
+          for (int e = 0; e < 8; ++e) z[e] = (a[e] * sc[e] + tc[e] * gl[e]) * dg[e];                 // dh
         }
         af[rt][s] = pack_bf16x8(z);
         if (inb[rt]) {
@@ -325,7 +338,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
           if (dst) *reinterpret_cast<uint4*>(dst + (size_t)rowv[rt] * HN + k) = __builtin_bit_cast(uint4, af[rt][s]);
         }
       }
-    if (kc + 1 < nkc) { wload(kc + 1); aload(kc + 1); }
+    if (!PF && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
     const bf16_t* wb = Wc + (size_t)(kc & 1) * NP * LDW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -341,6 +354,20 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     }
     if (kc + 1 < nkc) wstore((kc + 1) & 1);
     __syncthreads();
+  };
+
+  wload(0);
+  aload(std::integral_constant<int, 0>{}, 0);
+  wstore(0);
+  __syncthreads();
+  if (PF) {
+#pragma unroll 1
+    for (int kc = 0; kc < nkc; kc += 2) {
+      step(std::integral_constant<int, 0>{}, kc);
+      if (kc + 1 < nkc) step(std::integral_constant<int, PF ? 1 : 0>{}, kc + 1);
+    }
+  } else {
+    for (int kc = 0; kc < nkc; ++kc) step(std::integral_constant<int, 0>{}, kc);
   }
 
   // ---- epilogue: lane holds row m = lr, columns n = j*16 + lg*4 + r
