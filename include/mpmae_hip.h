@@ -147,6 +147,15 @@ typedef struct MpmaeRsArgs {
   float* s0; float* s1;            /* statistics / parameter-gradient outputs (accumulated) */
   size_t ws_floats;
   int rpg;                         /* rows per GRN group (which = 4, 5); 0 = all rows */
+  /* Optional (which = 4, 5; single GRN group; C = 40 / 80 / 160): mpmae_grn_fwd_finalize / mpmae_grn_bwd_finalize
+   * folded into the kernel's prologue (every workgroup recomputes the H-vector, workgroup 0 publishes it);
+   * fin_sum == NULL keeps v0 / v1 as inputs.
+   *   which 4: fin_sum = G2[H] -> Gx, Ainv, scale = 1 + gamma Gx Ainv written to fin_gx, fin_ainv, fin_out; v1 = GRN beta
+   *   which 5: fin_sum = S1[H], fin_sum0 = S0[H], fin_gx / fin_ainv read -> coef (also to fin_out if set), fin_dgamma /
+   *            fin_dbeta accumulated; v0 = scale */
+  const float* fin_sum; const float* fin_sum0; const float* fin_gamma;
+  float* fin_gx; float* fin_ainv; float* fin_out; float* fin_dgamma; float* fin_dbeta;
+  float fin_eps;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpmae_hip.so")
+# MPMAE_LIB: developer override for A/B runs of two builds inside one GPU session
+LIB_PATH = os.environ.get("MPMAE_LIB") or os.path.join(_HERE, "libmpmae_hip.so")
 
 c_void_p, c_int, c_float, c_size_t = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 
@@ -98,7 +99,10 @@ class RsArgs(C.Structure):
                 ("out", c_void_p), ("xhat", c_void_p), ("xn", c_void_p), ("rstd", c_void_p), ("R", c_void_p),
                 ("lng", c_void_p), ("ws", c_void_p), ("act", c_void_p), ("M", c_int),
                 ("C", c_int), ("H", c_int), ("s0", c_void_p), ("s1", c_void_p), ("ws_floats", c_size_t),
-                ("rpg", c_int)]
+                ("rpg", c_int),
+                ("fin_sum", c_void_p), ("fin_sum0", c_void_p), ("fin_gamma", c_void_p), ("fin_gx", c_void_p),
+                ("fin_ainv", c_void_p), ("fin_out", c_void_p), ("fin_dgamma", c_void_p), ("fin_dbeta", c_void_p),
+                ("fin_eps", C.c_float)]
 
 
 class StemTailArgs(C.Structure):

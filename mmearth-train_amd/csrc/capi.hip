@@ -944,6 +944,8 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
   p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
   p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
+  p.fin_sum = nullptr;
+  if (a.fin_sum) return (int)hipErrorInvalidValue;      // folded GRN finalisation: chunked kernels only
   const int ngroups = a.M / 16;
   if (which == 0 || which == 1) {
     constexpr int KS = (KC + 31) / 32, LDW = KS * 32 + 8, SLD = HN + 8;
@@ -1000,12 +1002,15 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
   p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
   p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
+  p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
+  p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
   if ((a.ldw & 7) || HN % NC || HN % KCH) return (int)hipErrorInvalidValue;
   const int rowblocks = cdiv(a.M, 64 * RT);
   if (which == 0 || which == 1) {
+    if (a.fin_sum) return (int)hipErrorInvalidValue;
     // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
     static int target = rsc_env("MPMAE_RSC_BLOCKS", 1536);
     int nsplit = 1;
@@ -1038,9 +1043,15 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     const int rowblocks = cdiv(a.M, 64 * RTN);
     constexpr int NP = ((KC + 15) / 16) * 16;
     static int pf_on = rsc_env("MPMAE_RSC_PF", 1);
-    const bool pf = PFN && pf_on && rpg >= a.M;       // early-issue variant: single GRN group only
-    const size_t lds = (size_t)2 * NP * (KCH + RSC_PAD) * 2 + (size_t)2 * KC * 4 + (pf ? (size_t)2 * HN * 4 : 0);
+    const bool pf = PFN && pf_on && rpg >= a.M;       // LDS-staged GRN vectors (+ early issue): single GRN group only
+    const size_t lds = (size_t)2 * NP * (KCH + RSC_PAD) * 2 + (size_t)2 * KC * 4 + (pf ? (size_t)2 * HN * 4 + 32 : 0);
     if (lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    if (a.fin_sum) {                                   // folded GRN finalisation
+      if (!pf || !a.fin_gamma || !a.fin_gx || !a.fin_ainv) return (int)hipErrorInvalidValue;
+      if (which == 4 && (!a.fin_out || !a.v1)) return (int)hipErrorInvalidValue;
+      if (which == 5 && (!a.fin_sum0 || !a.fin_dgamma || !a.fin_dbeta || !a.v0)) return (int)hipErrorInvalidValue;
+      if (((uintptr_t)a.fin_sum | (uintptr_t)a.fin_gamma) & 15) return (int)hipErrorInvalidValue;
+    }
     if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
 #define RSC_NARROW(MODE_, PF_) do { \
       static size_t cur = 64 * 1024; \
@@ -1064,7 +1075,7 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) {
     static int nc32 = rsc_env("MPMAE_RSC_NC32", 1);     // 32-column chunks: the N range splits 4 ways (measured 27.7 -> 24.1 us)
-    if (nc32) return launch_rsc<160, 1, 32, 64, 1, 1>(which, *a, S_(s));
+    if (nc32) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));
     return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
   }
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
@@ -1073,12 +1084,12 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
     static int v40 = rsc_env("MPMAE_RSC_N40", 2), v80 = rsc_env("MPMAE_RSC_N80", 1);
     if (a->C == 40 && a->H == 160) {
       if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2>(which, *a, S_(s));
-      if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1>(which, *a, S_(s));
+      if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1, 2>(which, *a, S_(s));
       if (v40 == 3) return launch_rsc<40, 4, 160, 160, 1>(which, *a, S_(s));
       return launch_rsc<40, 4, 160, 160, 2>(which, *a, S_(s));
     }
     if (a->C == 80 && a->H == 320) {
-      if (v80 == 1) return launch_rsc<80, 2, 64, 64, 1>(which, *a, S_(s));
+      if (v80 == 1) return launch_rsc<80, 2, 64, 64, 1, 2>(which, *a, S_(s));
       if (v80 == 2) return launch_rsc<80, 2, 64, 32, 1>(which, *a, S_(s));
       return launch_rsc<80, 2, 64, 64, 2>(which, *a, S_(s));
     }

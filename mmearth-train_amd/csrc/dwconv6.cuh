@@ -29,20 +29,55 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   float* wl = reinterpret_cast<float*>(dw5_smem + dw5_map_bytes<T, S>(p.g.grid));
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
   const int C = p.C, n = blockIdx.x, c0 = blockIdx.y * CW;
+  // Prologue: every global load goes out first (the sample's visible rows, the taps); the zero fill of the map runs
+  // under their latency and one barrier later both land in LDS - one exposed memory latency instead of two.
+  using D = Dw5<T, S>;
+  constexpr int U = 4, WMAX = (49 * CW + 255) / 256;
+  const int items = p.g.keep * S * S * D::VPL;
+  const T* x = reinterpret_cast<const T*>(p.x);
+  auto row_ld = [&](int it, int& dst) -> uint4 {          // by value: arrays captured by reference ended up in scratch
+    const bool ok = it < items;
+    const int itc = ok ? it : 0;
+    const int v = itc % D::VPL, pt = itc / D::VPL;
+    const int slot = pt / (S * S), q = pt - slot * (S * S);
+    const int iy = q / S, ix = q - iy * S;
+    const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
+    const int py = patch / p.g.grid, px = patch - py * p.g.grid;
+    dst = ok ? (((py * S + iy + 3) * MS + px * S + ix + 3) * CW + v * D::EPV) : -1;
+    return *reinterpret_cast<const uint4*>(x + ((size_t)(n * p.g.keep + slot) * (S * S) + q) * C + c0 + v * D::EPV);
+  };
+  auto row_st = [&](const uint4& v, int dst) { if (dst >= 0) *reinterpret_cast<uint4*>(map + dst) = v; };
+  auto tap = [&](int i) {
+    const int k = i / CW, cc = i - k * CW;
+    int kh = k / 7, kw = k - kh * 7;
+    if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
+    return p.w[kh * p.s_kh + kw * p.s_kw + (c0 + cc) * p.s_c];
+  };
+  static_assert(U == 4, "four rows in flight per thread");
+  int d0, d1, d2, d3;
+  const uint4 v0 = row_ld(tid, d0), v1 = row_ld(tid + blockDim.x, d1), v2 = row_ld(tid + 2 * blockDim.x, d2),
+              v3 = row_ld(tid + 3 * blockDim.x, d3);
+  float wv[WMAX];
+#pragma unroll
+  for (int u = 0; u < WMAX; ++u) {
+    const int i = tid + u * blockDim.x;
+    wv[u] = tap(i < 49 * CW ? i : 0);
+  }
   {
     uint4* m4 = reinterpret_cast<uint4*>(dw5_smem);
     const int nvec = (int)(dw5_map_bytes<T, S>(p.g.grid) / 16);
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
     for (int i = tid; i < nvec; i += blockDim.x) m4[i] = z;
   }
-  for (int i = tid; i < 49 * CW; i += blockDim.x) {
-    const int k = i / CW, cc = i - k * CW;
-    int kh = k / 7, kw = k - kh * 7;
-    if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
-    wl[i] = p.w[kh * p.s_kh + kw * p.s_kw + (c0 + cc) * p.s_c];
-  }
   __syncthreads();
-  dw5_scatter<T, S, false>(p.g, n, reinterpret_cast<const T*>(p.x), map, MS, C, c0);
+#pragma unroll
+  for (int u = 0; u < WMAX; ++u) {
+    const int i = tid + u * blockDim.x;
+    if (i < 49 * CW) wl[i] = wv[u];
+  }
+  for (int i = tid + WMAX * blockDim.x; i < 49 * CW; i += blockDim.x) wl[i] = tap(i);      // blocks under 256 threads
+  row_st(v0, d0); row_st(v1, d1); row_st(v2, d2); row_st(v3, d3);
+  for (int it = tid + blockDim.x * U; it < items; it += blockDim.x) { int d; const uint4 v = row_ld(it, d); row_st(v, d); }
   __syncthreads();
 
   const int cp = lane % CP, ox = (lane / CP) % S, sub = lane / (CP * S);      // CP * S == 32
@@ -189,62 +224,60 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
   const int C = p.C, n = blockIdx.x, c0 = (blockIdx.y * 4 + wave) * CW;
   const bool chunk_ok = c0 < C;
   const int cc0 = chunk_ok ? c0 : 0;
-  {
-    uint4* m4 = reinterpret_cast<uint4*>(map);
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = lane; i < MAPB / 16; i += 64) m4[i] = z;
+  // every global load of the prologue first (taps, the sample's visible rows, the slot table of this lane's output
+  // column); the zero fill runs under their latency
+  float wv[13];                      // 49*16 = 784 taps: 13 loads per lane, all in flight together
+#pragma unroll
+  for (int u = 0; u < 13; ++u) {
+    const int i = lane + 64 * u, ic = i < 49 * CW ? i : 0;
+    const int k = ic / CW, cc = ic - k * CW;
+    int kh = k / 7, kw = k - kh * 7;
+    if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
+    wv[u] = p.w[kh * p.s_kh + kw * p.s_kw + (cc0 + cc) * p.s_c];
   }
-  {
-    float wv[13];                      // 49*16 = 784 taps: 13 loads per lane, all in flight together
-#pragma unroll
-    for (int u = 0; u < 13; ++u) {
-      const int i = lane + 64 * u, ic = i < 49 * CW ? i : 0;
-      const int k = ic / CW, cc = ic - k * CW;
-      int kh = k / 7, kw = k - kh * 7;
-      if (p.flip) { kh = 6 - kh; kw = 6 - kw; }
-      wv[u] = p.w[kh * p.s_kh + kw * p.s_kw + (cc0 + cc) * p.s_c];
-    }
-#pragma unroll
-    for (int u = 0; u < 13; ++u) if (lane + 64 * u < 49 * CW) wl[lane + 64 * u] = wv[u];
-  }
-  __syncthreads();
-  {
-    const T* x = reinterpret_cast<const T*>(p.x);
-    const int items = p.g.keep * 2;
-    uint4 val[2];
-    int dst[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {                 // G*G*2 <= 128 items: at most 2 per lane
-      const int it = lane + 64 * u;
-      const bool ok = it < items;
-      const int v = it & 1, slot = ok ? it >> 1 : 0;
-      const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
-      const int py = patch / G, px = patch - py * G;
-      val[u] = *reinterpret_cast<const uint4*>(x + (size_t)(n * p.g.keep + slot) * C + cc0 + v * 8);
-      dst[u] = ok ? ((py + 3) * MS + px + 3) * CW + v * 8 : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) if (dst[u] >= 0) *reinterpret_cast<uint4*>(map + dst[u]) = val[u];
-  }
-  __syncthreads();
-  const int cp = lane & 7, ox = lane >> 3;
-  if (ox >= G || !chunk_ok) return;
-  const int c = c0 + 2 * cp;
-  T* out = reinterpret_cast<T*>(p.out);
-  const T* add = reinterpret_cast<const T*>(p.add);
-  f32x2_t b2 = {0.f, 0.f};
-  if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
+  const T* x = reinterpret_cast<const T*>(p.x);
+  auto row_ld = [&](int it, int& dst) -> uint4 {          // G*G*2 <= 128 items: at most 2 per lane
+    const bool ok = it < p.g.keep * 2;
+    const int v = it & 1, slot = ok ? it >> 1 : 0;
+    const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
+    const int py = patch / G, px = patch - py * G;
+    dst = ok ? ((py + 3) * MS + px + 3) * CW + v * 8 : -1;
+    return *reinterpret_cast<const uint4*>(x + (size_t)(n * p.g.keep + slot) * C + cc0 + v * 8);
+  };
+  int d0, d1;
+  const uint4 v0 = row_ld(lane, d0), v1 = row_ld(lane + 64, d1);
+  const int cp = lane & 7, oxr = lane >> 3, ox = oxr < G ? oxr : 0;
+  const int c = cc0 + 2 * cp;
   int rows[G];
-  uint32_t addraw[G];
-  f32x2_t acc[G];
 #pragma unroll
   for (int o = 0; o < G; ++o) {
     const int patch = o * G + ox;
     const int slot = p.g.inv ? p.g.inv[n * G * G + patch] : patch;
     rows[o] = slot >= 0 ? n * p.g.keep + slot : -1;
+  }
+  {
+    uint4* m4 = reinterpret_cast<uint4*>(map);
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = lane; i < MAPB / 16; i += 64) m4[i] = z;
+  }
+  T* out = reinterpret_cast<T*>(p.out);
+  const T* add = reinterpret_cast<const T*>(p.add);
+  f32x2_t b2 = {0.f, 0.f};
+  if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
+  uint32_t addraw[G];
+  f32x2_t acc[G];
+#pragma unroll
+  for (int o = 0; o < G; ++o) {
     addraw[o] = (add && rows[o] >= 0) ? *reinterpret_cast<const uint32_t*>(add + (size_t)rows[o] * C + c) : 0u;
     acc[o] = b2;
   }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 13; ++u) if (lane + 64 * u < 49 * CW) wl[lane + 64 * u] = wv[u];
+  if (d0 >= 0) *reinterpret_cast<uint4*>(map + d0) = v0;
+  if (d1 >= 0) *reinterpret_cast<uint4*>(map + d1) = v1;
+  __syncthreads();
+  if (oxr >= G || !chunk_ok) return;
   const T* tile = map + ox * CW + 2 * cp;
 #pragma unroll 1
   for (int kx = 0; kx < 7; ++kx) {

@@ -15,7 +15,10 @@
 #include "gemm.cuh"
 
 // (a 160-byte row stride = 32 mod 64, which the ds_read_b128 lane-group table suggests, measured SLOWER: 5.39 vs 5.32 ms/step)
-constexpr int FBM = 128, FBK = 64, FPAD = 8, FLD = FBK + FPAD;   // LDS row = 72 bf16 = 144 B
+#ifndef MPMAE_FPAD
+#define MPMAE_FPAD 8
+#endif
+constexpr int FBM = 128, FBK = 64, FPAD = MPMAE_FPAD, FLD = FBK + FPAD;   // LDS row = 72 bf16 = 144 B
 
 __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nrows, int ld, int k, int K) {
   // 8 bf16 at (row, k..k+7); zero beyond the matrix. K % 8 == 0 is required by the dispatcher.

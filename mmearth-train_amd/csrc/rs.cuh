@@ -35,6 +35,10 @@ struct RsP {
   float* ws;            // slab rows: wide: [gridDim.x][HN] (+ second stat); narrow MODE 1: [gridDim.x][2][KC]
   const uint8_t* act;   // row activity or nullptr
   int M;
+  // rsc_narrow with LDS-staged vectors: optional folded GRN finalisation (see MpmaeRsArgs.fin_*)
+  const float* fin_sum; const float* fin_sum0; const float* fin_gamma;
+  float* fin_gx; float* fin_ainv; float* fin_out; float* fin_dgamma; float* fin_dbeta;
+  float fin_eps;
 };
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(const float (&v)[8]) {

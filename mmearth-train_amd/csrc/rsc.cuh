@@ -229,10 +229,12 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 
 // =====================================================================================
 // grid = ceil(M / (64*RT)); block = 256. rpg = rows per GRN group (M for the batch-global sparse GRN).
-// PF = 1 (few, latency-bound workgroups: C = 160 has 1.25 workgroups per CU): the activation chunk kc+1 is requested at the
-// TOP of iteration kc into a second register set (a whole prologue + MFMA phase hides the HBM latency instead of the MFMA
-// phase alone) and the GRN scale / coef vectors are staged in LDS once instead of 4 dependent L2 loads per chunk. Needs a
-// single GRN group (rpg >= M).
+// PF bit 0 (few, latency-bound workgroups: C = 160 has 1.25 workgroups per CU): the activation chunk kc+1 is requested at
+// the TOP of iteration kc into a second register set (a whole prologue + MFMA phase hides the HBM latency instead of the
+// MFMA phase alone). PF bit 1: the GRN scale / beta / coef vectors are staged in LDS once instead of 4 dependent L2 loads
+// per chunk, and (p.fin_sum != nullptr) the GRN finalisation itself runs here: every workgroup recomputes the H-vector
+// from the column sums (one block reduction) while its first operand loads are in flight, workgroup 0 publishes it -
+// two launches fewer per block and direction on the main lane. Needs a single GRN group (rpg >= M).
 template <int KC, int MODE, int RT, int KCH, int PF = 0>
 __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
   using T = bf16_t;
@@ -249,11 +251,8 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
   constexpr int nkc = HN / KCH;
+  constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0;
   if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
-  if (PF) for (int i = tid; i < HN / 4; i += 256) {
-    reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(p.v0)[i];
-    reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
-  }
 
   uint4 wr[WV];
   auto wload = [&](int kc) {
@@ -280,9 +279,9 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     rowv[rt] = rbase + rt * 16 + lr;
     inb[rt] = rowv[rt] < p.M;
     live[rt] = inb[rt] && (!p.act || p.act[rowv[rt]]);
-    goff[rt] = (inb[rt] && !PF) ? (size_t)(rowv[rt] / rpg) * HN : 0;
+    goff[rt] = (inb[rt] && !STG) ? (size_t)(rowv[rt] / rpg) * HN : 0;
   }
-  constexpr int NB = PF ? 2 : 1;
+  constexpr int NB = EARLY ? 2 : 1;
   uint4 araw[NB][RT][KSC], hraw[NB][RT][KSC];
   auto aload = [&](auto bsel, int kc) {
     constexpr int B = decltype(bsel)::value;
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 
   auto step = [&](auto bsel, int kc) {
     constexpr int B = decltype(bsel)::value;
-    if (PF && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, PF ? (B ^ 1) : 0>{}, kc + 1); }
+    if (EARLY && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, EARLY ? (B ^ 1) : 0>{}, kc + 1); }
     // ---- prologue on this chunk's activation fragments (registers), results stored once
     bf16x8_t af[RT][KSC];
 #pragma unroll
@@ -312,8 +311,8 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
         const int k = kc * KCH + s * 32 + lg * 8;
-        const float* sp = PF ? vec + k : p.v0 + goff[rt] + k;
-        const float* tp = PF ? vec + HN + k : p.v1 + ((MODE == 0) ? 0 : goff[rt]) + k;       // grn beta is per channel, coef per group
+        const float* sp = STG ? vec + k : p.v0 + goff[rt] + k;
+        const float* tp = STG ? vec + HN + k : p.v1 + ((MODE == 0) ? 0 : goff[rt]) + k;       // grn beta is per channel, coef per group
         const float4 sa = *reinterpret_cast<const float4*>(sp), sb = *reinterpret_cast<const float4*>(sp + 4);
         const float4 ta = *reinterpret_cast<const float4*>(tp), tb = *reinterpret_cast<const float4*>(tp + 4);
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -338,7 +337,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
           if (dst) *reinterpret_cast<uint4*>(dst + (size_t)rowv[rt] * HN + k) = __builtin_bit_cast(uint4, af[rt][s]);
         }
       }
-    if (!PF && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
+    if (!EARLY && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
     const bf16_t* wb = Wc + (size_t)(kc & 1) * NP * LDW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -358,13 +357,58 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 
   wload(0);
   aload(std::integral_constant<int, 0>{}, 0);
+  if (STG) {
+    float* fsh = vec + 2 * HN;                      // [4] block-reduction scratch
+    if (!p.fin_sum) {
+      for (int i = tid; i < HN / 4; i += 256) {
+        reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(p.v0)[i];
+        reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
+      }
+    } else if (MODE == 0) {                         // grn_fwd_finalize_kernel (rows.cuh), same summation order
+      float s = 0.f;
+      for (int j = tid; j < HN; j += 256) { const float gx = sqrtf(p.fin_sum[j]); vec[j] = gx; s += gx; }
+      s = wave_sum(s);
+      if (lane == 0) fsh[wave] = s;
+      __syncthreads();
+      const float ainv = 1.f / ((fsh[0] + fsh[1] + fsh[2] + fsh[3]) / HN + p.fin_eps);
+      const bool pub = blockIdx.x == 0;
+      if (pub && tid == 0) p.fin_ainv[0] = ainv;
+      for (int j = tid; j < HN; j += 256) {
+        const float gx = vec[j], sc = 1.f + p.fin_gamma[j] * (gx * ainv);
+        vec[j] = sc;
+        vec[HN + j] = p.v1[j];
+        if (pub) { p.fin_gx[j] = gx; p.fin_out[j] = sc; }
+      }
+    } else {                                        // grn_bwd_finalize_kernel
+      const float ainv = p.fin_ainv[0];
+      float s = 0.f;
+      for (int j = tid; j < HN; j += 256) s += p.fin_gamma[j] * p.fin_sum[j] * p.fin_gx[j];
+      s = wave_sum(s);
+      if (lane == 0) fsh[wave] = s;
+      __syncthreads();
+      const float T2 = (fsh[0] + fsh[1] + fsh[2] + fsh[3]) * ainv * ainv / HN;
+      const bool pub = blockIdx.x == 0;
+      for (int j = tid; j < HN; j += 256) {
+        const float gx = p.fin_gx[j], s1 = p.fin_sum[j];
+        const float dGx = p.fin_gamma[j] * s1 * ainv - T2;
+        const float cf = (gx > 0.f) ? dGx / gx : 0.f;
+        vec[j] = p.v0[j];
+        vec[HN + j] = cf;
+        if (pub) {
+          if (p.fin_out) p.fin_out[j] = cf;
+          atomicAdd(p.fin_dgamma + j, gx * ainv * s1);
+          atomicAdd(p.fin_dbeta + j, p.fin_sum0[j]);
+        }
+      }
+    }
+  }
   wstore(0);
   __syncthreads();
-  if (PF) {
+  if (EARLY) {
 #pragma unroll 1
     for (int kc = 0; kc < nkc; kc += 2) {
       step(std::integral_constant<int, 0>{}, kc);
-      if (kc + 1 < nkc) step(std::integral_constant<int, PF ? 1 : 0>{}, kc + 1);
+      if (kc + 1 < nkc) step(std::integral_constant<int, EARLY ? 1 : 0>{}, kc + 1);
     }
   } else {
     for (int kc = 0; kc < nkc; ++kc) step(std::integral_constant<int, 0>{}, kc);

@@ -59,6 +59,8 @@ class Engine:
         # decoder GEMMs more than the two column passes it removes; off by default
         self.grouped_epi = self.dt == BF16 and os.environ.get("MPMAE_GROUPED_EPI", "0") != "0" and cfg.num_patches >= 43
         self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
+        # GRN finalisation recomputed in the prologue of the fused kernels (no separate launches on the main lane)
+        self.grn_fold = os.environ.get("MPMAE_GRN_FOLD", "1") != "0" and os.environ.get("MPMAE_RSC_PF", "1") != "0"
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
                            and (lanes is None or bool(lanes)))
@@ -596,12 +598,17 @@ class Engine:
                        C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
             self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H,
                      rpg, kind="colstats", nbytes=M * H * esz)
-        self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
-                 _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
+        fold = blk["grn_fold"] = (rs_n == "fused" and G == 1 and self.grn_fold
+                                  and Cc >= int(os.environ.get("MPMAE_GRN_FOLD_MINC", "0")))
+        if not fold:
+            self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
+                     _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
         if rs_n == "fused":   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
+            fin = dict(fin_sum=blk["G2"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"], fin_ainv=blk["Ainv"],
+                       fin_out=blk["scale"], fin_eps=eps) if fold else {}   # GRN finalisation folded into the prologue
             self._rs(lst, tag + ":grn.apply+pw2", 4, blk, (2 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["h"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
-                     v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0)
+                     v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0, **fin)
             return blk["out"]
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                  _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
@@ -643,8 +650,10 @@ class Engine:
         if not blk["sparse"] and not self.grouped_epi:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
-        self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
-                 _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
+        fold = blk.get("grn_fold", False)
+        if not fold:
+            self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
+                     _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
         rsc = rs_n == "fused"
         if not rsc:
             self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
@@ -653,7 +662,10 @@ class Engine:
             self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, (3 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H,
                      A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
                      xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act, s0=Gd[nm["ln_w"]],
-                     s1=Gd[nm["ln_b"]], rpg=0)
+                     s1=Gd[nm["ln_b"]], rpg=0,
+                     **(dict(fin_sum=blk["S1"], fin_sum0=blk["S0"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"],
+                             fin_ainv=blk["Ainv"], fin_out=blk["coef"], fin_dgamma=Gd[nm["gg"]],
+                             fin_dbeta=Gd[nm["gb"]]) if fold else {}))
         elif rs_n == "plain":   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
             self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
                      W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
