@@ -243,10 +243,13 @@ class Engine:
         self.scr_dz2 = [self._t(maxMH), self._t(maxMH)]   # dz / dh, alternating per block (side lane reads dh)
         self.scr_dz = self.scr_dz2[0]
         self.scr_dxn = self._t(maxMC)
-        self.scr_dd2 = [self._t(maxMC), self._t(maxMC)]   # dd, alternating per block (side lane reads it)
+        self.ring = int(os.environ.get("MPMAE_RING", "3"))      # depth of the dd / dx rings (2 = ping-pong)
+        self.scr_dd2 = [self._t(maxMC) for _ in range(self.ring)]   # dd, one per block in turn (side lane reads it)
         self.scr_dd = self.scr_dd2[0]
-        self.scr_dxA = self._t(maxMC)
-        self.scr_dxB = self._t(maxMC)
+        # dx ring: a block's dout is still read by its pw2 weight gradient (side lane) while later blocks run; with
+        # a ping-pong the data gradient two blocks on had to wait for it (20-60 us main-lane stalls in the timeline)
+        self.scr_dx = [self._t(maxMC) for _ in range(self.ring)]
+        self.scr_dxA, self.scr_dxB = self.scr_dx[0], self.scr_dx[1]
         self.dy = self._t(N * L, D)
         # fp32 scratch for the two-stage reductions (per-block / per-split partial slabs)
         self.ws_floats = 32 * 1024 * 1024
@@ -632,7 +635,7 @@ class Engine:
         t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1      # dz / dd alternate per block: the side lane reads them
         dz = self.scr_dz2[t & 1][:M * H]
         dxn = self.scr_dxn[:M * Cc]
-        dd = self.scr_dd2[t & 1][:M * Cc]
+        dd = self.scr_dd2[t % len(self.scr_dd2)][:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
         rs, rs_n = blk.get("rs", False), blk.get("rs_n")
         if rs:
@@ -1051,14 +1054,16 @@ class Engine:
         self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
                    ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
         self._guard(b, cur)
-        other = self.scr_dxA
+        ring, ri = self.scr_dx, 2 % len(self.scr_dx)      # dxdec = ring[0], cur = ring[1]
+        other = ring[ri]
         bi = len(self.blocks) - 1
         for i in range(3, -1, -1):
             for j in range(cfg.depths[i] - 1, -1, -1):
                 blk = self.blocks[bi]
                 nxt = other[:blk["M"] * blk["C"]]
                 self._block_bwd(b, blk, cur, nxt)
-                other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
+                ri = (ri + 1) % len(ring)
+                other = ring[ri]
                 cur = nxt
                 bi -= 1
             if i > 0:
@@ -1089,7 +1094,8 @@ class Engine:
                              _p(P[pre + ".0.ln.weight"]), _p(P[pre + ".0.ln.bias"]), 0, _p(nxt), 0,
                              _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]), self.M[i - 1], Ci, _p(self.act[i - 1]))
                 self._guard(b, nxt)
-                other = self.scr_dxB if other is self.scr_dxA else self.scr_dxA
+                ri = (ri + 1) % len(ring)
+                other = ring[ri]
                 cur = nxt
         # stem
         C0, k = dims[0], cfg.stem_k
