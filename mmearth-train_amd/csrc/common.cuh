@@ -201,10 +201,15 @@ __device__ __forceinline__ float sum16(float v) {
   return v;
 }
 
+// sum over the 64 lanes (every lane active), result in every lane: the DPP row sum, then the four row results through
+// v_readlane (SGPRs) - 4 DPP adds + 4 readlanes + 3 adds instead of 6 dependent ds_bpermute round trips
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  const int r = __builtin_bit_cast(int, sum16(v));
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(r, 48));
+  return (a + b) + (c + d);
 }
 
 // ---------------------------------------------------------------------------------
