@@ -738,6 +738,25 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
   static int bk32 = -1;
   if (bk32 < 0) { const char* e = getenv("MPMAE_NT_BK32"); bk32 = e ? atoi(e) : 1; }
+  static int glds = -1;
+  if (glds < 0) { const char* e = getenv("MPMAE_NT_GLDS"); glds = e ? atoi(e) : 1; }
+  if (glds && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K % 64 == 0) {
+    // direct global -> LDS slabs, swizzled unpadded rows
+    if (glds == 2 || a.K <= 512) {
+      const size_t l = (size_t)(2 * FBM * 32 + 2 * BN * 32) * sizeof(bf16_t);
+      const size_t need = l > (size_t)128 * 68 * 4 ? l : (size_t)128 * 68 * 4;
+      LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 32, true>), g, dim3(256), need, st, a);
+    } else {
+      const size_t l = (size_t)(2 * FBM * 64 + 2 * BN * 64) * sizeof(bf16_t);
+      static bool once = false;
+      if (!once && l > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<BN, EPI_STORE, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) return (int)hipGetLastError();
+        once = true;
+      }
+      LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 64, true>), g, dim3(256), l, st, a);
+    }
+    return (int)hipGetLastError();
+  }
   if (bk32 && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K <= 512) {
     // short K, wide N (decoder pw1 / pw2.dgrad, pixel heads): half-depth K slabs, 41 KB of LDS instead of 74 KB ->
     // 3-4 workgroups per CU (measured 84 -> 67, 72 -> 58, 85 -> 77 us; for K = 2048 the 64-deep slabs stay faster)

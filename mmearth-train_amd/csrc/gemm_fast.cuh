@@ -29,9 +29,18 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 // EPI: EPI_STORE (bias, optional residual R, row mask) | EPI_GELU_SUMSQ (store h, per-block column
 // partials of gelu(h)^2 -> ws[blockIdx.x][N]) | EPI_DZ_STATS (store dz, partials of dz and
 // dz*gelu(R) -> ws[blockIdx.x][N], ws[gridDim.x + blockIdx.x][N]); statistics: single group only.
-template <int BN, int EPI, int BK = FBK>
+// GLDS: the operand slabs go global -> LDS directly (global_load_lds_dwordx4: no staging VGPRs, no ds_write pass). The LDS
+// image of such a load is lane-linear (wave-uniform base + 16 B x lane), so rows cannot be padded; bank conflicts of the
+// fragment reads are removed by an XOR swizzle of the 16-byte chunk index instead, applied to the per-lane SOURCE address
+// and again on the read: chunk ^ (row & 7) for 128-byte rows, chunk ^ ((row >> 1) & 3) for 64-byte rows (both conflict-free
+// under the ds_read_b128 lane grouping of the microarchitecture guide). Needs K % BK == 0 (no zero fill); rows / columns
+// beyond M / N are clamped (their products are never stored).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN, int EPI, int BK = FBK, bool GLDS = false>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
-  constexpr int LDK = BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
+  constexpr int LDK = GLDS ? BK : BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
   using T = bf16_t;
   constexpr int NJ = BN / 32;                 // 16-wide N tiles per wave (wave tile 64 x BN/2)
   constexpr int BCH = BN * CPR / 256;           // 16-byte chunks of the B tile per thread
@@ -82,6 +91,49 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
   };
 
   const int nk = (p.K + BK - 1) / BK;
+  if constexpr (GLDS) {
+    static_assert(BK == 64 || BK == 32, "swizzle table");
+    auto swz = [](int row) { return BK == 64 ? (row & 7) : ((row >> 1) & 3); };
+    auto dma = [&](int buf, int k0) {
+#pragma unroll
+      for (int i = 0; i < ACH; ++i) {
+        const int sl = i * 256 + tid, row = sl / CPR, ch = (sl % CPR) ^ swz(row);
+        const bf16_t* src = A + (size_t)min(m0 + row, p.M - 1) * p.lda + k0 + ch * 8;
+        bf16_t* dst = As + buf * FBM * LDK + (i * 256 + wave * 64) * 8;            // wave-uniform; lane l lands at + 8 l
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < BCH; ++i) {
+        const int sl = i * 256 + tid, row = sl / CPR, ch = (sl % CPR) ^ swz(row);
+        const bf16_t* src = B + (size_t)min(n0 + row, p.N - 1) * p.ldb + k0 + ch * 8;
+        bf16_t* dst = Bs + buf * BN * LDK + (i * 256 + wave * 64) * 8;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+      }
+    };
+    const int sw = swz(lr);                 // every fragment row of this lane is lr (mod 16)
+    dma(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) dma((kt + 1) & 1, (kt + 1) * BK);
+      const bf16_t* a = As + (kt & 1) * FBM * LDK + (wm * 64 + lr) * LDK;
+      const bf16_t* b = Bs + (kt & 1) * BN * LDK + (wn * (BN / 2) + lr) * LDK;
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 32) {
+        const int co = (((ks >> 3) + lg) ^ sw) * 8;
+        bf16x8_t af[4], bfr[NJ];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * LDK + co));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * LDK + co));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();                      // carries the vmcnt(0) that retires the slab just requested
+    }
+  } else {
   gload(0);
   lstore(0);
   __syncthreads();
@@ -104,6 +156,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
     }
     if (kt + 1 < nk) lstore((kt + 1) & 1);
     __syncthreads();
+  }
   }
 
   // ---- epilogue: registers -> LDS (fp32, 64 columns at a time) -> 16-byte global stores ----
