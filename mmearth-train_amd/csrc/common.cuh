@@ -132,13 +132,13 @@ __device__ __forceinline__ f32x2_t gelu2_fwd(f32x2_t x) {
   f32x2_t t, r;
   // v_med3_f32 with an |x| source modifier; a finite upper bound keeps hipcc from rewriting it as canonicalise + max
   t.x = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.x), 0.f, 4.5f); t.y = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.y), 0.f, 4.5f);
-  r.x = __builtin_amdgcn_fmed3f(x.x, 0.f, 3.0e38f); r.y = __builtin_amdgcn_fmed3f(x.y, 0.f, 3.0e38f);
+  r.x = __builtin_amdgcn_fmed3f(x.x, 0.f, 3.4028234e38f); r.y = __builtin_amdgcn_fmed3f(x.y, 0.f, 3.4028234e38f);
   return r - t * gelu2_bump(t);
 }
 __device__ __forceinline__ void gelu2_both(f32x2_t x, f32x2_t& g, f32x2_t& dg) {
   f32x2_t t, r, xc;
   t.x = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.x), 0.f, 4.5f); t.y = __builtin_amdgcn_fmed3f(__builtin_fabsf(x.y), 0.f, 4.5f);
-  r.x = __builtin_amdgcn_fmed3f(x.x, 0.f, 3.0e38f); r.y = __builtin_amdgcn_fmed3f(x.y, 0.f, 3.0e38f);
+  r.x = __builtin_amdgcn_fmed3f(x.x, 0.f, 3.4028234e38f); r.y = __builtin_amdgcn_fmed3f(x.y, 0.f, 3.4028234e38f);
   xc.x = __builtin_amdgcn_fmed3f(x.x, -4.5f, 4.5f); xc.y = __builtin_amdgcn_fmed3f(x.y, -4.5f, 4.5f);
   g = r - t * gelu2_bump(t);
   f32x2_t q = (f32x2_t)(1.184819193e-04f);

@@ -227,3 +227,110 @@ def test_grouped_layernorm_feeds_the_downsample_gemm():
     dy = dyg.view(NK, S // 2, S // 2, 2, 2, Cc).permute(0, 1, 4, 2, 3, 5).reshape(M, Cc)       # back to row order
     yr.backward(dy)
     assert _rel(dx, xr.grad * live) < 1e-4 and _rel(dg, gr.grad) < 1e-4 and _rel(db, br.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M,Cc", [(1000, 40), (333, 80), (1216, 160)])
+def test_folded_grn_finalisation_equals_the_separate_launches(M, Cc):
+    """mpmae_rs which = 4 / 5 with fin_* set (GRN finalisation recomputed in the kernel prologue) against
+    mpmae_grn_fwd_finalize / mpmae_grn_bwd_finalize followed by the same kernel: same arithmetic in the same
+    order, so stored tensors must agree bit for bit and the published vectors to fp32 round-off."""
+    L, lib = _lib()
+    dev, H = "cuda", 4 * Cc
+    torch.manual_seed(3 * M + Cc)
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    P = lambda t: C.c_void_p(t.data_ptr())
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    h = torch.randn(M, H, device=dev).to(bf)
+    x = torch.randn(M, Cc, device=dev).to(bf)
+    W2 = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    b2 = torch.randn(Cc, device=dev) * 0.1
+    G2 = (torch.rand(H, device=dev) + 0.1) * M
+    gamma = torch.randn(H, device=dev) * 0.5
+    gbeta = torch.randn(H, device=dev) * 0.1
+    eps = 1e-6
+    # ---- forward: separate finalize, then the kernel on its outputs
+    Gx, Ainv, scale = torch.empty(H, device=dev), torch.empty(1, device=dev), torch.empty(H, device=dev)
+    assert lib.mpmae_grn_fwd_finalize(P(G2), P(gamma), eps, 1, H, P(Gx), P(Ainv), P(scale), _st()) == 0
+    z0, out0 = torch.empty(M, H, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf)
+    assert lib.mpmae_rs(4, C.byref(args(A=h, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=out0, xn=z0, R=x, act=act)), _st()) == 0
+    Gx1, Ainv1, scale1 = torch.zeros(H, device=dev), torch.zeros(1, device=dev), torch.zeros(H, device=dev)
+    z1, out1 = torch.empty_like(z0), torch.empty_like(out0)
+    assert lib.mpmae_rs(4, C.byref(args(A=h, W=W2, ldw=H, bias=b2, v1=gbeta, out=out1, xn=z1, R=x, act=act, fin_sum=G2,
+                                        fin_gamma=gamma, fin_gx=Gx1, fin_ainv=Ainv1, fin_out=scale1, fin_eps=eps)), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(z0, z1) and torch.equal(out0, out1)
+    assert torch.equal(Gx, Gx1) and torch.equal(Ainv, Ainv1) and torch.equal(scale, scale1)
+    # ---- backward
+    dz = torch.randn(M, H, device=dev).to(bf)
+    S0, S1 = torch.randn(H, device=dev) * M ** 0.5, torch.randn(H, device=dev) * M ** 0.5
+    W1T = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    xhat = torch.randn(M, Cc, device=dev).to(bf)
+    rstd = torch.rand(M, device=dev) + 0.5
+    lng = torch.rand(Cc, device=dev) + 0.5
+    coef, dgam, dbet = torch.empty(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    assert lib.mpmae_grn_bwd_finalize(P(S0), P(S1), P(Gx), P(Ainv), P(gamma), 1, H, P(coef), P(dgam), P(dbet), _st()) == 0
+    dza, dd0 = dz.clone(), torch.empty(M, Cc, device=dev, dtype=bf)
+    g0, gb0 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    assert lib.mpmae_rs(5, C.byref(args(A=dza, A2=h, W=W1T, ldw=H, v0=scale, v1=coef, out=dd0, xhat=xhat, rstd=rstd, lng=lng,
+                                        act=act, s0=g0, s1=gb0)), _st()) == 0
+    dzb, dd1 = dz.clone(), torch.empty_like(dd0)
+    g1, gb1 = torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev)
+    coef1, dgam1, dbet1 = torch.zeros(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    assert lib.mpmae_rs(5, C.byref(args(A=dzb, A2=h, W=W1T, ldw=H, v0=scale, out=dd1, xhat=xhat, rstd=rstd, lng=lng, act=act,
+                                        s0=g1, s1=gb1, fin_sum=S1, fin_sum0=S0, fin_gamma=gamma, fin_gx=Gx, fin_ainv=Ainv,
+                                        fin_out=coef1, fin_dgamma=dgam1, fin_dbeta=dbet1)), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dza, dzb) and torch.equal(dd0, dd1)
+    assert torch.equal(coef, coef1) and torch.equal(dgam, dgam1) and torch.equal(dbet, dbet1)
+    assert _rel(g0, g1) < 1e-6 and _rel(gb0, gb1) < 1e-6
+
+
+def test_polynomial_gelu_over_every_bf16_input():
+    """The bf16 path's transcendental-free GELU (common.cuh gelu2_fwd) through mpmae_grn_apply with scale 1, beta 0,
+    on all 65536 bf16 bit patterns: |error| <= 3.1e-5 before the bf16 rounding of the result (tools/gelu_fit.py)."""
+    L, lib = _lib()
+    dev = "cuda"
+    bits = torch.arange(65536, dtype=torch.int32, device=dev).to(torch.int16)
+    h = bits.view(bf).reshape(64, 1024).contiguous()
+    z = torch.empty_like(h)
+    scale, beta = torch.ones(1024, device=dev), torch.zeros(1024, device=dev)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.mpmae_grn_apply(1, P(h), P(z), P(scale), P(beta), 64, 1024, 64, None, _st()) == 0
+    torch.cuda.synchronize()
+    x = h.double().flatten()
+    fin = torch.isfinite(x)
+    ref = (0.5 * x * (1 + torch.erf(x / math.sqrt(2))))[fin]
+    got = z.double().flatten()[fin]
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    assert (err <= ref.abs() * 2.0 ** -8 + 4e-5).all(), float((err - ref.abs() * 2.0 ** -8).max())
+
+
+@pytest.mark.parametrize("M,N,K,resid", [(4200, 512, 2048, True), (4100, 384, 512, False), (5000, 256, 64, False)])
+def test_direct_to_lds_gemm_matches_torch(M, N, K, resid):
+    """mpmae_gemm bf16 NT with K % 64 == 0 and M >= 4096 takes the global_load_lds path (swizzled unpadded LDS rows,
+    ragged last row tile clamped): compare with an fp32 matmul of the same bf16 operands."""
+    L, lib = _lib()
+    dev = "cuda"
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev).to(bf)
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
+    bias = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev).to(bf)
+    c = torch.empty(M, N, device=dev, dtype=bf)
+    g = L.GemmArgs()
+    g.A, g.B, g.bias, g.C = a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
+    if resid:
+        g.R, g.ldr = r.data_ptr(), N
+    assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+    ref = a.float() @ w.float().t() + bias + (r.float() if resid else 0)
+    assert _rel(c, ref) < 6e-3
