@@ -472,7 +472,7 @@ class Engine:
         2/3 on materialised z / dh) or "fused" (which 4/5, GRN application and its backward in the operand
         prologue). Measured on MI355X at bs 256: fused wins for C <= 160; at C = 320 (M = 4864 rows, 76
         workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
-        if not self._rs_ok(blk):
+        if not self._rs_ok(blk) or blk["C"] > int(os.environ.get("MPMAE_RS_MAXC", "100000")):
             return False, None
         if self._rsc_ok(blk):
             return True, ("fused" if blk["C"] <= 160 else None)
