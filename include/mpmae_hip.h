@@ -156,6 +156,10 @@ typedef struct MpmaeRsArgs {
   const float* fin_sum; const float* fin_sum0; const float* fin_gamma;
   float* fin_gx; float* fin_ainv; float* fin_out; float* fin_dgamma; float* fin_dbeta;
   float fin_eps;
+  /* Optional (C = 40 / 80, single GRN group): dz never materialised. which = 1 with out == NULL only produces the
+   * statistics; which = 5 with dz_dout / dz_w2t set recomputes dz = dout W2 chunk by chunk instead of reading A
+   * (A is then only the destination of dh): dz_dout = dout [M,C], dz_w2t = staged W2^T [H][dz_ldw2]. */
+  const void* dz_dout; const void* dz_w2t; int dz_ldw2;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
             cs1[e] += o[e] * gh[e];
           }
         }
-        if (row < p.M) st8<T>(p.out + (size_t)row * HN + n8, o);
+        if (row < p.M && (MODE == 0 || p.out)) st8<T>(p.out + (size_t)row * HN + n8, o);      // MODE 1 without `out`: statistics only
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 // per chunk, and (p.fin_sum != nullptr) the GRN finalisation itself runs here: every workgroup recomputes the H-vector
 // from the column sums (one block reduction) while its first operand loads are in flight, workgroup 0 publishes it -
 // two launches fewer per block and direction on the main lane. Needs a single GRN group (rpg >= M).
+// PF bit 2 (MODE 1, HBM-bound stages C = 40 / 80): dz is not READ but recomputed, dz = dout W2 for this chunk's columns
+// (p.D rows in registers for the whole kernel, W2^T chunk [KCH][C] through LDS): with the tile-pair row interleave the
+// transposed MFMA leaves 8 consecutive dz columns of row lr in exactly the lane that needs them as the next MFMA's
+// operand, so pw2.dgrad (which = 1) only has to produce the GRN statistics and never stores dz: -105 MB written and
+// -79 MB read per stage-0 block on kernels that run at the HBM roofline.
 template <int KC, int MODE, int RT, int KCH, int PF = 0>
 __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
   using T = bf16_t;
@@ -251,8 +256,28 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
   constexpr int nkc = HN / KCH;
-  constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0;
+  constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0, DZR = (PF & 4) != 0 && MODE == 1;
+  static_assert(!DZR || (STG && !EARLY), "dz recomputation: staged vectors, no early issue");
+  constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8, WV2 = (KCH * VPR2 + 255) / 256;
+  bf16_t* W2c = reinterpret_cast<bf16_t*>(vec + 2 * HN + 8);                          // [2][KCH][LDW2] (DZR): W2^T rows of the chunk
   if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
+
+  uint4 wr2[DZR ? WV2 : 1];
+  auto wload2 = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < WV2; ++i) {
+      const int v = tid + 256 * i, n = v / VPR2, k = (v - n * VPR2) * 8;
+      wr2[i] = (v < KCH * VPR2 && k < KC) ? *reinterpret_cast<const uint4*>(p.W2 + (size_t)(kc * KCH + n) * p.ldw2 + k)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto wstore2 = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WV2; ++i) {
+      const int v = tid + 256 * i, n = v / VPR2, k = (v - n * VPR2) * 8;
+      if (v < KCH * VPR2) *reinterpret_cast<uint4*>(W2c + (size_t)buf * KCH * LDW2 + n * LDW2 + k) = wr2[i];
+    }
+  };
 
   uint4 wr[WV];
   auto wload = [&](int kc) {
@@ -290,7 +315,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
         const size_t off = (size_t)rowv[rt] * HN + kc * KCH + s * 32 + lg * 8;
-        araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (!DZR) araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
         if (MODE == 1) hraw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
       }
   };
@@ -300,10 +325,22 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[rt][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  bf16x8_t df[DZR ? RT : 1][DZR ? KS2 : 1];        // dout rows of this wave as MFMA operand fragments (whole C extent)
+  if (DZR) {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) {
+        const int k = s2 * 32 + lg * 8;
+        const uint4 v = (inb[rt] && k < KC) ? *reinterpret_cast<const uint4*>(p.D + (size_t)rowv[rt] * KC + k) : make_uint4(0u, 0u, 0u, 0u);
+        df[rt][s2] = __builtin_bit_cast(bf16x8_t, v);
+      }
+  }
 
   auto step = [&](auto bsel, int kc) {
     constexpr int B = decltype(bsel)::value;
     if (EARLY && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, EARLY ? (B ^ 1) : 0>{}, kc + 1); }
+    const bf16_t* w2b = W2c + (size_t)(kc & 1) * KCH * LDW2;
     // ---- prologue on this chunk's activation fragments (registers), results stored once
     bf16x8_t af[RT][KSC];
 #pragma unroll
@@ -318,7 +355,23 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
         const float tc[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         float a[8], z[8];
-        unpack8(araw[B][rt][s], a);
+        if (DZR) {       // dz[row lr][kc*KCH + s*32 + lg*8 + e], e = t*4 + r, from the tile pair (t = 0, 1) of this 32-column group
+          f32x4_t d2[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            d2[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < KS2; ++s2) {
+              const bf16x8_t wf2 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(
+                  w2b + (s * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * LDW2 + s2 * 32 + lg * 8));
+              d2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, df[rt][s2], d2[t], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(d2[e >> 2][e & 3]));       // dz as the unfused path stored it
+        } else {
+          unpack8(araw[B][rt][s], a);
+        }
         if (MODE == 0) {
           float ga[8];
           gelu_n<T, 8>(a, ga);
@@ -337,7 +390,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
           if (dst) *reinterpret_cast<uint4*>(dst + (size_t)rowv[rt] * HN + k) = __builtin_bit_cast(uint4, af[rt][s]);
         }
       }
-    if (!EARLY && kc + 1 < nkc) { wload(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
+    if (!EARLY && kc + 1 < nkc) { wload(kc + 1); if (DZR) wload2(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
     const bf16_t* wb = Wc + (size_t)(kc & 1) * NP * LDW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -351,11 +404,12 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         for (int s = 0; s < KSC; ++s)
           acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[rt][s], acc[rt][j], 0, 0, 0);
     }
-    if (kc + 1 < nkc) wstore((kc + 1) & 1);
+    if (kc + 1 < nkc) { wstore((kc + 1) & 1); if (DZR) wstore2((kc + 1) & 1); }
     __syncthreads();
   };
 
   wload(0);
+  if (DZR) wload2(0);
   aload(std::integral_constant<int, 0>{}, 0);
   if (STG) {
     float* fsh = vec + 2 * HN;                      // [4] block-reduction scratch
@@ -403,6 +457,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     }
   }
   wstore(0);
+  if (DZR) wstore2(0);
   __syncthreads();
   if (EARLY) {
 #pragma unroll 1

@@ -61,6 +61,7 @@ class Engine:
         self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
         # GRN finalisation recomputed in the prologue of the fused kernels (no separate launches on the main lane)
         self.grn_fold = os.environ.get("MPMAE_GRN_FOLD", "1") != "0" and os.environ.get("MPMAE_RSC_PF", "1") != "0"
+        self.dz_recompute = os.environ.get("MPMAE_DZR", "1") != "0"
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
         self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
                            and (lanes is None or bool(lanes)))
@@ -638,9 +639,13 @@ class Engine:
         dd = self.scr_dd2[t % len(self.scr_dd2)][:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
         rs, rs_n = blk.get("rs", False), blk.get("rs_n")
+        # HBM-bound stages: dz is never materialised - pw2.dgrad only produces the GRN statistics and the fused
+        # pw1.dgrad kernel recomputes dz = dout W2 chunk by chunk (MpmaeRsArgs.dz_*)
+        dzr = (rs and rs_n == "fused" and Cc <= int(os.environ.get("MPMAE_DZR_MAXC", "80")) and blk.get("grn_fold", False)
+               and self.dz_recompute)
         if rs:
-            self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + 2 * M * H) * esz, 2 * M * Cc * H, A=dout, W=w2t["t"],
-                     ldw=w2t["ld"], out=dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
+            self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + (1 if dzr else 2) * M * H) * esz, 2 * M * Cc * H, A=dout,
+                     W=w2t["t"], ldw=w2t["ld"], out=None if dzr else dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
         elif blk["sparse"] or self.grouped_epi:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
                        K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
@@ -662,10 +667,12 @@ class Engine:
             self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
                      _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
         if rsc:  # dh (written over dz) in the operand prologue, pwconv1 data gradient, LayerNorm backward
-            self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, (3 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H,
+            dzkw = dict(dz_dout=dout, dz_w2t=w2t["t"], dz_ldw2=w2t["ld"]) if dzr else {}
+            self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, ((2 if dzr else 3) * M * H + (3 if dzr else 2) * M * Cc) * esz,
+                     (4 if dzr else 2) * M * Cc * H,
                      A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
                      xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act, s0=Gd[nm["ln_w"]],
-                     s1=Gd[nm["ln_b"]], rpg=0,
+                     s1=Gd[nm["ln_b"]], rpg=0, **dzkw,
                      **(dict(fin_sum=blk["S1"], fin_sum0=blk["S0"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"],
                              fin_ainv=blk["Ainv"], fin_out=blk["coef"], fin_dgamma=Gd[nm["gg"]],
                              fin_dbeta=Gd[nm["gb"]]) if fold else {}))

@@ -334,3 +334,50 @@ def test_direct_to_lds_gemm_matches_torch(M, N, K, resid):
     assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
     ref = a.float() @ w.float().t() + bias + (r.float() if resid else 0)
     assert _rel(c, ref) < 6e-3
+
+
+@pytest.mark.parametrize("M,Cc", [(1000, 40), (333, 80)])
+def test_dz_recomputation_matches_the_materialised_path(M, Cc):
+    """mpmae_rs which = 1 with out == NULL (statistics only) and which = 5 with dz_dout / dz_w2t (dz = dout W2 recomputed
+    chunk by chunk, never read) against the pair that stores and re-reads dz. Same MFMA operands and order, so dz is
+    identical; dh / dd may differ by a bf16 ulp where the two instantiations contract an fma differently."""
+    L, lib = _lib()
+    dev, H = "cuda", 4 * Cc
+    torch.manual_seed(7 * M + Cc)
+    ws = torch.empty(8 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    live = act.bool()[:, None]
+    h = torch.randn(M, H, device=dev).to(bf)
+    dout = (torch.randn(M, Cc, device=dev) * 0.1).to(bf) * live
+    W2T = (torch.randn(H, Cc, device=dev) / math.sqrt(H)).to(bf)
+    W1T = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    scale, coef = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.05
+    xhat = torch.randn(M, Cc, device=dev).to(bf)
+    rstd, lng = torch.rand(M, device=dev) + 0.5, torch.rand(Cc, device=dev) + 0.5
+    dz = torch.empty(M, H, device=dev, dtype=bf)
+    s0, s1, u0, u1 = (torch.zeros(H, device=dev) for _ in range(4))
+    assert lib.mpmae_rs(1, C.byref(args(A=dout, W=W2T, ldw=Cc, out=dz, R=h, s0=s0, s1=s1)), _st()) == 0
+    assert lib.mpmae_rs(1, C.byref(args(A=dout, W=W2T, ldw=Cc, out=None, R=h, s0=u0, s1=u1)), _st()) == 0
+    dd0, dd1 = torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf)
+    g0, g1 = torch.zeros(2 * Cc, device=dev), torch.zeros(2 * Cc, device=dev)
+    dh0, dh1 = dz.clone(), torch.empty_like(dz)
+    assert lib.mpmae_rs(5, C.byref(args(A=dh0, A2=h, W=W1T, ldw=H, v0=scale, v1=coef, out=dd0, xhat=xhat, rstd=rstd, lng=lng,
+                                        act=act, s0=g0, s1=g0[Cc:])), _st()) == 0
+    assert lib.mpmae_rs(5, C.byref(args(A=dh1, A2=h, W=W1T, ldw=H, v0=scale, v1=coef, out=dd1, xhat=xhat, rstd=rstd, lng=lng,
+                                        act=act, s0=g1, s1=g1[Cc:], dz_dout=dout, dz_w2t=W2T, dz_ldw2=Cc)), _st()) == 0
+    torch.cuda.synchronize()
+    assert _rel(u0, s0) < 1e-5 and _rel(u1, s1) < 1e-5
+    assert _rel(dh1, dh0) < 5e-3 and (dh1 != dh0).float().mean().item() < 1e-3
+    assert _rel(dd1, dd0) < 1e-2 and _rel(g1, g0) < 1e-3
+    # and against plain torch on the same bf16 operands
+    hf, r_dz = h.float(), (dout.float() @ W2T.float().t()).to(bf)
+    r_dh = ((r_dz.float() * scale + coef * _gelu(hf)) * _dgelu(hf)).to(bf)
+    assert _rel(dh1, r_dh) < 1.5e-2

@@ -90,12 +90,29 @@ def run(M, Cc, timing):
     r_dd = ((rstd[:, None] * (gq - gq.mean(1, keepdim=True) - xh * (gq * xh).mean(1, keepdim=True))) * live).to(bf)
     out["5:dh"] = rel(dzc, r_dh); out["5:dd"] = rel(dd, r_dd)
     out["5:dgamma"] = rel(gbuf[:Cc], (r_dxn * xh).sum(0)); out["5:dbeta"] = rel(gbuf[Cc:], r_dxn.sum(0))
+    extra = []
+    if Cc <= 80:        # dz never materialised: which 1 statistics only, which 5 recomputes dz = dout W2
+        u0 = torch.zeros(H, device=dev); u1 = torch.zeros(H, device=dev)
+        a1n = args(M, Cc, H, A=dout, W=W2T, ldw=Cc, out=None, R=h, s0=u0, s1=u1)
+        assert lib.mpmae_rs(1, C.byref(a1n), st) == 0
+        dhb = torch.empty(M, H, device=dev, dtype=bf); dd2 = torch.empty(M, Cc, device=dev, dtype=bf)
+        gbuf2 = torch.zeros(2 * Cc, device=dev)
+        a5n = args(M, Cc, H, A=dhb, A2=h, W=W1T, ldw=H, v0=scale, v1=coef, out=dd2, xhat=xhat, rstd=rstd, lng=lnw, act=act,
+                   s0=gbuf2, s1=gbuf2[Cc:], rpg=0, dz_dout=dout, dz_w2t=W2T, dz_ldw2=Cc)
+        assert lib.mpmae_rs(5, C.byref(a5n), st) == 0
+        torch.cuda.synchronize()
+        out["1n:s0"] = rel(u0, t0); out["1n:s1"] = rel(u1, t1)
+        out["5n:dh-5:dh"] = rel(dhb, dzc); out["5n:dd-5:dd"] = rel(dd2, dd)
+        out["5n:ndiff"] = float((dhb != dzc).sum().item())
+        extra = [("1 (no dz store)", 1, a1n), ("5 (dz recomputed)", 5, a5n)]
     torch.cuda.synchronize()
     msg = "  ".join(f"{k} {v:.1e}" for k, v in out.items())
     print(f"M={M} C={Cc}: {msg}")
     if timing:
         for w, a in ((0, a0), (4, a4), (1, a1), (5, a5)):
             print(f"    which {w}: {timeit(lambda: lib.mpmae_rs(w, C.byref(a), st)):7.1f} us")
+        for nm_, w, a in extra:
+            print(f"    which {nm_}: {timeit(lambda: lib.mpmae_rs(w, C.byref(a), st)):7.1f} us")
 
 
 cases = [(1000, 160, False), (76, 160, False), (19456, 160, True), (304, 320, False), (4864, 320, True),
