@@ -156,10 +156,12 @@ typedef struct MpmaeRsArgs {
   const float* fin_sum; const float* fin_sum0; const float* fin_gamma;
   float* fin_gx; float* fin_ainv; float* fin_out; float* fin_dgamma; float* fin_dbeta;
   float fin_eps;
-  /* Optional (C = 40 / 80, single GRN group): dz never materialised. which = 1 with out == NULL only produces the
-   * statistics; which = 5 with dz_dout / dz_w2t set recomputes dz = dout W2 chunk by chunk instead of reading A
-   * (A is then only the destination of dh): dz_dout = dout [M,C], dz_w2t = staged W2^T [H][dz_ldw2]. */
-  const void* dz_dout; const void* dz_w2t; int dz_ldw2;
+  /* Optional (C = 40 / 80, single GRN group): the wide tensors never materialised. which = 0 / 1 with out == NULL only
+   * produce the statistics (which 0 still writes x-hat, xn, rstd). which = 5 with dz_dout / dz_w2t set recomputes
+   * dz = dout W2 chunk by chunk instead of reading A (A is then only the destination of dh): dz_dout = dout [M,C],
+   * dz_w2t = staged W2^T [H][dz_ldw2]. which = 4 with the same fields recomputes h = xn W1^T + b1 instead of reading A:
+   * dz_dout = xn [M,C], dz_w2t = staged W1 [H][dz_ldw2], dz_bias = b1 [H]. */
+  const void* dz_dout; const void* dz_w2t; int dz_ldw2; const float* dz_bias;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 

@@ -102,7 +102,7 @@ class RsArgs(C.Structure):
                 ("rpg", c_int),
                 ("fin_sum", c_void_p), ("fin_sum0", c_void_p), ("fin_gamma", c_void_p), ("fin_gx", c_void_p),
                 ("fin_ainv", c_void_p), ("fin_out", c_void_p), ("fin_dgamma", c_void_p), ("fin_dbeta", c_void_p),
-                ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int)]
+                ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p)]
 
 
 class StemTailArgs(C.Structure):

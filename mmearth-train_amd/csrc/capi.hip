@@ -963,9 +963,9 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
   p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
   p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
-  p.fin_sum = nullptr; p.D = nullptr; p.W2 = nullptr; p.ldw2 = 0;
+  p.fin_sum = nullptr; p.D = nullptr; p.W2 = nullptr; p.ldw2 = 0; p.hb = nullptr;
   if (a.fin_sum || a.dz_dout) return (int)hipErrorInvalidValue;      // folded GRN finalisation / dz recomputation: chunked kernels only
-  if (which == 1 && !a.out) return (int)hipErrorInvalidValue;
+  if (which < 2 && !a.out) return (int)hipErrorInvalidValue;
   const int ngroups = a.M / 16;
   if (which == 0 || which == 1) {
     constexpr int KS = (KC + 31) / 32, LDW = KS * 32 + 8, SLD = HN + 8;
@@ -1024,7 +1024,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
   p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
   p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
-  p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2;
+  p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
@@ -1065,7 +1065,8 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     constexpr int NP = ((KC + 15) / 16) * 16;
     static int pf_on = rsc_env("MPMAE_RSC_PF", 1);
     const bool pf = PFN && pf_on && rpg >= a.M;       // LDS-staged GRN vectors (+ early issue): single GRN group only
-    const bool dzr = which == 5 && a.dz_dout != nullptr;            // dz recomputed from dout (never read)
+    const bool dzr = a.dz_dout != nullptr;            // which 5: dz recomputed from dout; which 4: h recomputed from xn (never read)
+    if (dzr && which == 4 && (!a.dz_bias || ((uintptr_t)a.dz_bias & 15))) return (int)hipErrorInvalidValue;
     if (dzr && (!(PFN & 4) || !pf || !a.dz_w2t || (a.dz_ldw2 & 7) || (((uintptr_t)a.dz_dout | (uintptr_t)a.dz_w2t) & 15))) return (int)hipErrorInvalidValue;
     constexpr int KP2 = ((KC + 31) / 32) * 32;
     const size_t lds = (size_t)2 * NP * (KCH + RSC_PAD) * 2 + (size_t)2 * KC * 4 + (pf ? (size_t)2 * HN * 4 + 32 : 0) +
@@ -1082,7 +1083,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       static size_t cur = 64 * 1024; \
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
       LAUNCH((rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg); } while (0)
-    if (which == 4) { if (pf) RSC_NARROW(0, (PFN & 3)); else RSC_NARROW(0, 0); }
+    if (which == 4) { if (dzr) RSC_NARROW(0, (PFN & 4) ? (PFN & 6) : 0); else if (pf) RSC_NARROW(0, (PFN & 3)); else RSC_NARROW(0, 0); }
     else {
       if (dzr) RSC_NARROW(1, (PFN & 4) ? (PFN & 6) : 0);
       else if (pf) RSC_NARROW(1, (PFN & 3)); else RSC_NARROW(1, 0);

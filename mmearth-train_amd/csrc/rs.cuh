@@ -39,7 +39,8 @@ struct RsP {
   const float* fin_sum; const float* fin_sum0; const float* fin_gamma;
   float* fin_gx; float* fin_ainv; float* fin_out; float* fin_dgamma; float* fin_dbeta;
   float fin_eps;
-  const bf16_t* D; const bf16_t* W2; int ldw2;     // rsc_narrow MODE 1 with dz recomputation: dout [M][C], W2^T [H][ldw2]
+  const bf16_t* D; const bf16_t* W2; int ldw2;     // rsc_narrow with operand recomputation: dout / xn [M][C], W2^T / W1 [H][ldw2]
+  const float* hb;                                 // MODE 0: pwconv1 bias [H]
 };
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(const float (&v)[8]) {

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
             cs1[e] += o[e] * gh[e];
           }
         }
-        if (row < p.M && (MODE == 0 || p.out)) st8<T>(p.out + (size_t)row * HN + n8, o);      // MODE 1 without `out`: statistics only
+        if (row < p.M && p.out) st8<T>(p.out + (size_t)row * HN + n8, o);      // without `out`: statistics (and x-hat / xn) only
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -256,13 +256,14 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
   constexpr int nkc = HN / KCH;
-  constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0, DZR = (PF & 4) != 0 && MODE == 1;
-  static_assert(!DZR || (STG && !EARLY), "dz recomputation: staged vectors, no early issue");
+  // RC: the wide operand of this kernel is recomputed instead of read: MODE 1 dz = dout W2, MODE 0 h = xn W1^T + b1
+  constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0, RC = (PF & 4) != 0, DZR = RC && MODE == 1, HR = RC && MODE == 0;
+  static_assert(!RC || (STG && !EARLY), "operand recomputation: staged vectors, no early issue");
   constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8, WV2 = (KCH * VPR2 + 255) / 256;
   bf16_t* W2c = reinterpret_cast<bf16_t*>(vec + 2 * HN + 8);                          // [2][KCH][LDW2] (DZR): W2^T rows of the chunk
   if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
 
-  uint4 wr2[DZR ? WV2 : 1];
+  uint4 wr2[RC ? WV2 : 1];
   auto wload2 = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < WV2; ++i) {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
         const size_t off = (size_t)rowv[rt] * HN + kc * KCH + s * 32 + lg * 8;
-        if (!DZR) araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
+        if (!RC) araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
         if (MODE == 1) hraw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
       }
   };
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[rt][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  bf16x8_t df[DZR ? RT : 1][DZR ? KS2 : 1];        // dout rows of this wave as MFMA operand fragments (whole C extent)
-  if (DZR) {
+  bf16x8_t df[RC ? RT : 1][RC ? KS2 : 1];          // dout / xn rows of this wave as MFMA operand fragments (whole C extent)
+  if (RC) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
         const float tc[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
         float a[8], z[8];
-        if (DZR) {       // dz[row lr][kc*KCH + s*32 + lg*8 + e], e = t*4 + r, from the tile pair (t = 0, 1) of this 32-column group
+        if (RC) {        // dz / h [row lr][kc*KCH + s*32 + lg*8 + e], e = t*4 + r, from the tile pair (t = 0, 1) of this 32-column group
           f32x4_t d2[2];
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
@@ -368,7 +369,15 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
             }
           }
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(d2[e >> 2][e & 3]));       // dz as the unfused path stored it
+          for (int e = 0; e < 8; ++e) a[e] = d2[e >> 2][e & 3];
+          if (HR) {          // h = acc + b1 on live rows, as which = 0 stored it
+            const float4 ha = *reinterpret_cast<const float4*>(p.hb + k), hb4 = *reinterpret_cast<const float4*>(p.hb + k + 4);
+            const float hbv[8] = {ha.x, ha.y, ha.z, ha.w, hb4.x, hb4.y, hb4.z, hb4.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] = live[rt] ? a[e] + hbv[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(a[e]));                    // the value the unfused path stored
         } else {
           unpack8(araw[B][rt][s], a);
         }
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
           if (dst) *reinterpret_cast<uint4*>(dst + (size_t)rowv[rt] * HN + k) = __builtin_bit_cast(uint4, af[rt][s]);
         }
       }
-    if (!EARLY && kc + 1 < nkc) { wload(kc + 1); if (DZR) wload2(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
+    if (!EARLY && kc + 1 < nkc) { wload(kc + 1); if (RC) wload2(kc + 1); aload(std::integral_constant<int, 0>{}, kc + 1); }
     const bf16_t* wb = Wc + (size_t)(kc & 1) * NP * LDW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -404,12 +413,12 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         for (int s = 0; s < KSC; ++s)
           acc[rt][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[s], af[rt][s], acc[rt][j], 0, 0, 0);
     }
-    if (kc + 1 < nkc) { wstore((kc + 1) & 1); if (DZR) wstore2((kc + 1) & 1); }
+    if (kc + 1 < nkc) { wstore((kc + 1) & 1); if (RC) wstore2((kc + 1) & 1); }
     __syncthreads();
   };
 
   wload(0);
-  if (DZR) wload2(0);
+  if (RC) wload2(0);
   aload(std::integral_constant<int, 0>{}, 0);
   if (STG) {
     float* fsh = vec + 2 * HN;                      // [4] block-reduction scratch
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     }
   }
   wstore(0);
-  if (DZR) wstore2(0);
+  if (RC) wstore2(0);
   __syncthreads();
   if (EARLY) {
 #pragma unroll 1

@@ -610,9 +610,13 @@ class Engine:
         if rs_n == "fused":   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
             fin = dict(fin_sum=blk["G2"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"], fin_ainv=blk["Ainv"],
                        fin_out=blk["scale"], fin_eps=eps) if fold else {}   # GRN finalisation folded into the prologue
-            self._rs(lst, tag + ":grn.apply+pw2", 4, blk, (2 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["h"],
+            # optional (off: 5.146 vs 5.152 ms, noise): h recomputed from xn, 26 MB instead of 105 MB read per stage-0 block
+            hr = fold and Cc <= int(os.environ.get("MPMAE_HR_MAXC", "0"))
+            hkw = dict(dz_dout=blk["xn"], dz_w2t=self.w[tag + ".W1"]["t"], dz_ldw2=self.w[tag + ".W1"]["ld"], dz_bias=P[nm["b1"]]) if hr else {}
+            self._rs(lst, tag + ":grn.apply+pw2", 4, blk, ((1 if hr else 2) * M * H + (3 if hr else 2) * M * Cc) * esz,
+                     (4 if hr else 2) * M * Cc * H, A=blk["h"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
-                     v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0, **fin)
+                     v1=P[nm["gb"]], out=blk["out"], xn=blk["z"], R=x, act=act, rpg=0, **fin, **hkw)
             return blk["out"]
         self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                  _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)

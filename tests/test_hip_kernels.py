@@ -377,6 +377,24 @@ def test_dz_recomputation_matches_the_materialised_path(M, Cc):
     assert _rel(u0, s0) < 1e-5 and _rel(u1, s1) < 1e-5
     assert _rel(dh1, dh0) < 5e-3 and (dh1 != dh0).float().mean().item() < 1e-3
     assert _rel(dd1, dd0) < 1e-2 and _rel(g1, g0) < 1e-3
+    # forward twin: which = 4 recomputing h = xn W1^T + b1 is bit-identical to reading the h that which = 0 stored
+    d = (torch.randn(M, Cc, device=dev) * 2 + 0.3).to(bf) * live
+    lnw, lnb = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
+    W1 = (torch.randn(H, Cc, device=dev) / math.sqrt(Cc)).to(bf)
+    b1, b2, gbeta = torch.randn(H, device=dev) * 0.1, torch.randn(Cc, device=dev) * 0.1, torch.randn(H, device=dev) * 0.1
+    xh, xn, rs_ = torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, device=dev)
+    hs, q0, q1 = torch.empty(M, H, device=dev, dtype=bf), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    assert lib.mpmae_rs(0, C.byref(args(A=d, W=W1, ldw=Cc, bias=b1, v0=lnw, v1=lnb, out=hs, xhat=xh, xn=xn, rstd=rs_, act=act, s0=q0)), _st()) == 0
+    assert lib.mpmae_rs(0, C.byref(args(A=d, W=W1, ldw=Cc, bias=b1, v0=lnw, v1=lnb, out=None, xhat=xh, xn=xn, rstd=rs_, act=act, s0=q1)), _st()) == 0
+    x = torch.randn(M, Cc, device=dev).to(bf) * live
+    W2 = W2T.t().contiguous()
+    za, oa, zb, ob = (torch.empty(M, H, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf),
+                      torch.empty(M, H, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf))
+    assert lib.mpmae_rs(4, C.byref(args(A=hs, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=oa, xn=za, R=x, act=act)), _st()) == 0
+    assert lib.mpmae_rs(4, C.byref(args(A=hs, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=ob, xn=zb, R=x, act=act, dz_dout=xn,
+                                        dz_w2t=W1, dz_ldw2=Cc, dz_bias=b1)), _st()) == 0
+    torch.cuda.synchronize()
+    assert _rel(q1, q0) < 1e-5 and torch.equal(za, zb) and torch.equal(oa, ob)
     # and against plain torch on the same bf16 operands
     hf, r_dz = h.float(), (dout.float() @ W2T.float().t()).to(bf)
     r_dh = ((r_dz.float() * scale + coef * _gelu(hf)) * _dgelu(hf)).to(bf)

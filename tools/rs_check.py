@@ -104,7 +104,18 @@ def run(M, Cc, timing):
         out["1n:s0"] = rel(u0, t0); out["1n:s1"] = rel(u1, t1)
         out["5n:dh-5:dh"] = rel(dhb, dzc); out["5n:dd-5:dd"] = rel(dd2, dd)
         out["5n:ndiff"] = float((dhb != dzc).sum().item())
-        extra = [("1 (no dz store)", 1, a1n), ("5 (dz recomputed)", 5, a5n)]
+        # h never materialised: which 0 statistics only, which 4 recomputes h = xn W1^T + b1
+        v0_ = torch.zeros(H, device=dev)
+        xh2 = torch.empty_like(xhat); xn2 = torch.empty_like(xn); rs2 = torch.empty_like(rstd)
+        a0n = args(M, Cc, H, A=d, W=W1, ldw=Cc, bias=b1, v0=lnw, v1=lnb, out=None, xhat=xh2, xn=xn2, rstd=rs2, act=act, s0=v0_)
+        assert lib.mpmae_rs(0, C.byref(a0n), st) == 0
+        z2 = torch.empty_like(z); o2 = torch.empty_like(o)
+        a4n = args(M, Cc, H, A=h, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=o2, xn=z2, R=x, act=act, rpg=0,
+                   dz_dout=xn, dz_w2t=W1, dz_ldw2=Cc, dz_bias=b1)
+        assert lib.mpmae_rs(4, C.byref(a4n), st) == 0
+        torch.cuda.synchronize()
+        out["0n:s0"] = rel(v0_, s0); out["4n:z-4:z"] = rel(z2, z); out["4n:out-4:out"] = rel(o2, o)
+        extra = [("0 (no h store)", 0, a0n), ("4 (h recomputed)", 4, a4n), ("1 (no dz store)", 1, a1n), ("5 (dz recomputed)", 5, a5n)]
     torch.cuda.synchronize()
     msg = "  ".join(f"{k} {v:.1e}" for k, v in out.items())
     print(f"M={M} C={Cc}: {msg}")
