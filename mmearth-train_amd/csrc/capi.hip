@@ -1110,7 +1110,7 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (which > 3 || (small && which < 2)) {
     static int v40 = rsc_env("MPMAE_RSC_N40", 2), v80 = rsc_env("MPMAE_RSC_N80", 1);
     if (a->C == 40 && a->H == 160) {
-      if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2>(which, *a, S_(s));
+      if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2, 6>(which, *a, S_(s));
       if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1, 6>(which, *a, S_(s));
       if (v40 == 3) return launch_rsc<40, 4, 160, 160, 1>(which, *a, S_(s));
       return launch_rsc<40, 4, 160, 160, 2>(which, *a, S_(s));
@@ -1118,7 +1118,7 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
     if (a->C == 80 && a->H == 320) {
       if (v80 == 1) return launch_rsc<80, 2, 64, 64, 1, 6>(which, *a, S_(s));
       if (v80 == 2) return launch_rsc<80, 2, 64, 32, 1>(which, *a, S_(s));
-      return launch_rsc<80, 2, 64, 64, 2>(which, *a, S_(s));
+      return launch_rsc<80, 2, 64, 64, 2, 6>(which, *a, S_(s));
     }
   }
   if (which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;
