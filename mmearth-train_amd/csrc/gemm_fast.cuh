@@ -92,8 +92,12 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
 
   const int nk = (p.K + BK - 1) / BK;
   if constexpr (GLDS) {
-    static_assert(BK == 64 || BK == 32, "swizzle table");
-    auto swz = [](int row) { return BK == 64 ? (row & 7) : ((row >> 1) & 3); };
+    // Swizzle: conflict-free for BOTH fragment row patterns below (tools/lds_bank_model.py): A rows are lr (mod 16); B rows
+    // of a tile PAIR are interleaved, row = (lr >> 2) * 8 + t * 4 + (lr & 3), so that with the MFMA issued transposed
+    // (D[n][m] = B . A^T) a lane ends up with 8 CONSECUTIVE output columns of one row: the epilogue is one 16-byte store per
+    // row and pair straight from the accumulators - no LDS staging pass, no barriers.
+    static_assert((BK == 64 || BK == 32) && EPI == EPI_STORE && NJ % 2 == 0, "swizzle table / plain epilogue");
+    auto swz = [](int row) { return BK == 64 ? ((row & 3) | (((row >> 3) & 1) << 2)) : ((row & 1) | (((row >> 3) & 1) << 1)); };
     auto dma = [&](int buf, int k0) {
 #pragma unroll
       for (int i = 0; i < ACH; ++i) {
@@ -110,29 +114,66 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
       }
     };
-    const int sw = swz(lr);                 // every fragment row of this lane is lr (mod 16)
+    const int swa = swz(lr);                                         // A rows: (mod 16) = lr
+    const int browl = (lr >> 2) * 8 + (lr & 3);                      // B rows of a pair: + t * 4
+    const int swb = swz(browl);                                      // independent of t (bit 2 is not used)
     dma(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
       if (kt + 1 < nk) dma((kt + 1) & 1, (kt + 1) * BK);
       const bf16_t* a = As + (kt & 1) * FBM * LDK + (wm * 64 + lr) * LDK;
-      const bf16_t* b = Bs + (kt & 1) * BN * LDK + (wn * (BN / 2) + lr) * LDK;
+      const bf16_t* b = Bs + (kt & 1) * BN * LDK + (wn * (BN / 2) + browl) * LDK;
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 32) {
-        const int co = (((ks >> 3) + lg) ^ sw) * 8;
+        const int coa = (((ks >> 3) + lg) ^ swa) * 8, cob = (((ks >> 3) + lg) ^ swb) * 8;
         bf16x8_t af[4], bfr[NJ];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * LDK + co));
+        for (int i = 0; i < 4; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(a + i * 16 * LDK + coa));
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + j * 16 * LDK + co));
+        for (int j = 0; j < NJ; ++j)      // j = 2 jp + t
+          bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(b + ((j >> 1) * 32 + (j & 1) * 4) * LDK + cob));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
       __syncthreads();                      // carries the vmcnt(0) that retires the slab just requested
     }
+    // epilogue: lane = row m0 + wm*64 + i*16 + lr, columns n0 + wn*(BN/2) + jp*32 + lg*8 + (t*4 + r)
+    bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
+#pragma unroll
+    for (int jp = 0; jp < NJ / 2; ++jp) {
+      const int col = n0 + wn * (BN / 2) + jp * 32 + lg * 8;
+      if (col >= p.N) continue;                          // N % 8 == 0 guaranteed by the dispatcher
+      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + lr;
+        if (row >= p.M) continue;
+        const bool live = !p.act || p.act[row];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * jp + (e >> 2)][e & 3] + bv[e];
+        if (Rg) {
+          float rr[8];
+          ld8<bf16_t>(Rg + (size_t)row * p.ldr + col, rr);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        if (!live) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
+        st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+      }
+    }
+    return;
   } else {
   gload(0);
   lstore(0);

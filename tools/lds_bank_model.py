@@ -56,3 +56,13 @@ if __name__ == "__main__":
     for name, swz in [("chunk ^ (row & 7)", lambda r: r & 7), ("chunk ^ ((row & 3) | ((row >> 3) & 1) << 2)", lambda r: (r & 3) | (((r >> 3) & 1) << 2))]:
         res = [read_cycles(frag(128, swz, s, rowmap=lambda lr, t=t: (lr >> 2) * 8 + t * 4 + (lr & 3))) for t in (0, 1) for s in (0, 1)]
         print(f"  {name:44s} read {res}")
+    print("interleaved tile pairs, 64-byte rows (BK = 32), chunk = lg ^ f(row)")
+    import itertools
+    best = []
+    for bits in itertools.product(range(5), repeat=2):      # f = bit a of row | bit b of row << 1
+        f = lambda r, a=bits[0], b=bits[1]: ((r >> a) & 1) | (((r >> b) & 1) << 1)
+        resB = [read_cycles(frag(64, f, 0, rowmap=lambda lr, t=t: (lr >> 2) * 8 + t * 4 + (lr & 3))) for t in (0, 1)]
+        resA = read_cycles(frag(64, f, 0))
+        best.append((max(resB + [resA]), bits, resB, resA))
+    for m, bits, rb, ra in sorted(best)[:4]:
+        print(f"  f = row bit {bits[0]} | row bit {bits[1]} << 1: B {rb} A {ra}")
