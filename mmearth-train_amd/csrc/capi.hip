@@ -728,6 +728,8 @@ static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
   return true;
 }
 
+static bool glds_bn64() { static int v = -1; if (v < 0) { const char* e = getenv("MPMAE_NT_GLDS64"); v = e ? atoi(e) : 1; } return v != 0; }
+
 template <int BN>
 static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   size_t lds = (size_t)(2 * FBM * FLD + 2 * BN * FLD) * sizeof(bf16_t);
@@ -740,7 +742,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   if (bk32 < 0) { const char* e = getenv("MPMAE_NT_BK32"); bk32 = e ? atoi(e) : 1; }
   static int glds = -1;
   if (glds < 0) { const char* e = getenv("MPMAE_NT_GLDS"); glds = e ? atoi(e) : 1; }
-  if (glds && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K % 64 == 0) {
+  if (glds && (epi == EPI_STORE || epi == EPI_RESID) && (BN == 128 || glds_bn64()) && a.M >= 4096 && a.K % 64 == 0) {
     // direct global -> LDS slabs, swizzled unpadded rows
     if (glds == 2 || a.K <= 512) {
       const size_t l = (size_t)(2 * FBM * 32 + 2 * BN * 32) * sizeof(bf16_t);

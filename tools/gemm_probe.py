@@ -19,7 +19,8 @@ def t(fn, n=30):
 
 shapes = [(12544, 2048, 512, "dec pw1"), (12544, 512, 2048, "dec pw2"), (12544, 2048, 512, "dec pw2.dgrad"),
           (12544, 512, 2048, "dec pw1.dgrad"), (12544, 512, 2000, "head pix dgrad"), (12544, 2000, 512, "head pix fwd"),
-          (4864, 1280, 320, "s3 pw1"), (4864, 320, 1280, "s3 pw2")]
+          (4864, 1280, 320, "s3 pw1"), (4864, 320, 1280, "s3 pw2"), (12544, 2816, 512, "head pix fwd (real)"),
+          (12544, 512, 2816, "head pix dgrad (real)"), (20480, 160, 320, "down1 conv"), (81920, 80, 160, "down0 conv"), (5120, 320, 640, "down2 conv")]
 for M, N, K, name in shapes:
     a = torch.randn(M, K, device="cuda", dtype=bf); w = torch.randn(N, K, device="cuda", dtype=bf) / K ** 0.5
     bias = torch.randn(N, device="cuda"); c = torch.empty(M, N, device="cuda", dtype=bf)
