@@ -925,9 +925,12 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
     const int nblk = cdiv(M, rpw);
     float* o0 = single1 ? ws : s0;
     float* o1 = single1 ? ws + (size_t)nblk * H : s1;
-    const int vpl = cdiv(H / 8, 64);
+    int vpl = cdiv(H / 8, 64), ysplit = 1;
+    static int cs_split = -1;
+    if (cs_split < 0) { const char* e = getenv("MPMAE_CS_SPLIT"); cs_split = e ? atoi(e) : 1; }
+    if (cs_split && nblk * 2 <= 1024 && vpl > 1) { ysplit = vpl; vpl = 1; }      // few row slabs: split the columns over gridDim.y
     const size_t lds = (size_t)4 * (mode + 1) * H * sizeof(float);
-#define CS3(TT, VV) LAUNCH((colstats_v3_kernel<TT, VV>), dim3(nblk), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
+#define CS3(TT, VV) LAUNCH((colstats_v3_kernel<TT, VV>), dim3(nblk, ysplit), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
 #define CS3_T(TT) do { if (vpl == 1) CS3(TT, 1); else if (vpl == 2) CS3(TT, 2); else if (vpl <= 4) CS3(TT, 4); else CS3(TT, 6); } while (0)
     if (dt == 0) CS3_T(float); else CS3_T(bf16_t);
 #undef CS3_T

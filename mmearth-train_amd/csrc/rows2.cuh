@@ -243,7 +243,9 @@ __global__ __launch_bounds__(256) void colstats_v2_kernel(const T* __restrict__ 
 // column statistics v3: one 256-thread block per slab of `rows_per_block` rows (= one statistics
 // group in grouped mode); wave w takes rows w, w+4, ...; lanes own 16-byte column vectors
 // (VPL per lane), the four waves are combined through LDS and the block writes one [H] row
-// (two in mode 1) to out0/out1 at row blockIdx.x.
+// (two in mode 1) to out0/out1 at row blockIdx.x. gridDim.y > 1 splits the columns: block (x, y) owns the vectors
+// [y * 64 * VPL, (y + 1) * 64 * VPL) - the per-sample statistics of the dense decoder (256 groups of 49 rows) would otherwise
+// run as 256 workgroups, one wave per SIMD.
 template <typename T, int VPL>
 __global__ __launch_bounds__(256) void colstats_v3_kernel(const T* __restrict__ h, const T* __restrict__ dz, int mode,
                                                           float* __restrict__ out0, float* __restrict__ out1,
@@ -251,17 +253,17 @@ __global__ __launch_bounds__(256) void colstats_v3_kernel(const T* __restrict__ 
   extern __shared__ float red[];                       // [4 waves][(mode+1)][H]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int mb = blockIdx.x * rows_per_block, me = min(M, mb + rows_per_block);
-  const int nvec = H / 8;
+  const int nvec = H / 8, vbase = blockIdx.y * (64 * VPL);
   float a0[VPL][8], a1[VPL][8];
 #pragma unroll
   for (int i = 0; i < VPL; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a0[i][e] = 0.f; a1[i][e] = 0.f; }
-#pragma unroll 2
+#pragma unroll 4
   for (int m = mb + wave; m < me; m += 4) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      const int v = lane + 64 * i;
+      const int v = vbase + lane + 64 * i;
       if (v < nvec) {
         float hv[8];
         ld8<T>(h + (size_t)m * H + v * 8, hv);
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void colstats_v3_kernel(const T* __restrict__ 
   const int nst = mode + 1;
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
-    const int v = lane + 64 * i;
+    const int v = vbase + lane + 64 * i;
     if (v < nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -290,7 +292,8 @@ __global__ __launch_bounds__(256) void colstats_v3_kernel(const T* __restrict__ 
     }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < H; j += 256) {
+  const int jb = vbase * 8, je = min(H, jb + 64 * VPL * 8);
+  for (int j = jb + threadIdx.x; j < je; j += 256) {
     out0[(size_t)blockIdx.x * H + j] = red[(0 * nst) * H + j] + red[(1 * nst) * H + j] + red[(2 * nst) * H + j] + red[(3 * nst) * H + j];
     if (mode == 1)
       out1[(size_t)blockIdx.x * H + j] = red[(0 * nst + 1) * H + j] + red[(1 * nst + 1) * H + j] + red[(2 * nst + 1) * H + j] + red[(3 * nst + 1) * H + j];
