@@ -1147,7 +1147,10 @@ class Engine:
         if self.stem_im2col:
             Kc = 9 * cfg.in_chans
             self.dw_stem_pad = torch.zeros(C0 * self.ldk, dtype=torch.float32, device=self.device)
+            # zeroed at the START of the backward: in the tail it sat on the critical path between the last data gradient
+            # and AdamW (profiles/r01/timeline_final.txt)
             self._op(b, "stem:conv.dWpad.zero", lib.mpmae_memset_async, _p(self.dw_stem_pad), 0, C0 * self.ldk * 4)
+            b.insert(0, b.pop())
             self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", P=dc1, Q=self.col, M=self.Mfull, Nn=C0, Kk=self.ldk, ldp=C0,
                         ldq=self.ldk, dW=self.dw_stem_pad, sn=self.ldk, sk=1, db=Gd["encoder.initial_conv.0.bias"])
             # (C0, 9*Cin) padded row-major -> ME kernel layout (9, Cin, C0)
