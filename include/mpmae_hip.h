@@ -298,7 +298,8 @@ int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, f
                         float* dlog_vars, mpmae_stream_t stream);
 
 /* ---- optimizer (main_pretrain.py:312-320; helpers.py:509-526) ------------------------------ */
-/* hp (device) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} */
+/* hp (device, 8 floats) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale, skip, skipped_steps, -, -}:
+ * when skip != 0 mpmae_adamw leaves p / m / v untouched (non-finite loss, engine_pretrain.py:83-85). */
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
                 float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask,
                 mpmae_stream_t stream);
@@ -306,8 +307,10 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
 /* hyper-parameter hand-over for replayed steps: copies record (*counter % slots) of a pinned,
  * device-visible ring of {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} records into hp and
  * increments *counter, in stream order (the host fills slot t % slots before enqueueing step t and
- * must not run more than `slots` steps ahead). */
-int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, mpmae_stream_t stream);
+ * must not run more than `slots` steps ahead). `total` (may be NULL) is the step's loss on the device:
+ * a non-finite value sets hp[4] (skip this update) and increments hp[5]. */
+int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total,
+                   mpmae_stream_t stream);
 
 /* ---- launch programs ----------------------------------------------------------------------
  * The reference drives its step from Python (engine_pretrain.py:46-118, one autograd graph per

@@ -112,25 +112,7 @@ class SyntheticLoader:
             yield self.samples
 
 
-def param_groups_weight_decay(model, weight_decay):
-    """timm.optim.optim_factory.param_groups_weight_decay (main_pretrain.py:312-319)."""
-    decay, no_decay = [], []
-    for name, p in model.named_parameters():
-        if not p.requires_grad:
-            continue
-        (no_decay if (p.ndim <= 1 or name.endswith(".bias")) else decay).append(p)
-    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
-
-
-def save_model(args, epoch, model, optimizer):
-    """Checkpoint layout of helpers.save_model (/root/reference/helpers.py:529-565)."""
-    out = Path(args.output_dir)
-    torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                "optimizer": optimizer.state_dict() if optimizer is not None else None,
-                "epoch": epoch, "scaler": {}, "args": args}, out / f"checkpoint-{epoch}.pth")
-    old = epoch - args.save_ckpt_num * args.save_ckpt_freq
-    if (out / f"checkpoint-{old}.pth").exists():
-        os.remove(out / f"checkpoint-{old}.pth")
+from mmearth_train_amd.helpers import auto_load_model, param_groups_weight_decay, save_model  # noqa: E402,F401
 
 
 def main(args):
@@ -140,6 +122,13 @@ def main(args):
     if args.distributed and world > 1:
         mdist.init(backend="nccl", local_rank=local_rank)
     device = torch.device("cuda", local_rank) if args.device == "cuda" else torch.device(args.device)
+    if device.type != "cuda":
+        raise RuntimeError("the pretraining path runs on the HIP engine only (no CPU fallback): --device cuda")
+    if not args.sparse:
+        raise NotImplementedError("--sparse False (the reference's dense debug encoder, broken at 56/8) is not provided")
+    if args.use_mixed:
+        print("--use_mixed: fp16 autocast + GradScaler are replaced by bf16 activations with fp32 master weights "
+              "(--compute_dtype bf16, no loss scaling needed)")
     torch.cuda.set_device(device)
     torch.manual_seed(args.seed + rank)
 
@@ -163,24 +152,36 @@ def main(args):
     loader = SyntheticLoader(model.cfg, args.batch_size, args.steps_per_epoch, seed=1000 + rank)
 
     runner, optimizer = None, None
-    if args.fast_path and args.update_freq == 1:
-        eng = model._get_engine(args.batch_size)
+    if args.fast_path:
+        # fused step: launch program + flat-buffer AdamW; --update_freq accumulates in the flat gradient buffer and
+        # the bucketed RCCL all-reduce runs on the update micro-step (dist.StepRunner)
+        eng = model._get_engine(args.batch_size, args.mask_ratio)
         model._engine = eng
-        runner = mdist.StepRunner(eng, world_size=world, mode="program", lr=args.lr, weight_decay=args.weight_decay)
+        runner = mdist.StepRunner(eng, world_size=world, mode="program", lr=args.lr, weight_decay=args.weight_decay,
+                                  update_freq=args.update_freq)
     else:
+        # debugging path through torch autograd + torch.optim.AdamW; gradients are averaged across ranks on every
+        # update step (engine_pretrain.train_one_epoch) - the reference wraps the model in DDP (main_pretrain.py:306-310)
         optimizer = torch.optim.AdamW(param_groups_weight_decay(model, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))
 
     if args.output_dir:
         Path(args.output_dir).mkdir(parents=True, exist_ok=True)
+    auto_load_model(args, model, optimizer=optimizer, runner=runner)       # --resume / --auto_resume (helpers.py:568-610)
+    if world > 1:
+        torch.distributed.broadcast(model._pflat, src=0)
     start = time.time()
+    stats = None
     for epoch in range(args.start_epoch, args.epochs):
-        train_one_epoch(model, loader, optimizer, device, epoch, args, runner=runner)
+        # mask noise / crop windows are a function of (seed, rank, epoch): a resumed run repeats the uninterrupted one
+        torch.manual_seed(args.seed + rank + 7919 * epoch)
+        stats = train_one_epoch(model, loader, optimizer, device, epoch, args, runner=runner)
         if args.output_dir and args.save_ckpt and rank == 0 and \
                 ((epoch + 1) % args.save_ckpt_freq == 0 or epoch + 1 == args.epochs):
-            save_model(args, epoch, model, optimizer)
+            save_model(args, epoch, model, optimizer=optimizer, runner=runner)
     if rank == 0:
         print("Training time {:.0f}s".format(time.time() - start))
     mdist.shutdown()
+    return stats
 
 
 if __name__ == "__main__":

@@ -164,7 +164,7 @@ SYMBOLS = {
                       c_void_p],
     "mpmae_strided_add": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_stem_tail": [c_int, c_int, P(StemTailArgs), c_void_p],
-    "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p],
+    "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],
     "mpmae_program_end": [c_void_p],
     "mpmae_program_num_ops": [c_void_p],

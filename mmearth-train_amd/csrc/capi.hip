@@ -693,8 +693,8 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
 
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
                         float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
-  if (T > 64) return (int)hipErrorInvalidValue;
-  LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
+  if (T > 16 || T < 1) return (int)hipErrorInvalidValue;
+  LAUNCH(loss_finalize_kernel, dim3(1), dim3(64 * T), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
                      total, coef, dlog_vars);
   RET();
 }
@@ -1270,9 +1270,9 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
   return (int)hipGetLastError();
 }
 
-int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, mpmae_stream_t s) {
+int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total, mpmae_stream_t s) {
   if (!ring_pinned || slots < 1 || !counter || !hp) return (int)hipErrorInvalidValue;
-  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp);
+  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp, total);
   RET();
 }
 

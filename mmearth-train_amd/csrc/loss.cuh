@@ -406,12 +406,17 @@ __global__ __launch_bounds__(256) void loss_img_multi_kernel(const ImgP* __restr
 __global__ void loss_finalize_kernel(const float* __restrict__ acc, int Nn, const float* __restrict__ log_vars, int Tn,
                                      float loss_scale, float* __restrict__ losses, float* __restrict__ weighted,
                                      float* __restrict__ total, float* __restrict__ coef, float* __restrict__ dlog_vars) {
+  // one wave per modality: its 64 lanes fold the per-sample {sum, count} partials (fixed order -> deterministic)
   __shared__ float w[64];
-  const int i = threadIdx.x;
-  float wi = 0.f;
-  if (i < Tn) {
-    float ssum = 0.f, scnt = 0.f;
-    for (int n = 0; n < Nn; ++n) { ssum += acc[((size_t)i * Nn + n) * 2]; scnt += acc[((size_t)i * Nn + n) * 2 + 1]; }
+  const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float ssum = 0.f, scnt = 0.f;
+  for (int n = lane; n < Nn; n += 64) {
+    const float2 a = *reinterpret_cast<const float2*>(acc + ((size_t)i * Nn + n) * 2);
+    ssum += a.x; scnt += a.y;
+  }
+  ssum = wave_sum(ssum); scnt = wave_sum(scnt);
+  if (lane == 0) {
+    float wi = 0.f;
     const float Li = ssum / scnt;
     losses[i] = Li;
     float dLi = 1.f;
@@ -421,16 +426,15 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, int Nn, cons
       wi = (e * Li + s) * nz;
       dLi = e * nz;
       if (dlog_vars) dlog_vars[i] += loss_scale * (1.f - e * Li) * nz;
-      weighted[i] = wi;
     } else {
       wi = Li;
-      weighted[i] = Li;
     }
+    weighted[i] = wi;
     coef[i] = loss_scale * dLi / scnt;
+    w[i] = wi;
   }
-  w[i] = wi;
   __syncthreads();
-  if (i == 0) {
+  if (threadIdx.x == 0) {
     float t = 0.f;
     for (int j = 0; j < Tn; ++j) t += w[j];
     total[0] = t;

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const float* __restrict__ hp, float beta1, float beta2,
                                                     float eps, float wd, size_t n,
                                                     const uint8_t* __restrict__ decay) {
+  if (hp[4] != 0.f) return;      // non-finite loss this step (hp_fetch): the update is skipped, p / m / v stay intact
   const float lr = hp[0], ibc1 = hp[1], isbc2 = hp[2], gs = hp[3];
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gs;
@@ -202,11 +203,20 @@ __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ ds
 // ring; this kernel (one per optimizer step, in stream order) copies the slot its device-side
 // counter points at into `hp` and advances the counter. A plain async H2D copy would read the
 // pinned record when the copy EXECUTES, by which time a host running ahead has overwritten it.
-__global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp) {
+__global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
+                                const float* __restrict__ total) {
   const int c = *counter;
   if (threadIdx.x < 4) hp[threadIdx.x] = ring[(size_t)(c % R) * 4 + threadIdx.x];
   __syncthreads();
-  if (threadIdx.x == 0) *counter = c + 1;
+  if (threadIdx.x == 0) {
+    *counter = c + 1;
+    // engine_pretrain.py:83-85 stops on a non-finite loss BEFORE the optimizer step; here the check stays on the
+    // device: hp[4] makes this step's AdamW a no-op, hp[5] counts skipped steps (the host polls it lazily)
+    const float t = total ? *total : 0.f;
+    const bool bad = !(fabsf(t) <= 3.0e38f);
+    hp[4] = bad ? 1.f : 0.f;
+    if (bad) hp[5] += 1.f;
+  }
 }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {

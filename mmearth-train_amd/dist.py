@@ -112,16 +112,25 @@ class StepRunner:
     if capture is not possible; measured slower than "program" because graph branches do not
     overlap as well as real streams); "eager" is the Python loop over the C-ABI calls."""
 
-    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None):
+    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None, update_freq=1):
         self.eng = engine
         self.world = world_size
         self.lr = lr
         self.wd = weight_decay
-        self.t = 0
+        self.t = 0                       # optimizer updates done (AdamW bias-correction step)
+        self.micro = 0                   # micro-steps done inside the current accumulation window
+        # gradient accumulation (main_pretrain.py --update_freq, engine_pretrain.py:87-94): every micro-step
+        # back-propagates loss / update_freq into the SAME flat gradient buffer; the buffer is zeroed at the
+        # start of a window and all-reduced + applied at its end. (The reference's DDP all-reduces on every
+        # micro-step; the sum is the same, the traffic here is 1 / update_freq of it.)
+        self.update_freq = int(update_freq)
+        if self.update_freq > 1 and (mode == "hipgraph" or (mode is None and use_graph)):
+            raise ValueError("update_freq > 1 needs mode 'program' or 'eager'")
         self.graph_mode = "eager"
         self.buckets = plan_buckets(engine.offsets, engine.n_params) if world_size > 1 else []
         self.segments = split_bwd_segments(engine.bwd_ops) if world_size > 1 else [engine.bwd_ops]
-        self.comm_stream = torch.cuda.Stream(device=engine.device) if world_size > 1 else None
+        self.comm_stream = (torch.cuda.Stream(device=engine.device)
+                            if world_size > 1 and engine.device.type == "cuda" else None)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
         self.graphs = None
         self.prog = None
@@ -131,7 +140,8 @@ class StepRunner:
             mode = "hipgraph" if use_graph else "eager"
         if mode == "program":
             self.prog, self.spans = engine.record_program(
-                engine.step_pieces(self.segments if world_size > 1 else None, weight_decay=weight_decay))
+                engine.step_pieces(self.segments if world_size > 1 else None, weight_decay=weight_decay,
+                                   loss_scale=1.0 / self.update_freq))
             self.graph_mode = "program"
         elif mode == "hipgraph":
             self._capture()
@@ -140,11 +150,12 @@ class StepRunner:
     def _fwd(self):
         self.eng.forward()
 
-    def _bwd_head(self):
+    def _bwd_head(self, zero=True):
         eng = self.eng
         st = eng._stream()
-        eng.gflat.zero_()
-        eng.finalize_loss(st, True, 1.0)
+        if zero:
+            eng.gflat.zero_()
+        eng.finalize_loss(st, True, 1.0 / self.update_freq)
 
     def _bwd_seg(self, i):
         self.eng._run(self.segments[i], self.eng._stream())
@@ -199,25 +210,36 @@ class StepRunner:
             eng.single_stream = False
 
     def _launch_allreduce(self, b, works):
+        lo, hi = self.buckets[b]
+        if self.comm_stream is None:         # host tensors (gloo logic tests): the collective is synchronous
+            dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM)
+            return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.comm_stream.wait_event(ev)
-        lo, hi = self.buckets[b]
         with torch.cuda.stream(self.comm_stream):
             works.append(dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def step(self):
+        """One micro-step. Returns True when it ended with an optimizer update."""
         eng = self.eng
-        self.t += 1
-        eng.set_hyper(self.lr, self.t, grad_scale=1.0 / self.world)
+        first = self.micro == 0                       # zero the gradient buffer
+        last = self.micro == self.update_freq - 1     # exchange + AdamW
+        self.micro = 0 if last else self.micro + 1
+        if last:
+            self.t += 1
+            eng.set_hyper(self.lr, self.t, grad_scale=1.0 / self.world)
         if self.prog is not None:
-            return self._step_program()
-        if self.world == 1:
-            if self.graphs:
-                self.graphs[0].replay()
-                eng.note_optimizer_launch()
-            else:
-                self._fwd(); self._bwd_head(); self._bwd_seg(0); self._opt()
+            self._step_program(first, last)
+        else:
+            self._step_launches(first, last)
+        return last
+
+    def _step_launches(self, first, last):
+        eng = self.eng
+        if self.graphs and self.world == 1:
+            self.graphs[0].replay()
+            eng.note_optimizer_launch()
             return
         works = []
         nseg = len(self.segments)
@@ -226,40 +248,74 @@ class StepRunner:
                 self.graphs[i].replay()
             else:
                 if i == 0:
-                    self._fwd(); self._bwd_head()
+                    self._fwd(); self._bwd_head(zero=first)
                 self._bwd_seg(i)
-            self._launch_allreduce(i, works)
-        # scalar loss all-reduce for logging (engine_pretrain.py:104), no host sync
-        self.loss_buf.copy_(eng.total)
-        lw = dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True)
-        for w in works:
-            w.wait()                     # current stream waits for the collectives
-        lw.wait()
+            if last and self.world > 1:
+                self._launch_allreduce(i, works)
+        if not last:
+            return
+        if self.world > 1:
+            # scalar loss all-reduce for logging (engine_pretrain.py:104), no host sync
+            self.loss_buf.copy_(eng.total)
+            works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
+            for w in works:
+                w.wait()                     # current stream waits for the collectives
         if self.graphs:
             self.graphs[-1].replay()
             eng.note_optimizer_launch()
         else:
             self._opt()
 
-    def _step_program(self):
+    def _span(self, i, j):
+        """Program range covering pieces i..j (inclusive): [fwd, zero, seg0, seg1, ..., opt]."""
+        lo = self.spans[i][0]
+        return (lo, self.spans[j][0] + self.spans[j][1] - lo)
+
+    def _step_program(self, first, last):
         eng = self.eng
-        if self.world == 1:
-            first, _ = self.spans[0]
-            last, cnt = self.spans[-1]
-            eng.run_program(self.prog, (first, last + cnt - first))       # the whole step in one call
-            eng.note_optimizer_launch()
+        nseg = len(self.segments)
+        FWD, ZERO, SEG0, OPT = 0, 1, 2, 2 + nseg
+        if self.world == 1 or not last:
+            hi = OPT if last else OPT - 1
+            if first:
+                eng.run_program(self.prog, self._span(FWD, hi))            # the whole micro-step in one call
+            else:
+                eng.run_program(self.prog, self._span(FWD, FWD))
+                eng.run_program(self.prog, self._span(SEG0, hi))
+            if last:
+                eng.note_optimizer_launch()
             return
         works = []
-        for i in range(len(self.segments)):
-            eng.run_program(self.prog, self.spans[i])
+        eng.run_program(self.prog, self._span(FWD, ZERO if first else FWD))
+        for i in range(nseg):
+            eng.run_program(self.prog, self._span(SEG0 + i, SEG0 + i))
             self._launch_allreduce(i, works)
         self.loss_buf.copy_(eng.total)
-        lw = dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True)
+        works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
-        lw.wait()
-        eng.run_program(self.prog, self.spans[-1])
+        eng.run_program(self.prog, self._span(OPT, OPT))
         eng.note_optimizer_launch()
+
+    # -- checkpoint state of the fused optimizer (helpers.save_model / auto_load_model: the "optimizer" entry)
+    def state_dict(self):
+        eng = self.eng
+        return {"fused_adamw": True, "step": self.t, "exp_avg": eng.mflat.detach().cpu().clone(),
+                "exp_avg_sq": eng.vflat.detach().cpu().clone(), "param_order": list(eng.offsets.keys()),
+                "lr": self.lr, "weight_decay": self.wd, "betas": (0.9, 0.95)}
+
+    def load_state_dict(self, sd):
+        eng = self.eng
+        if not sd.get("fused_adamw") or list(sd["param_order"]) != list(eng.offsets.keys()):
+            raise ValueError("optimizer state does not belong to this model's fused AdamW")
+        eng.mflat.copy_(sd["exp_avg"])
+        eng.vflat.copy_(sd["exp_avg_sq"])
+        self.t = int(sd["step"])
+        self.micro = 0
+
+    def skipped_steps(self) -> int:
+        """Updates skipped because the loss was non-finite (device-side guard in mpmae_hp_fetch); host sync."""
+        return int(self.eng.hp[5].item())
 
     def mean_loss(self) -> float:
         if self.world == 1:

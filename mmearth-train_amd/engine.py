@@ -115,7 +115,7 @@ class Engine:
                 self.decay_mask[off:off + n] = 1
             off += n
         self.n_params = total
-        self.hp = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.hp = torch.zeros(8, dtype=torch.float32, device=dev)   # {lr, 1/bc1, 1/sqrt(bc2), grad_scale, skip, n_skipped, -, -}
         # hyper-parameter ring: slot t % HP_SLOTS is written by set_hyper for optimizer launch t and read on the
         # device by mpmae_hp_fetch (a replayed step must not read a record the host has already overwritten)
         self.HP_SLOTS = 16
@@ -1210,10 +1210,52 @@ class Engine:
             dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
         self.noise.copy_(noise, non_blocking=True)
 
+    # ------------------------------------------------------------------ forward segments (FCMAE.forward_encoder / _decoder / _loss)
+    def _segment_bounds(self):
+        names = [op[0] for op in self.fwd_ops]
+        i_proj = names.index("proj")
+        i_loss = next(i for i, n in enumerate(names) if n.startswith("loss:"))
+        return dict(encoder=(0, i_proj), decoder=(i_proj, i_loss), loss=(i_loss, len(names)))
+
+    def run_segment(self, which: str):
+        """Run one of the three pieces of the forward program: "encoder" (mask, stem, stages -> enc_out rows),
+        "decoder" (proj, mask token, decoder block, heads -> predictions), "loss" (12 losses + weighting).
+        The later pieces re-stage the weights first (a caller may have changed them since the last encoder run)."""
+        lo, hi = self._segment_bounds()[which]
+        ops = list(self.fwd_ops[lo:hi])
+        if which != "encoder":
+            ops = [self.fwd_ops[0]] + ops                      # "prep": weight staging
+        if which == "loss":
+            self.loss_acc.zero_()
+        elif which == "encoder":
+            self.stats.zero_()
+        self._run(ops, self._stream())
+        if which == "loss":
+            self.finalize_loss(self._stream(), False, 1.0)
+
+    def set_mask(self, mask):
+        """Install a caller-supplied mask [N, L] (0 keep / 1 remove, `keep` zeros per row): the rank kernel is
+        stable, so ranking the mask values themselves reproduces exactly this mask and its vis / inv tables."""
+        self.noise.copy_(mask.reshape(self.N, self.L).to(torch.float32))
+        _lib.check(self.lib.mpmae_mask_gen(_p(self.noise), self.N, self.L, self.keep, _p(self.mask), _p(self.vis),
+                                           _p(self.inv), self._stream()), "mask_gen")
+
+    def set_preds(self, preds):
+        """Load predictions in the reference's shapes ([N, p*p*C, h, w] / [N, K]) into the head output buffers."""
+        N, L = self.N, self.L
+        for om in self.cfg.out_mods:
+            c, v = self.head_cols[om.name], preds[om.name]
+            if om.kind.startswith("pix"):
+                self.pred_pix[:, c:c + om.head_out] = v.reshape(N, om.head_out, L).permute(0, 2, 1).reshape(N * L, om.head_out)
+            else:
+                self.pred_img[:, c:c + om.head_out] = v.reshape(N, om.head_out)
+
     # ------------------------------------------------------------------ native launch programs
     def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0):
-        """The whole micro-step as op tuples, grouped into the pieces a data-parallel runner issues
-        between collectives: [forward + loss + backward segment 0], [segment 1], ..., [AdamW]."""
+        """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
+        runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
+        [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
+        mpmae_program_run call (the plain single-GPU step is the whole range)."""
         lib, a = self.lib, self._fin_args
         m0 = dict(lane=0, wait=(), signal=None)
 
@@ -1223,15 +1265,15 @@ class Engine:
                     (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
-        first = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), m0)]
-        first += list(self.fwd_ops) + [fin(False)]
-        first += [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4), m0), fin(True)]
-        first += list(segs[0])
+        fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), m0)]
+        fwd += list(self.fwd_ops) + [fin(False)]
+        zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4), m0)]
+        first = [fin(True)] + list(segs[0])
         opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                                 _p(self.hp)), m0),
+                                                 _p(self.hp), _p(self.total)), m0),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
-        return [first] + [list(sg) for sg in segs[1:]] + [opt]
+        return [fwd, zero, first] + [list(sg) for sg in segs[1:]] + [opt]
 
     def record_program(self, pieces):
         """Record op tuples into a native launch program (include/mpmae_hip.h, "launch programs").
@@ -1305,7 +1347,7 @@ class Engine:
     def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, note=True):
         st = self._stream()
         _lib.check(self.lib.mpmae_hp_fetch(C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                           _p(self.hp), st), "hp_fetch")
+                                           _p(self.hp), _p(self.total), st), "hp_fetch")
         err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                    beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), st)
         _lib.check(err, "adamw")

@@ -23,9 +23,27 @@ def adjust_learning_rate(optimizer, epoch, args):
     return lr
 
 
+def _allreduce_grads_(model):
+    """DDP gradient averaging for the torch-autograd path (main_pretrain.py:306-310)."""
+    import torch.distributed as tdist
+    if not tdist.is_initialized() or tdist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    tdist.all_reduce(flat)
+    flat /= tdist.get_world_size()
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].view_as(g))
+        off += g.numel()
+
+
 def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=None, print_freq=20):
-    """model: fcmae.FCMAE. data_loader yields dicts modality -> tensor. With `runner`
-    (dist.StepRunner) the fused HIP optimizer / HIP-graph path is used instead of torch autograd."""
+    """model: fcmae.FCMAE. data_loader yields dicts modality -> tensor. With `runner` (dist.StepRunner) the
+    fused launch program (forward, backward, bucketed all-reduce, AdamW; gradient accumulation over
+    args.update_freq micro-steps) is used; otherwise torch autograd + `optimizer` with explicit gradient
+    averaging across ranks. A non-finite loss stops training (engine_pretrain.py:83-85): on the fused path the
+    device skips the poisoned update itself (mpmae_hp_fetch) and the host notices at the next read-back."""
     update_freq = args.update_freq
     n_iter = len(data_loader)
     t0 = time.time()
@@ -45,18 +63,25 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
             losses_t, total_t = eng.losses, eng.total
         else:
             loss, pred, mask, loss_dict_, log_vars, normalized = model(samples, mask_ratio=args.mask_ratio)
+            if not math.isfinite(float(loss.item())):
+                print("Loss is {}, stopping training".format(float(loss.item())))
+                sys.exit(1)
             (loss / update_freq).backward()
             if (it + 1) % update_freq == 0:
+                _allreduce_grads_(model)
                 optimizer.step()
                 optimizer.zero_grad()
             losses_t, total_t = model._engine.losses, loss.detach()
         if it % print_freq == 0 or it == n_iter - 1:
-            loss_value = float(total_t.item())           # the only host sync of the loop
-            if not math.isfinite(loss_value):
+            loss_value = float(total_t.item())           # the only host sync of the fused loop
+            if not math.isfinite(loss_value) or (runner is not None and runner.skipped_steps() > 0):
                 print("Loss is {}, stopping training".format(loss_value))
                 sys.exit(1)
             names = [om.name for om in model.cfg.out_mods]
             loss_dict = dict(zip(names, losses_t.tolist()))
+            if model.cfg.loss_aggr == "uncertainty":
+                log_vars = model.loss_fn.log_vars.tolist()
+                normalized = model._engine.weighted.clone() if model._engine is not None else None
             mean = mdist.mean_scalar(loss_value)
             print(f"Epoch: [{epoch}]  [{it}/{n_iter}]  loss: {mean:.4f}  "
                   f"img/s: {(it + 1) * samples['sentinel2'].shape[0] / (time.time() - t0):.0f}", flush=True)

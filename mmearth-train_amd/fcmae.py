@@ -67,14 +67,18 @@ class _StepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, loss_scale_token, *params):
         ctx.model = model
-        eng = model._engine
+        ctx.eng = eng = model._engine
         eng.forward()
+        eng.fwd_generation = getattr(eng, "fwd_generation", 0) + 1
+        ctx.generation = eng.fwd_generation
         return eng.total.clone().reshape(())
 
     @staticmethod
     def backward(ctx, grad_out):
-        model = ctx.model
-        eng = model._engine
+        model, eng = ctx.model, ctx.eng
+        if getattr(eng, "fwd_generation", 0) != ctx.generation:
+            raise RuntimeError("FCMAE.backward: the engine's static activation buffers were overwritten by a later "
+                               "forward of the same batch size; call loss.backward() before the next forward")
         eng.backward(zero_grad=True)
         g = eng.gflat * grad_out
         outs = tuple(g[o:o + n].view(p.shape) for p, (o, n) in zip(model._plist, model._poffs))
@@ -133,6 +137,11 @@ class FCMAE(nn.Module):
         init_reference_(OrderedDict((k, p.data) for k, p in views.items()))
         # module tree with the reference's names
         self.loss_fn = loss_fn
+        # registration order = the reference's (named_parameters() / optimizer state indices line up with a model
+        # built by /root/reference/models/fcmae.py): SparseConvNeXtV2 creates downsample_layers before the stem
+        self.add_module("encoder", _Node())
+        for child in ("downsample_layers", "initial_conv", "stem", "stages"):
+            self.encoder.add_module(child, _Node())
         for key, p in views.items():
             if key == "loss_fn.log_vars":
                 loss_fn.log_vars = p
@@ -156,12 +165,15 @@ class FCMAE(nn.Module):
                                "pass device=... to the constructor instead of calling .to()/.half()")
         return self
 
-    def _get_engine(self, N: int) -> Engine:
-        eng = self._engines.get(N)
+    def _get_engine(self, N: int, mask_ratio=None) -> Engine:
+        """One engine (buffer plan + launch program) per (batch size, number of visible patches): the call-time
+        mask_ratio decides len_keep, as in the reference (fcmae.py:415,451 - the constructor's value is only stored)."""
+        keep = self.cfg.len_keep(mask_ratio)
+        eng = self._engines.get((N, keep))
         if eng is None:
             eng = Engine(self.cfg, N, dtype=self.compute_dtype, device=self._device,
-                         param_buffers=(self._pflat, self._gflat))
-            self._engines[N] = eng
+                         param_buffers=(self._pflat, self._gflat), mask_ratio=mask_ratio)
+            self._engines[(N, keep)] = eng
         return eng
 
     # ------------------------------------------------------------------ reference helpers
@@ -220,25 +232,70 @@ class FCMAE(nn.Module):
                 out[k] = v
         return out
 
+    # ------------------------------------------------------------------ stage helpers (fcmae.py:242-412)
+    # The three public pieces of the reference's forward. They run the matching segment of the engine's forward
+    # launch program and return detached tensors in the reference's shapes; only `forward` is connected to autograd.
+    def forward_encoder(self, imgs: Tensor, mask_ratio: float):
+        """imgs [N, C, S, S] -> (x [N, dims[-1], S/p, S/p] dense encoder output, mask [N, L])  (fcmae.py:242-247)"""
+        N = imgs.shape[0]
+        eng = self._engine = self._get_engine(N, mask_ratio)
+        eng.inp["sentinel2"].copy_(imgs.reshape(eng.inp["sentinel2"].shape), non_blocking=True)
+        eng.noise.copy_(torch.randn(N, self.cfg.num_patches, device=self._device))
+        eng.run_segment("encoder")
+        x = eng.dense_map(eng.enc_out, self.cfg.dims[-1], 3).to(torch.float32)
+        return x, eng.mask.clone()
+
+    def forward_decoder(self, x: Tensor, mask: Tensor):
+        """x [N, dims[-1], h, w], mask [N, L] (0 keep / 1 remove) -> dict modality -> prediction (fcmae.py:249-265).
+        The mask must keep the same number of patches in every sample (what gen_random_mask produces)."""
+        N = x.shape[0]
+        keep = int((mask[0] == 0).sum().item())
+        if not bool(((mask == 0).sum(dim=1) == keep).all()):
+            raise ValueError("forward_decoder: every sample must keep the same number of patches")
+        eng = self._engine = self._get_engine(N, 1.0 - (keep + 0.5) / self.cfg.num_patches)
+        assert eng.keep == keep
+        eng.set_mask(mask)
+        rows = x.permute(0, 2, 3, 1).reshape(N, self.cfg.num_patches, -1)
+        vis = eng.vis.view(N, keep).long()
+        eng.enc_out.copy_(torch.gather(rows, 1, vis[:, :, None].expand(-1, -1, rows.shape[-1]))
+                          .reshape(eng.enc_out.shape).to(eng.enc_out.dtype))
+        eng.run_segment("decoder")
+        return OrderedDict((k, v.to(torch.float32).clone()) for k, v in eng.preds().items())
+
+    def forward_loss(self, imgs_dict: Dict[AnyStr, Tensor], preds: Dict[AnyStr, Tensor], mask: Tensor):
+        """-> (loss, loss_dict, log_vars, normalized_loss_list)  (fcmae.py:267-412)"""
+        N = mask.shape[0]
+        keep = int((mask[0] == 0).sum().item())
+        eng = self._engine = self._get_engine(N, 1.0 - (keep + 0.5) / self.cfg.num_patches)
+        eng.set_mask(mask)
+        for k, dst in eng.inp.items():
+            if k != "sentinel2" or "sentinel2" in preds:
+                dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
+        eng.set_preds(preds)
+        eng.run_segment("loss")
+        return self._loss_outputs(eng, eng.total.clone().reshape(()))
+
+    def _loss_outputs(self, eng, loss):
+        losses = eng.losses.clone()
+        loss_dict = OrderedDict((om.name, losses[i]) for i, om in enumerate(self.cfg.out_mods))
+        if self.cfg.loss_aggr == "uncertainty":
+            return loss, loss_dict, self.loss_fn.log_vars.tolist(), eng.weighted.clone()
+        return loss, loss_dict, None, None
+
     # ------------------------------------------------------------------ forward
     def forward(self, imgs_dict: Dict[AnyStr, Tensor], labels=None, mask_ratio: float = 0.6):
-        imgs_dict = self._crop(imgs_dict)
+        cropped = self._crop(imgs_dict)
+        if cropped is not imgs_dict:         # the reference replaces the caller's dict entries by the cropped tiles
+            for k in cropped:
+                imgs_dict[k] = cropped[k]
         N = imgs_dict["sentinel2"].shape[0]
-        if abs(mask_ratio - self.cfg.mask_ratio) > 1e-12:
-            raise NotImplementedError("call-time mask_ratio must equal the constructor's (engine buffers are sized by it)")
-        eng = self._engine = self._get_engine(N)
+        eng = self._engine = self._get_engine(N, mask_ratio)
         noise = torch.randn(N, self.cfg.num_patches, device=self._device)
         eng.set_inputs(imgs_dict, noise)
         loss = _StepFn.apply(self, None, *self._plist)
         pred = eng.preds()
         mask = eng.mask.clone()
-        losses = eng.losses.clone()
-        loss_dict = OrderedDict((om.name, losses[i]) for i, om in enumerate(self.cfg.out_mods))
-        if self.cfg.loss_aggr == "uncertainty":
-            log_vars = self.loss_fn.log_vars.tolist()
-            normalized = eng.weighted.clone()
-        else:
-            log_vars, normalized = None, None
+        loss, loss_dict, log_vars, normalized = self._loss_outputs(eng, loss)
         return loss, pred, mask, loss_dict, log_vars, normalized
 
 

@@ -1,0 +1,211 @@
+"""GPU tests (-m gpu) of the drop-in boundary: FCMAE.forward_encoder / forward_decoder / forward_loss, call-time
+mask_ratio, gradient accumulation (update_freq) on the fused path, the device-side non-finite guard, and
+main_pretrain.main end to end (train, checkpoint, auto-resume == uninterrupted run, hub consumer)."""
+import os
+import re
+import subprocess
+import sys
+from collections import OrderedDict
+
+import pytest
+import torch
+
+from tests.golden_cases import CASES, case_cfg, case_data
+from tests.test_hip_parity import _engine, _oracle, _rel
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _module(cfg, sd, subset="all_mod", dtype="f32"):
+    from mmearth_train_amd import MODALITIES as MM
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    from mmearth_train_amd.synth import expand_aliases
+    args = default_args(out_modalities=MM.subset(subset))
+    m = fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True, patch_size=8,
+                              img_size=56, args=args, loss_fn=UncertaintyWeightingStrategy(len(cfg.out_mods)),
+                              sparse=True, device="cuda:0", dtype=dtype)
+    m.load_state_dict(expand_aliases(cfg, sd), strict=True)
+    return m
+
+
+def test_forward_pieces_equal_forward_and_oracle():
+    """forward_encoder -> forward_decoder -> forward_loss (fcmae.py:242-412) chained by the caller reproduce
+    forward(): encoder map, every prediction, the 12 losses and the weighted total, all against the oracle."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    model = _module(cfg, sd)
+    dev = {k: v.to("cuda:0") for k, v in inputs.items()}
+    torch.manual_seed(c["nseed"])
+    x, mask = model.forward_encoder(dev["sentinel2"].clone(), 0.6)
+    (oloss, opred, omask, oloss_dict, _, ow), taps, _ = _oracle(cfg, sd, inputs, model._engine.noise.cpu())
+    assert torch.equal(mask.cpu(), omask)
+    assert tuple(x.shape) == (2, 320, 7, 7)
+    assert _rel(x, taps["enc_out"]) < 1e-4
+    pred = model.forward_decoder(x, mask)
+    for k, v in opred.items():
+        assert tuple(pred[k].shape) == tuple(v.shape), k
+        assert _rel(pred[k], v) < 2e-4, k
+    # forward() hands forward_loss the nan_to_num'ed pixel targets (fcmae.py:445-449); a direct caller does the same
+    clean = OrderedDict((k, torch.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0) if k in
+                         ("sentinel2", "sentinel1", "aster", "canopy_height_eth") else v) for k, v in inputs.items())
+    dev = {k: v.to("cuda:0") for k, v in clean.items()}
+    loss, loss_dict, log_vars, normalized = model.forward_loss(dev, pred, mask)
+    assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+    for k, v in oloss_dict.items():
+        assert abs(loss_dict[k].item() - v.item()) <= 1e-4 * abs(v.item()) + 1e-7, k
+    assert len(log_vars) == 12 and torch.allclose(normalized.cpu(), ow.detach(), rtol=1e-4, atol=1e-6)
+    # a caller-made prediction (not the decoder's) goes through forward_loss too: zeros -> the plain target energy
+    zero = OrderedDict((k, torch.zeros_like(v)) for k, v in pred.items())
+    l0, d0, _, _ = model.forward_loss(dev, zero, mask)
+    op = OrderedDict((k, torch.zeros_like(v)) for k, v in opred.items())
+    from oracle import mpmae_ref as O
+    ref0 = O.forward_loss(OrderedDict((k, v.clone()) for k, v in sd.items()), clean, op, omask, cfg)
+    assert abs(l0.item() - ref0[0].item()) <= 1e-4 * abs(ref0[0].item())
+
+
+@pytest.mark.parametrize("ratio", [0.75, 0.3])
+def test_call_time_mask_ratio_decides_len_keep(ratio):
+    """fcmae.py:415,451 (quirk q9): the constructor's mask_ratio is only stored; forward(mask_ratio=r) keeps int(L(1-r))."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    model = _module(cfg, sd)                               # constructed with 0.6
+    torch.manual_seed(5)
+    loss, pred, mask, loss_dict, _, _ = model({k: v.to("cuda:0") for k, v in inputs.items()}, mask_ratio=ratio)
+    keep = int(49 * (1 - ratio))
+    assert ((mask == 0).sum(1) == keep).all()
+    from mmearth_train_amd.config import make_cfg
+    import dataclasses
+    ocfg = dataclasses.replace(cfg, mask_ratio=ratio)
+    (oloss, opred, omask, _, _, _), _, grads = _oracle(ocfg, sd, inputs, model._engine.noise.cpu())
+    assert torch.equal(mask.cpu(), omask)
+    assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+    assert _rel(pred["sentinel2"], opred["sentinel2"]) < 2e-4
+    loss.backward()
+    g = dict(model.named_parameters())["encoder.stages.1.0.pwconv1.linear.weight"].grad
+    assert _rel(g, grads["encoder.stages.1.0.pwconv1.linear.weight"]) < 2e-4
+    assert len(model._engines) == 1 and (2, keep) in model._engines
+
+
+@pytest.mark.parametrize("mode", ["program", "eager"])
+def test_update_freq_accumulates_in_the_flat_gradient_buffer(mode):
+    """--update_freq 2 on the fused path: two micro-steps on different batches, loss / 2 each, ONE AdamW."""
+    from mmearth_train_amd import dist as mdist
+    from mmearth_train_amd.synth import make_inputs
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    inputs2, noise2 = make_inputs(cfg, c["N"], seed=77)
+    ref = _engine(cfg, c["N"], "f32", sd, inputs, noise, lanes=False)
+    ref.forward(loss_scale=0.5); ref.backward(zero_grad=True)
+    ref.set_inputs(inputs2, noise2)
+    ref.forward(loss_scale=0.5); ref.backward(zero_grad=False)
+    torch.cuda.synchronize()
+    g_ref = ref.gflat.clone()
+    ref.optimizer_step(1e-3)
+    eng = _engine(cfg, c["N"], "f32", sd, inputs, noise)
+    run = mdist.StepRunner(eng, world_size=1, lr=1e-3, mode=mode, update_freq=2)
+    p0 = eng.pflat.clone()
+    assert run.step() is False
+    torch.cuda.synchronize()
+    assert torch.equal(eng.pflat, p0)                       # no update on the first micro-step
+    eng.set_inputs(inputs2, noise2)
+    assert run.step() is True
+    torch.cuda.synchronize()
+    assert _rel(eng.gflat, g_ref) < 2e-5
+    assert _rel(eng.pflat, ref.pflat) < 2e-5 and not torch.equal(eng.pflat, p0)
+    # next window starts from a zeroed buffer
+    run.step(); torch.cuda.synchronize()
+    ref.set_inputs(inputs2, noise2); ref.forward(loss_scale=0.5); ref.backward(zero_grad=True); torch.cuda.synchronize()
+    assert _rel(eng.gflat, ref.gflat) < 1e-3               # (parameters differ by one AdamW step's rounding only)
+
+
+def test_non_finite_loss_skips_the_update_on_the_device():
+    """engine_pretrain.py:83-85 stops before the optimizer on a non-finite loss; the fused path has no host sync
+    there, so the device guard (mpmae_hp_fetch -> hp[4]) must leave parameters and moments untouched."""
+    from mmearth_train_amd import dist as mdist
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], "bf16", sd, inputs, noise)
+    run = mdist.StepRunner(eng, world_size=1, lr=1e-3, mode="program")
+    run.step(); torch.cuda.synchronize()
+    assert run.skipped_steps() == 0
+    p1, m1, v1 = eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone()
+    bad = OrderedDict((k, v.clone()) for k, v in inputs.items())
+    bad["sentinel2"][0, 0] = float("inf")                    # every visible patch of sample 0; reaches the encoder (fcmae.py:439: imgs taken before nan_to_num)
+    eng.set_inputs(bad, noise)
+    run.step(); torch.cuda.synchronize()
+    assert not torch.isfinite(eng.total).all()
+    assert run.skipped_steps() == 1
+    assert torch.equal(eng.pflat, p1) and torch.equal(eng.mflat, m1) and torch.equal(eng.vflat, v1)
+    eng.set_inputs(inputs, noise)
+    run.step(); torch.cuda.synchronize()
+    assert torch.isfinite(eng.total).all() and torch.isfinite(eng.pflat).all() and not torch.equal(eng.pflat, p1)
+
+
+def _main(argv):
+    import main_pretrain
+    return main_pretrain.main(main_pretrain.get_args_parser().parse_args(argv))
+
+
+def test_main_pretrain_trains_checkpoints_and_auto_resumes(tmp_path):
+    """main_pretrain.main end to end on synthetic tiles: 2 epochs in one go == 1 epoch + auto-resumed second epoch
+    (model and fused-AdamW state), update_freq 2; the checkpoint loads into a stock torch.optim.AdamW and into hubconf.MPMAE."""
+    common = ["--model", "convnextv2_atto", "--input_size", "56", "--patch_size", "8", "--batch_size", "4", "--update_freq", "2",
+              "--steps_per_epoch", "4", "--lr", "1e-3", "--min_lr", "1e-3", "--warmup_epochs", "0", "--norm_pix_loss", "True",
+              "--compute_dtype", "f32", "--seed", "3"]
+    a, b = tmp_path / "a", tmp_path / "b"
+    _main(common + ["--epochs", "2", "--output_dir", str(a)])
+    _main(common + ["--epochs", "1", "--output_dir", str(b)])
+    assert (b / "checkpoint-0.pth").exists()
+    _main(common + ["--epochs", "2", "--output_dir", str(b), "--auto_resume", "True"])
+    ca = torch.load(a / "checkpoint-1.pth", map_location="cpu", weights_only=False)
+    cb = torch.load(b / "checkpoint-1.pth", map_location="cpu", weights_only=False)
+    assert ca["epoch"] == cb["epoch"] == 1 and set(ca) == {"model", "optimizer", "epoch", "scaler", "args"}
+    assert len(ca["model"]) == 290
+    for k in ca["model"]:
+        assert _rel(cb["model"][k], ca["model"][k]) < 1e-4, k
+    sa, sb = ca["optimizer"]["state"], cb["optimizer"]["state"]
+    assert len(sa) == len(sb) == 180 and float(sa[0]["step"]) == float(sb[0]["step"]) == 4.0      # 2 epochs x 4 micro-steps / 2
+    for i in (0, 5, 100, 179):
+        assert _rel(sb[i]["exp_avg"], sa[i]["exp_avg"]) < 1e-3
+    c0 = torch.load(a / "checkpoint-0.pth", map_location="cpu", weights_only=False)
+    assert _rel(c0["model"]["proj.weight"], ca["model"]["proj.weight"]) > 1e-4                    # it did train
+    # consumers: torch AdamW built the reference's way (helpers.auto_load_model), and the hub entry point
+    from mmearth_train_amd.helpers import param_groups_weight_decay
+    from tests.test_boundary_host import _model
+    m = _model(device="cuda:0", dtype="f32")
+    m.load_state_dict(ca["model"], strict=True)
+    opt = torch.optim.AdamW(param_groups_weight_decay(m, 0.05), lr=1e-3, betas=(0.9, 0.95))
+    opt.load_state_dict(ca["optimizer"])
+    import hubconf
+    dense = hubconf.MPMAE("convnextv2_atto", ckpt_name=str(a / "checkpoint-1.pth"), num_classes=4)
+    assert torch.equal(dense.state_dict()["stages.3.1.pwconv2.weight"], ca["model"]["encoder.stages.3.1.pwconv2.linear.weight"])
+
+
+def test_main_pretrain_torch_autograd_path(tmp_path):
+    """--fast_path False: FCMAE.forward + loss.backward() + torch.optim.AdamW (update_freq 2), one epoch."""
+    stats = _main(["--model", "convnextv2_atto", "--input_size", "56", "--patch_size", "8", "--batch_size", "2", "--update_freq", "2",
+                   "--steps_per_epoch", "4", "--epochs", "1", "--lr", "1e-3", "--norm_pix_loss", "True", "--fast_path", "False",
+                   "--out_modalities", "pix_mod", "--output_dir", str(tmp_path)])
+    assert torch.isfinite(torch.tensor(stats[0]["loss"]))
+    ck = torch.load(tmp_path / "checkpoint-0.pth", map_location="cpu", weights_only=False)
+    assert len(ck["optimizer"]["state"]) > 0
+
+
+def test_two_rank_step_driver_with_update_freq_2(tmp_path):
+    """world 2 x update_freq 2 through the real driver (two processes on cuda:0 over gloo): the exchange happens once
+    per window, on the accumulated buffer; both ranks end equal and match the hand-averaged single-process run."""
+    env = dict(os.environ, DDP_PROBE_UPDATE_FREQ="2")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_probe.py"), str(tmp_path)], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for mode in ("program", "eager"):
+        m = re.search(mode + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
+        assert m and float(m.group(1)) < 1e-5, r.stdout
+        assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout

@@ -1,0 +1,369 @@
+"""GPU unit tests (-m gpu) of the bf16 PRODUCTION kernels the benchmark runs, each through the C ABI against
+plain torch fp32 computed on the same bf16-rounded operands. The launch records are taken
+from a real Engine (same tilings / kernel selections as the step), re-pointed at test-owned tensors:
+
+  mpmae_dwconv7_fwd      every (stage S = 8/4/2/1, dense decoder) forward and data-gradient (flip, add) record
+  mpmae_dwconv7_wgrad    every stage's record (v5 S >= 2, v6s1 S = 1, dense decoder)
+  mpmae_loss_multi       fwd + bwd, all three kinds, NaN targets / -1 labels / norm_pix, vs autograd of the oracle's losses
+  mpmae_ln_fwd / _bwd (+ _down) with dt = 1, mpmae_colstats, mpmae_pool_rows, mpmae_fill_mask_token,
+  the non-direct-to-LDS NT GEMM and the SCATTER_ROWS epilogue.
+
+Tolerance convention: a stored bf16 tensor may differ from round_bf16(fp32 reference) by ~1 ulp of the value plus a
+small absolute slack relative to the tensor's scale (cancellation): |got - ref| <= 2^-7 |ref| + 2^-9 max|ref|.
+fp32 reductions of bf16 data: 2e-4 relative to the max-norm.
+"""
+import copy
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+bf = torch.bfloat16
+DEV = "cuda:0"
+
+
+def _st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def _assert_bf16_close(got, ref32, what="", ulps=1.0):
+    ref = ref32.float()
+    err = (got.float() - ref).abs()
+    tol = ulps * (2.0 ** -7) * ref.abs() + (2.0 ** -9) * ref.abs().max()
+    bad = err > tol
+    assert not bad.any(), (what, int(bad.sum()), float((err - tol).max()), float(ref.abs().max()))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    """A small all_mod atto bf16 engine with some all-zero visible pixels (activity bits), masks generated."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.engine import Engine
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg()
+    N = 6
+    e = Engine(cfg, N, dtype="bf16", device=DEV)
+    e.load_state_dict(make_state_dict(cfg, seed=21))
+    inputs, noise = make_inputs(cfg, N, seed=22)
+    z = torch.rand(N, 1, 56, 56, generator=torch.Generator().manual_seed(23)) < 0.06
+    inputs["sentinel2"] = inputs["sentinel2"] * (~z)
+    e.set_inputs(inputs, noise)
+    names = [o[0] for o in e.fwd_ops]
+    e._run(e.fwd_ops[:names.index("stem:im2col")], e._stream())        # prep, mask, activity maps
+    torch.cuda.synchronize()
+    e.test_inputs = inputs
+    return e
+
+
+def _rows_to_map(e, rows, S, sparse):
+    """[M, C] compacted rows -> dense [N, C, g*S, g*S] map (zeros at masked patches)."""
+    N, g = e.N, e.grid
+    Cc = rows.shape[1]
+    if not sparse:
+        return rows.float().view(N, g, g, Cc).permute(0, 3, 1, 2).contiguous()
+    keep = e.keep
+    x = rows.float().view(N, keep, S, S, Cc)
+    out = torch.zeros(N, g, S, g, S, Cc, device=rows.device)
+    vis = e.vis.view(N, keep).long()
+    n_idx = torch.arange(N, device=rows.device)[:, None].expand(N, keep)
+    out[n_idx, vis // g, :, vis % g, :, :] = x
+    return out.view(N, g * S, g * S, Cc).permute(0, 3, 1, 2).contiguous()
+
+
+def _map_to_rows(e, m, S, sparse):
+    N, g = e.N, e.grid
+    Cc = m.shape[1]
+    if not sparse:
+        return m.permute(0, 2, 3, 1).reshape(N * g * g, Cc)
+    keep = e.keep
+    v = m.permute(0, 2, 3, 1).view(N, g, S, g, S, Cc)
+    vis = e.vis.view(N, keep).long()
+    n_idx = torch.arange(N, device=m.device)[:, None].expand(N, keep)
+    return v[n_idx, vis // g, :, vis % g, :, :].reshape(N * keep * S * S, Cc)
+
+
+def _dense_dw_weight(e, blk):
+    """torch conv2d weight [C, 1, kh, kw] of a block's depthwise kernel (ME layout rule helpers.py:676-687)."""
+    w, _, b, _, _ = e._dw_weight(blk)
+    if blk["sparse"]:
+        return w.view(7, 7, -1).permute(2, 1, 0).unsqueeze(1).contiguous(), b.reshape(-1)      # K[kw*7+kh, c]
+    return w.clone(), b.reshape(-1)
+
+
+def _blocks(e):
+    out, seen = [], set()
+    for blk in e.blocks + [e.dec]:
+        key = (blk["stage"], blk["C"])
+        if key not in seen:
+            seen.add(key)
+            out.append(blk)
+    return out
+
+
+def test_depthwise7_forward_and_data_gradient_every_stage(eng):
+    e, lib = eng, eng.lib
+    ops = {o[0]: o for o in e.fwd_ops + e.bwd_ops}
+    for blk in _blocks(e):
+        tag, M, Cc = blk["prefix"], blk["M"], blk["C"]
+        S = 1 if blk["stage"] is None else e.S[blk["stage"]]
+        act = e.act[blk["stage"]] if blk["sparse"] else None
+        live = act.bool()[:, None] if act is not None else torch.ones(M, 1, dtype=torch.bool, device=DEV)
+        Wd, bias = _dense_dw_weight(e, blk)
+        torch.manual_seed(M + Cc)
+        for which in (":dw", ":dw.dgrad"):
+            name, fn, args, _ = ops[tag + which]
+            assert fn is lib.mpmae_dwconv7_fwd
+            a = copy.copy(args[1]._obj)
+            x = (torch.randn(M, Cc, device=DEV) * 1.3).to(bf) * live
+            add = (torch.randn(M, Cc, device=DEV)).to(bf) * live if a.add else None
+            out = torch.full((M, Cc), 7.0, device=DEV, dtype=bf)
+            a.x, a.out, a.add = x.data_ptr(), out.data_ptr(), (add.data_ptr() if add is not None else 0)
+            assert bool(a.flip) == (which == ":dw.dgrad") and bool(a.add) == (which == ":dw.dgrad")
+            assert lib.mpmae_dwconv7_fwd(1, C.byref(a), _st()) == 0
+            xm = _rows_to_map(e, x, S, blk["sparse"])
+            if a.flip:        # data gradient of the cross-correlation: correlate with the flipped kernel, no bias, + residual
+                ym = F.conv2d(xm, Wd.flip(2, 3), None, padding=3, groups=Cc)
+            else:
+                ym = F.conv2d(xm, Wd, bias, padding=3, groups=Cc)
+            ref = _map_to_rows(e, ym, S, blk["sparse"])
+            if add is not None:
+                ref = ref + add.float()
+            ref = ref * live
+            _assert_bf16_close(out, ref, what=name)
+            assert (out[~live[:, 0]] == 0).all(), name        # inactive rows are written as zeros
+
+
+def test_depthwise7_weight_gradient_every_stage(eng):
+    e, lib = eng, eng.lib
+    ops = {o[0]: o for o in e.bwd_ops}
+    for blk in _blocks(e):
+        tag, M, Cc = blk["prefix"], blk["M"], blk["C"]
+        S = 1 if blk["stage"] is None else e.S[blk["stage"]]
+        act = e.act[blk["stage"]] if blk["sparse"] else None
+        live = act.bool()[:, None] if act is not None else torch.ones(M, 1, dtype=torch.bool, device=DEV)
+        name, fn, args, _ = ops[tag + ":dw.wgrad"]
+        assert fn is lib.mpmae_dwconv7_wgrad
+        a = copy.copy(args[1]._obj)
+        torch.manual_seed(3 * M + Cc)
+        x = torch.randn(M, Cc, device=DEV).to(bf) * live
+        dd = (torch.randn(M, Cc, device=DEV) * 0.2).to(bf) * live
+        wshape = (49, Cc) if blk["sparse"] else (Cc, 1, 7, 7)
+        dw = torch.zeros(wshape, device=DEV)
+        db = torch.zeros(Cc, device=DEV)
+        ws = torch.empty(32 << 20, device=DEV)
+        a.x, a.dd, a.dw, a.db, a.ws, a.ws_floats = x.data_ptr(), dd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel()
+        assert lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], _st()) == 0
+        xm = F.pad(_rows_to_map(e, x, S, blk["sparse"]), (3, 3, 3, 3))
+        dm = _rows_to_map(e, dd, S, blk["sparse"])
+        Hh = dm.shape[-1]
+        ref = torch.stack([torch.stack([(dm * xm[:, :, kh:kh + Hh, kw:kw + Hh]).sum((0, 2, 3)) for kw in range(7)], 1)
+                           for kh in range(7)], 1)                                 # [C, kh, kw]
+        got = dw.view(7, 7, Cc).permute(2, 1, 0) if blk["sparse"] else dw.view(Cc, 7, 7)
+        assert _rel(got, ref) < 2e-4, name
+        assert _rel(db, dd.float().sum(0)) < 2e-4, name
+        # accumulation semantics: a second launch adds
+        assert lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], _st()) == 0
+        assert _rel(got, 2 * ref) < 2e-4, name
+
+
+def test_loss_kernels_forward_and_backward_match_oracle_autograd(eng):
+    """One launch per loss kind (mpmae_loss_multi) on random bf16 predictions; the oracle's loss functions on the
+    SAME bf16-rounded predictions give the values, and their autograd the prediction gradients."""
+    from oracle import mpmae_ref as O
+    e, lib, cfg = eng, eng.lib, eng.cfg
+    torch.manual_seed(77)
+    e.pred_pix.copy_((torch.randn(e.pred_pix.shape, device=DEV) * 1.5).to(bf))
+    e.pred_img.zero_()
+    e.pred_img[:, :e.Wimg] = (torch.randn(e.N, e.Wimg, device=DEV) * 1.5).to(bf)
+    e.loss_acc.zero_()
+    names = [o[0] for o in e.fwd_ops]
+    loss_ops = [o for o in e.fwd_ops if o[0].startswith("loss:")]
+    assert len(loss_ops) == 3
+    e._run(loss_ops, e._stream())
+    e.finalize_loss(e._stream(), False, 1.0)
+    torch.cuda.synchronize()
+    preds = OrderedDict((k, v.float().cpu().clone().requires_grad_(True)) for k, v in e.preds().items())
+    clean = OrderedDict((k, torch.nan_to_num(v, nan=0.0, posinf=0.0, neginf=0.0) if k in
+                         ("sentinel2", "sentinel1", "aster", "canopy_height_eth") else v) for k, v in e.test_inputs.items())
+    sd = OrderedDict((k, v.detach().float().cpu().clone()) for k, v in e.params.items())
+    oloss, odict, _, ow = O.forward_loss(sd, clean, preds, e.mask.cpu(), cfg)
+    for i, om in enumerate(cfg.out_mods):
+        assert abs(e.losses[i].item() - odict[om.name].item()) <= 2e-5 * abs(odict[om.name].item()) + 1e-7, om.name
+    assert abs(e.total.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
+    # backward: d total / d pred
+    oloss.backward()
+    e.dpred_pix.fill_(7.0)
+    e.dpred_img.fill_(7.0)
+    e.finalize_loss(e._stream(), True, 1.0)
+    e._run([o for o in e.bwd_ops if o[0].startswith("dloss:")], e._stream())
+    torch.cuda.synchronize()
+    N, L, g = e.N, e.L, e.grid
+    for om in cfg.out_mods:
+        c = e.head_cols[om.name]
+        if om.kind.startswith("pix"):
+            got = e.dpred_pix[:, c:c + om.head_out].reshape(N, L, om.head_out).permute(0, 2, 1).reshape(N, om.head_out, g, g)
+        else:
+            got = e.dpred_img[:, c:c + om.head_out]
+        ref = preds[om.name].grad.to(DEV)
+        assert torch.isfinite(got.float()).all(), om.name
+        _assert_bf16_close(got, ref, what="dpred " + om.name, ulps=1.5)
+        assert ref.abs().max() > 0, om.name
+
+
+@pytest.mark.parametrize("M,Cc,act_fn", [(1000, 160, 0), (999, 512, 0), (4864, 320, 0), (777, 40, 1), (1216, 80, 0)])
+def test_layernorm_bf16_forward_backward(M, Cc, act_fn):
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(M + Cc)
+    rowmask = (torch.rand(M, device=DEV) > 0.15).to(torch.uint8)
+    live = rowmask.bool()[:, None]
+    x = (torch.randn(M, Cc, device=DEV) * 1.7 + 0.4).to(bf) * live
+    g, b = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV) * 0.2
+    xhat, y = torch.empty(M, Cc, device=DEV, dtype=bf), torch.empty(M, Cc, device=DEV, dtype=bf)
+    rstd = torch.empty(M, device=DEV)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.mpmae_ln_fwd(1, P(x), P(xhat), P(rstd), P(y), P(g), P(b), act_fn, 1e-6, M, Cc, P(rowmask), _st()) == 0
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    mu = xr.mean(1, keepdim=True)
+    r = torch.rsqrt(((xr - mu) ** 2).mean(1, keepdim=True) + 1e-6)
+    xh = (xr - mu) * r
+    yr = xh * gr + br
+    if act_fn:
+        yr = 0.5 * yr * (1 + torch.erf(yr / math.sqrt(2)))
+    yr = yr * live
+    _assert_bf16_close(xhat, (xh * live).detach(), "xhat")
+    _assert_bf16_close(y, yr.detach(), "y", ulps=1.5)
+    assert _rel(rstd, (r[:, 0] * live[:, 0]).detach()) < 1e-5
+    dy = (torch.randn(M, Cc, device=DEV) * 0.3).to(bf) * live
+    dx = torch.empty(M, Cc, device=DEV, dtype=bf)
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ws = torch.empty(8 << 20, device=DEV)
+    assert lib.mpmae_ln_bwd(1, P(dy), 1, 1.0, P(xhat), P(rstd), P(g), P(b), act_fn, P(dx), 0, P(dg), P(db), M, Cc, P(rowmask),
+                            P(ws), ws.numel(), _st()) == 0
+    # reference from the kernel's own stored x-hat (what the backward reads)
+    xs = xhat.float().clone()
+    gq = dy.float()
+    if act_fn:
+        pre = xs * g + b
+        gq = gq * (0.5 * (1 + torch.erf(pre / math.sqrt(2))) + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi))
+    gg = gq * g
+    ref_dx = rstd[:, None] * (gg - gg.mean(1, keepdim=True) - xs * (gg * xs).mean(1, keepdim=True)) * live
+    _assert_bf16_close(dx, ref_dx, "dx", ulps=1.5)
+    assert _rel(dg, (gq * xs).sum(0)) < 3e-4 and _rel(db, gq.sum(0)) < 3e-4
+
+
+@pytest.mark.parametrize("NK,S,Cc", [(12, 8, 40), (12, 4, 80), (30, 2, 160)])
+def test_grouped_layernorm_bf16(NK, S, Cc):
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    M = NK * S * S
+    torch.manual_seed(NK + S + Cc)
+    act = (torch.rand(M, device=DEV) > 0.2).to(torch.uint8)
+    live = act.bool()[:, None]
+    x = (torch.randn(M, Cc, device=DEV) * 1.3).to(bf) * live
+    g, b = torch.rand(Cc, device=DEV) + 0.5, torch.randn(Cc, device=DEV) * 0.1
+    xhat, rstd = torch.empty(M, Cc, device=DEV, dtype=bf), torch.empty(M, device=DEV)
+    yg = torch.full((M // 4, 4 * Cc), 9.0, device=DEV, dtype=bf)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.mpmae_ln_fwd_down(1, P(x), P(xhat), P(rstd), P(yg), P(g), P(b), 1e-6, M, Cc, S, P(act), _st()) == 0
+    xf = x.float()
+    mu = xf.mean(1, keepdim=True)
+    xh = (xf - mu) * torch.rsqrt(((xf - mu) ** 2).mean(1, keepdim=True) + 1e-6)
+    y = (xh * g + b) * live
+    ref = y.view(NK, S // 2, 2, S // 2, 2, Cc).permute(0, 1, 3, 4, 2, 5).reshape(M // 4, 4 * Cc)
+    _assert_bf16_close(yg, ref, "y grouped", ulps=1.5)
+    _assert_bf16_close(xhat, xh * live, "xhat")
+    dyg = (torch.randn(M // 4, 4 * Cc, device=DEV) * 0.3).to(bf)
+    dx = torch.empty(M, Cc, device=DEV, dtype=bf)
+    dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ws = torch.empty(4 << 20, device=DEV)
+    assert lib.mpmae_ln_bwd_down(1, P(dyg), P(xhat), P(rstd), P(g), P(dx), P(dg), P(db), M, Cc, S, P(act), P(ws), ws.numel(),
+                                 _st()) == 0
+    dy = dyg.float().view(NK, S // 2, S // 2, 2, 2, Cc).permute(0, 1, 4, 2, 3, 5).reshape(M, Cc) * live
+    xs = xhat.float()
+    gg = dy * g
+    ref_dx = rstd[:, None] * (gg - gg.mean(1, keepdim=True) - xs * (gg * xs).mean(1, keepdim=True)) * live
+    _assert_bf16_close(dx, ref_dx, "dx", ulps=1.5)
+    assert _rel(dg, (dy * xs).sum(0)) < 3e-4 and _rel(db, dy.sum(0)) < 3e-4
+
+
+@pytest.mark.parametrize("M,H,rpg", [(49 * 6, 2048, 49), (1000, 640, 1000), (4864, 1280, 4864)])
+def test_column_statistics_bf16(M, H, rpg):
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(M + H)
+    G = M // rpg
+    h = torch.randn(M, H, device=DEV).to(bf)
+    dz = (torch.randn(M, H, device=DEV) * 0.2).to(bf)
+    ws = torch.empty(16 << 20, device=DEV)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    s0 = torch.zeros(G, H, device=DEV)
+    assert lib.mpmae_colstats(1, P(h), None, 0, P(s0), None, M, H, rpg, P(ws), ws.numel(), _st()) == 0
+    hf = h.float()
+    ge = 0.5 * hf * (1 + torch.erf(hf / math.sqrt(2)))
+    assert _rel(s0, (ge ** 2).view(G, rpg, H).sum(1)) < 5e-4            # polynomial GELU: 3.1e-5 absolute per element
+    t0, t1 = torch.zeros(G, H, device=DEV), torch.zeros(G, H, device=DEV)
+    assert lib.mpmae_colstats(1, P(h), P(dz), 1, P(t0), P(t1), M, H, rpg, P(ws), ws.numel(), _st()) == 0
+    assert _rel(t0, dz.float().view(G, rpg, H).sum(1)) < 2e-4
+    assert _rel(t1, (dz.float() * ge).view(G, rpg, H).sum(1)) < 5e-4
+
+
+def test_pool_rows_and_mask_token_bf16(eng):
+    e, lib = eng, eng.lib
+    N, L, D = e.N, e.L, e.D
+    torch.manual_seed(5)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    x = torch.randn(N * L, D, device=DEV).to(bf)
+    pooled = torch.empty(N, D, device=DEV, dtype=bf)
+    assert lib.mpmae_pool_rows(1, P(x), P(pooled), N, L, D, _st()) == 0
+    _assert_bf16_close(pooled, x.float().view(N, L, D).mean(1), "pool")
+    tok = torch.randn(D, device=DEV)
+    xd = x.clone()
+    assert lib.mpmae_fill_mask_token(1, P(xd), P(tok), P(e.inv), N * L, D, _st()) == 0
+    masked = (e.inv.view(-1) < 0)[:, None]
+    ref = torch.where(masked, tok.to(bf)[None, :].expand(N * L, D), x)
+    assert torch.equal(xd, ref)
+    dtok = torch.zeros(D, device=DEV)
+    assert lib.mpmae_mask_token_bwd(1, P(x), P(e.inv), P(dtok), N * L, D, _st()) == 0
+    assert _rel(dtok, (x.float() * masked).sum(0)) < 2e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1200, 512, 320), (114, 512, 320), (3000, 160, 320), (700, 2816, 512), (6, 896, 512)])
+def test_nt_gemm_register_staged_variant_and_scatter_rows(M, N, K, eng):
+    """M < 4096 (or K % 64 != 0) keeps mpmae_gemm on the register-staged NT kernel; EPI_SCATTER_ROWS (the `proj`
+    launch: compacted stage-3 rows -> dense [N*L, D] decoder grid rows, engine.py `proj`) is checked on the engine's tables."""
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=DEV).to(bf)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(bf)
+    bias = torch.randn(N, device=DEV)
+    c = torch.empty(M, N, device=DEV, dtype=bf)
+    g = L.GemmArgs()
+    g.A, g.B, g.bias, g.C = a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr()
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
+    assert lib.mpmae_gemm(1, L.PRO["NONE"], L.EPI["STORE"], C.byref(g), _st()) == 0
+    ref = a.float() @ w.float().t() + bias
+    _assert_bf16_close(c, ref, "nt gemm", ulps=1.5)
+    e = eng
+    if M == 114 and K == 320:
+        assert M == e.M[3]
+        dst = torch.full((e.N * e.L, N), 3.0, device=DEV, dtype=bf)
+        g.C, g.vis, g.keep, g.L = dst.data_ptr(), e.vis.data_ptr(), e.keep, e.L
+        assert lib.mpmae_gemm(1, L.PRO["NONE"], L.EPI["SCATTER_ROWS"], C.byref(g), _st()) == 0
+        vis = e.vis.view(e.N, e.keep).long()
+        rows = (torch.arange(e.N, device=DEV)[:, None] * e.L + vis).reshape(-1)
+        _assert_bf16_close(dst[rows], ref, "scatter rows", ulps=1.5)
+        other = torch.ones(e.N * e.L, dtype=torch.bool, device=DEV)
+        other[rows] = False
+        assert (dst[other] == 3.0).all()            # masked positions are left to mpmae_fill_mask_token

@@ -21,17 +21,22 @@ def build(rank, N=8):
     return eng
 
 
+UF = int(os.environ.get("DDP_PROBE_UPDATE_FREQ", "1"))      # > 1: gradient accumulation over UF micro-steps per update
+
+
 def worker(rank, world, mode, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     from mmearth_train_amd import dist as mdist
     eng = build(rank)
-    run = mdist.StepRunner(eng, world_size=world, lr=1e-3, mode=mode)
-    run.step()
+    run = mdist.StepRunner(eng, world_size=world, lr=1e-3, mode=mode, update_freq=UF)
+    for _ in range(UF):
+        run.step()
     torch.cuda.synchronize()
     torch.save(eng.gflat.cpu() / world, f"{out}/g{rank}_{mode}.pt")      # all-reduced (summed) gradients of step 1
-    run.step()
+    for _ in range(UF):
+        run.step()
     torch.cuda.synchronize()
     torch.save(eng.pflat.cpu(), f"{out}/p{rank}_{mode}.pt")
     dist.barrier()
@@ -47,8 +52,10 @@ if __name__ == "__main__":
     gref = None
     for t in (1, 2):
         gs = []
-        for e in engs:
-            e.forward(); e.backward(); gs.append(e.gflat.clone())
+        for e in engs:      # UF identical micro-steps of loss / UF accumulate to the plain gradient
+            for u in range(UF):
+                e.forward(loss_scale=1.0 / UF); e.backward(zero_grad=(u == 0))
+            gs.append(e.gflat.clone())
         g = (gs[0] + gs[1]) / 2
         if gref is None:
             gref = g.cpu().clone()
