@@ -136,16 +136,20 @@ def test_non_finite_loss_skips_the_update_on_the_device():
     run.step(); torch.cuda.synchronize()
     assert run.skipped_steps() == 0
     p1, m1, v1 = eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone()
-    bad = OrderedDict((k, v.clone()) for k, v in inputs.items())
-    bad["sentinel2"][0, 0] = float("inf")                    # every visible patch of sample 0; reaches the encoder (fcmae.py:439: imgs taken before nan_to_num)
-    eng.set_inputs(bad, noise)
+    # a diverged run: one uncertainty weight overflowed -> exp(-s) L + s = inf. (A NaN/inf *pixel* does not do it in bf16
+    # mode: the packed polynomial GELU clamps through v_med3_f32, which returns a finite value for a NaN input.)
+    lv = eng.params["loss_fn.log_vars"]
+    keep0 = lv[0].clone()
+    lv[0] = float("inf")
+    p1, m1, v1 = eng.pflat.clone(), eng.mflat.clone(), eng.vflat.clone()
     run.step(); torch.cuda.synchronize()
     assert not torch.isfinite(eng.total).all()
     assert run.skipped_steps() == 1
     assert torch.equal(eng.pflat, p1) and torch.equal(eng.mflat, m1) and torch.equal(eng.vflat, v1)
+    lv[0] = keep0
     eng.set_inputs(inputs, noise)
     run.step(); torch.cuda.synchronize()
-    assert torch.isfinite(eng.total).all() and torch.isfinite(eng.pflat).all() and not torch.equal(eng.pflat, p1)
+    assert torch.isfinite(eng.total).all() and torch.isfinite(eng.pflat).all() and not torch.equal(eng.pflat[:1000], p1[:1000])
 
 
 def _main(argv):

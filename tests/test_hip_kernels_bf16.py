@@ -12,7 +12,6 @@ Tolerance convention: a stored bf16 tensor may differ from round_bf16(fp32 refer
 small absolute slack relative to the tensor's scale (cancellation): |got - ref| <= 2^-7 |ref| + 2^-9 max|ref|.
 fp32 reductions of bf16 data: 2e-4 relative to the max-norm.
 """
-import copy
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -122,7 +121,7 @@ def test_depthwise7_forward_and_data_gradient_every_stage(eng):
         for which in (":dw", ":dw.dgrad"):
             name, fn, args, _ = ops[tag + which]
             assert fn is lib.mpmae_dwconv7_fwd
-            a = copy.copy(args[1]._obj)
+            a = type(args[1]._obj).from_buffer_copy(args[1]._obj)
             x = (torch.randn(M, Cc, device=DEV) * 1.3).to(bf) * live
             add = (torch.randn(M, Cc, device=DEV)).to(bf) * live if a.add else None
             out = torch.full((M, Cc), 7.0, device=DEV, dtype=bf)
@@ -152,7 +151,7 @@ def test_depthwise7_weight_gradient_every_stage(eng):
         live = act.bool()[:, None] if act is not None else torch.ones(M, 1, dtype=torch.bool, device=DEV)
         name, fn, args, _ = ops[tag + ":dw.wgrad"]
         assert fn is lib.mpmae_dwconv7_wgrad
-        a = copy.copy(args[1]._obj)
+        a = type(args[1]._obj).from_buffer_copy(args[1]._obj)
         torch.manual_seed(3 * M + Cc)
         x = torch.randn(M, Cc, device=DEV).to(bf) * live
         dd = (torch.randn(M, Cc, device=DEV) * 0.2).to(bf) * live
