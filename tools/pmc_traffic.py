@@ -4,7 +4,7 @@ usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.c
 FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B
 (MI355X_MICROARCH.md, HBM section), so it is doubled. Values are averages per launch.
 """
-import csv, sys, json, collections
+import csv, sys, json, collections, subprocess, os
 
 
 def per_kernel(path, counter):
@@ -25,7 +25,12 @@ for k in sorted(set(fetch) | set(write)):
     w, nw = write.get(k, (0.0, 0))
     out[k] = dict(fetch_bytes=round(f * 1024 * 2), write_bytes=round(w * 1024), launches_sampled=max(nf, nw),
                   traffic_bytes=round(f * 1024 * 2 + w * 1024))
+try:
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                            cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip() or os.environ.get("MPMAE_COMMIT", "n/a")
+except Exception:
+    commit = os.environ.get("MPMAE_COMMIT", "n/a")
 json.dump(dict(note="avg per launch; fetch doubled per the gfx950 FETCH_SIZE correction; separate --pmc passes",
-               kernels=out), open(sys.argv[3], "w"), indent=1)
+               meta=dict(commit=commit), kernels=out), open(sys.argv[3], "w"), indent=1)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches_sampled"])[:30]:
     print(f"{k[:70]:70s} {d['launches_sampled']:5d} launches  fetch {d['fetch_bytes'] / 1e6:8.1f} MB  write {d['write_bytes'] / 1e6:8.1f} MB")
