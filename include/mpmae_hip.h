@@ -221,6 +221,53 @@ int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits,
                 mpmae_stream_t stream);
 
+/* ---- MX-fp8 pointwise path (BASELINE configs[4]: "fp8 MFMA pointwise path") ------------------
+ * The nn.Linear / 1x1-conv layers with K % 128 == 0 (decoder Block pwconv1/2 forward and data gradient,
+ * convnextv2.py:46-52) on v_mfma_scale_f32_16x16x128_f8f6f4: operands are OCP e4m3 bytes with one E8M0 scale per 32
+ * consecutive k (OCP MX v1.0 block format), quantised from bf16 by mpmae_quant_mx:
+ *   q[rows][K] bytes; scales[K/128][lds] dwords (byte b of dword [slab][row] = scale of block 4*slab + b), lds >= rows.
+ * mpmae_gemm_mx: C[M,N] (bf16) = deq(A)[M,K] deq(B)[N,K]^T + bias (+ R); args->A / B are the e4m3 matrices (lda / ldb in
+ * BYTES = elements), epi = EPI_STORE (0) or EPI_RESID (2); fp32 accumulation, bf16 output. */
+int mpmae_quant_mx(const void* x_bf16, int ld, int rows, int K, void* q, uint32_t* scales, int lds, mpmae_stream_t stream);
+int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* args, const uint32_t* scales_a, int lsa, const uint32_t* scales_b, int lsb,
+                  mpmae_stream_t stream);
+
+/* ---- library options ------------------------------------------------------------------------
+ * Process-wide kernel-selection / launch-shape switches for A/B measurements (set them before recording launch programs:
+ * a recorded launch keeps the choice it was recorded with). The library reads NO environment variables; this table and
+ * recorded programs are the only state it keeps - every other entry point is a pure function of its arguments. Defaults
+ * are the measured-best choices on MI355X. */
+enum MpmaeOption {
+  MPMAE_OPT_LNB_BLOCKS = 0,   /* default 1024: workgroup cap of the LayerNorm backward (slab rows) */
+  MPMAE_OPT_DW_NT8,   /* default 512: threads per workgroup of the v5 depthwise kernels at S = 8 */
+  MPMAE_OPT_DW6_T8,   /* default 320: threads per workgroup, packed depthwise S = 8 */
+  MPMAE_OPT_DW6_T4,   /* default 320: ... S = 4 */
+  MPMAE_OPT_DW6_T2,   /* default 320: ... S = 2 */
+  MPMAE_OPT_DW6_GC,   /* default 1: 1: compile-time patch-grid side (7) in the packed depthwise */
+  MPMAE_OPT_DW,   /* default 6: depthwise forward generation (6 = packed per-sample kernels; 3..5 = earlier ones kept for the fp32 mode / odd shapes) */
+  MPMAE_OPT_DWW_S1_NB,   /* default 0: persistent workgroups of the S = 1 depthwise weight gradient (0 = one per sample) */
+  MPMAE_OPT_DWW_NB,   /* default 128: persistent workgroups of the depthwise weight gradient */
+  MPMAE_OPT_DWW,   /* default 5: >= 6: packed depthwise weight gradient for S >= 2 (5 = default) */
+  MPMAE_OPT_NT_GLDS64,   /* default 1: direct-to-LDS NT GEMM also for 64-wide N tiles */
+  MPMAE_OPT_NT_BK32,   /* default 1: 32-deep K slabs for K <= 512 */
+  MPMAE_OPT_NT_GLDS,   /* default 1: direct-to-LDS operand slabs in the NT GEMM (2 = always 32-deep) */
+  MPMAE_OPT_TN,   /* default 2: weight-gradient kernel: 2 = transpose-read (ds_read_b64_tr_b16), 1 = register-transposing */
+  MPMAE_OPT_TN_BLOCKS,   /* default 512: target workgroup count of a weight gradient (row splits) */
+  MPMAE_OPT_TN_MINROWS,   /* default 256: minimum rows per split */
+  MPMAE_OPT_TN_BLOCKS_BIG,   /* default 256: target workgroup count when dW >= 64K elements */
+  MPMAE_OPT_CS_SPLIT,   /* default 1: column-statistics kernel: split rows over workgroups */
+  MPMAE_OPT_RSC_BLOCKS,   /* default 1536: target workgroup count of the wide row-streaming kernels */
+  MPMAE_OPT_RSC_PF,   /* default 1: LDS-staged GRN vectors / early operand issue in the narrow row-streaming kernels */
+  MPMAE_OPT_RSC_NC32,   /* default 1: 32-column weight chunks at C = 160 */
+  MPMAE_OPT_RSC_SMALL,   /* default 1: chunked row-streaming kernels at C = 40 / 80 too */
+  MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40 */
+  MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80 */
+  MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
+  MPMAE_OPT_COUNT_
+};
+int mpmae_set_option(int option, int value);
+int mpmae_get_option(int option);
+
 /* ---- row-wise ops -------------------------------------------------------------------------- */
 /* MinkowskiLayerNorm / LayerNorm (sparse_norm_layers.py:61-77; norm_layers.py:23-31):
  * xhat = (x-mean)*rstd (biased var), optional y = act(xhat*gamma+beta), act 0 = id, 1 = GELU. */

@@ -14,6 +14,7 @@
 #include "gemm_tn2.cuh"
 #include "rsc.cuh"
 #include "stemtail.cuh"
+#include "gemm_nt3.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -77,6 +78,45 @@ static void launch_reduce(int mode, const float* part, int P, int W, float* out,
   else if (mode == 3) LAUNCH(reduce_partials_kernel<3>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else LAUNCH(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
 }
+
+// ------------------------------------------------------------------------------------------
+// Library options (mpmae_set_option): explicit, process-wide A/B switches of kernel selection. They replace environment
+// variables read inside the library; defaults are the measured-best choices.
+// ------------------------------------------------------------------------------------------
+static int g_opt[MPMAE_OPT_COUNT_] = {
+    /* MPMAE_OPT_LNB_BLOCKS */ 1024,
+    /* MPMAE_OPT_DW_NT8 */ 512,
+    /* MPMAE_OPT_DW6_T8 */ 320,
+    /* MPMAE_OPT_DW6_T4 */ 320,
+    /* MPMAE_OPT_DW6_T2 */ 320,
+    /* MPMAE_OPT_DW6_GC */ 1,
+    /* MPMAE_OPT_DW */ 6,
+    /* MPMAE_OPT_DWW_S1_NB */ 0,
+    /* MPMAE_OPT_DWW_NB */ 128,
+    /* MPMAE_OPT_DWW */ 5,
+    /* MPMAE_OPT_NT_GLDS64 */ 1,
+    /* MPMAE_OPT_NT_BK32 */ 1,
+    /* MPMAE_OPT_NT_GLDS */ 1,
+    /* MPMAE_OPT_TN */ 2,
+    /* MPMAE_OPT_TN_BLOCKS */ 512,
+    /* MPMAE_OPT_TN_MINROWS */ 256,
+    /* MPMAE_OPT_TN_BLOCKS_BIG */ 256,
+    /* MPMAE_OPT_CS_SPLIT */ 1,
+    /* MPMAE_OPT_RSC_BLOCKS */ 1536,
+    /* MPMAE_OPT_RSC_PF */ 1,
+    /* MPMAE_OPT_RSC_NC32 */ 1,
+    /* MPMAE_OPT_RSC_SMALL */ 1,
+    /* MPMAE_OPT_RSC_N40 */ 2,
+    /* MPMAE_OPT_RSC_N80 */ 1,
+    /* MPMAE_OPT_STB_BLOCKS */ 512,
+};
+
+int mpmae_set_option(int option, int value) {
+  if (option < 0 || option >= MPMAE_OPT_COUNT_) return (int)hipErrorInvalidValue;
+  g_opt[option] = value;
+  return 0;
+}
+int mpmae_get_option(int option) { return (option < 0 || option >= MPMAE_OPT_COUNT_) ? -1 : g_opt[option]; }
 
 // C linkage comes from the declarations in include/mpmae_hip.h
 
@@ -249,8 +289,8 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
     const int G = nvec <= 8 ? 8 : nvec <= 16 ? 16 : nvec <= 32 ? 32 : 64;
     const int per = cdiv(nvec, G);
     const int rpw = 64 / G;
-    static int lncap = -1;
-    if (lncap < 0) { const char* e = getenv("MPMAE_LNB_BLOCKS"); lncap = e ? atoi(e) : 1024; }   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
+    int lncap;
+    lncap = g_opt[MPMAE_OPT_LNB_BLOCKS];   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
     int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, lncap);        // one slab row per wave; enough waves to hide the row latency
     while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
 #define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask, down_S)
@@ -362,8 +402,8 @@ static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
     cur = lds;
   }
   dim3 g(a.g.N, a.C / CW);
-  static int nt8 = -1;
-  if (nt8 < 0) { const char* e = getenv("MPMAE_DW_NT8"); nt8 = e ? atoi(e) : 512; }
+  int nt8;
+  nt8 = g_opt[MPMAE_OPT_DW_NT8];
   // S = 8: the 62x62 map takes 61 KB, so two workgroups per CU; 8 waves each keep 4 waves per SIMD busy
   LAUNCH((dwconv7_v5_kernel<T, S>), g, dim3(S == 8 ? nt8 : 256), lds, st, a);
   return true;
@@ -373,8 +413,8 @@ template <typename T, int S>
 static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
   constexpr int CW = 64 / S;
   size_t lds = dw5_map_bytes<T, S>(a.g.grid);
-  static int nt8 = -1;
-  if (nt8 < 0) { const char* e = getenv("MPMAE_DW_NT8"); nt8 = e ? atoi(e) : 512; }
+  int nt8;
+  nt8 = g_opt[MPMAE_OPT_DW_NT8];
   const int nthreads = S == 8 ? nt8 : 256;
   const size_t red = (size_t)(nthreads / 64) * 50 * CW * sizeof(float);
   if (red > lds) lds = red;
@@ -395,10 +435,10 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
 }
 
 static int dw6_threads(int S) {     // waves per workgroup (each wave walks two patches at a time)
-  static int t8 = -1, t4 = -1, t2 = -1;
-  if (t8 < 0) { const char* e = getenv("MPMAE_DW6_T8"); t8 = e ? atoi(e) : 320; }
-  if (t4 < 0) { const char* e = getenv("MPMAE_DW6_T4"); t4 = e ? atoi(e) : 320; }
-  if (t2 < 0) { const char* e = getenv("MPMAE_DW6_T2"); t2 = e ? atoi(e) : 320; }
+  int t8 = -1, t4 = -1, t2 = -1;
+  t8 = g_opt[MPMAE_OPT_DW6_T8];
+  t4 = g_opt[MPMAE_OPT_DW6_T4];
+  t2 = g_opt[MPMAE_OPT_DW6_T2];
   return S == 8 ? t8 : S == 4 ? t4 : t2;
 }
 
@@ -408,8 +448,8 @@ static bool launch_dw_v6(const MpmaeDwArgs& a, hipStream_t st) {
   const size_t lds = dw5_map_bytes<bf16_t, S>(a.g.grid) + 49 * CW * sizeof(float);
   if (lds > 64 * 1024) return false;
   dim3 g(a.g.N, a.C / CW);
-  static int gc = -1;
-  if (gc < 0) { const char* e = getenv("MPMAE_DW6_GC"); gc = e ? atoi(e) : 1; }
+  int gc;
+  gc = g_opt[MPMAE_OPT_DW6_GC];
   // compile-time map pitch: measured faster only at S = 2 for the forward / data-gradient kernel (17.7 vs 18.8 us; slower at
   // S = 4, 8), decisive for the weight-gradient kernel (220 -> 128 VGPRs)
   if (gc && S == 2 && a.g.grid == 7) LAUNCH((dwconv7_v6_kernel<S, 7>), g, dim3(dw6_threads(S)), lds, st, a);
@@ -431,8 +471,8 @@ static bool launch_dwwg_v6(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
 }
 
 static int dw_variant() {      // MPMAE_DW=4 forces the per-patch kernels (A/B measurements)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MPMAE_DW"); v = e ? atoi(e) : 6; }
+  int v;
+  v = g_opt[MPMAE_OPT_DW];
   return v;
 }
 
@@ -504,8 +544,8 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
       (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->dd) & 3) == 0) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    static int nbs1 = -1;
-    if (nbs1 < 0) { const char* e = getenv("MPMAE_DWW_S1_NB"); nbs1 = e ? atoi(e) : 0; }
+    int nbs1;
+    nbs1 = g_opt[MPMAE_OPT_DWW_S1_NB];
     const int want = nbs1 > 0 ? nbs1 : (cdiv(a->C, 64) <= 5 ? 128 : 64);      // ~512-640 workgroups in total (measured)
     int nb = a->g.N < want ? a->g.N : want;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
@@ -517,15 +557,15 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
   if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    static int nbmax = -1;
-    if (nbmax < 0) { const char* e = getenv("MPMAE_DWW_NB"); nbmax = e ? atoi(e) : 128; }
+    int nbmax;
+    nbmax = g_opt[MPMAE_OPT_DWW_NB];
     int nb = a->g.N < nbmax ? a->g.N : nbmax;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     bool ok = false;
     // the packed weight-gradient kernel needs 98 accumulator VGPRs per lane and measured slower than v5
     // (62 vs 45 us at stage 1); it stays available for experiments (MPMAE_DWW=6)
-    static int wg6 = -1;
-    if (wg6 < 0) { const char* e = getenv("MPMAE_DWW"); wg6 = (e && atoi(e) >= 6) ? 1 : 0; }
+    int wg6;
+    wg6 = g_opt[MPMAE_OPT_DWW] >= 6 ? 1 : 0;
     if (wg6 && dt == 1 && (a->C & 1) == 0 && (((uintptr_t)a->x | (uintptr_t)a->dd) & 3) == 0) {
       switch (a->g.S) { case 8: ok = launch_dwwg_v6<8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v6<4>(*a, nb, S_(s)); break;
                         default: ok = launch_dwwg_v6<2>(*a, nb, S_(s)); }
@@ -728,7 +768,7 @@ static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a) {
   return true;
 }
 
-static bool glds_bn64() { static int v = -1; if (v < 0) { const char* e = getenv("MPMAE_NT_GLDS64"); v = e ? atoi(e) : 1; } return v != 0; }
+static bool glds_bn64() { int v; v = g_opt[MPMAE_OPT_NT_GLDS64]; return v != 0; }
 
 template <int BN>
 static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
@@ -738,10 +778,10 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
     if (epi_lds > lds) lds = epi_lds;
   }
   dim3 g(cdiv(a.M, FBM), cdiv(a.N, BN));
-  static int bk32 = -1;
-  if (bk32 < 0) { const char* e = getenv("MPMAE_NT_BK32"); bk32 = e ? atoi(e) : 1; }
-  static int glds = -1;
-  if (glds < 0) { const char* e = getenv("MPMAE_NT_GLDS"); glds = e ? atoi(e) : 1; }
+  int bk32;
+  bk32 = g_opt[MPMAE_OPT_NT_BK32];
+  int glds;
+  glds = g_opt[MPMAE_OPT_NT_GLDS];
   if (glds && (epi == EPI_STORE || epi == EPI_RESID) && (BN == 128 || glds_bn64()) && a.M >= 4096 && a.K % 64 == 0) {
     // direct global -> LDS slabs, swizzled unpadded rows
     if (glds == 2 || a.K <= 512) {
@@ -784,6 +824,20 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   return (int)hipErrorInvalidValue;
 }
 
+template <int EPI>
+static int launch_nt3_k(const GemmP& a, const Nt3Scales& sc, hipStream_t st) {
+  const size_t lds = (size_t)N3_ST * N3_STAGE_B;
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    once = true;
+  }
+  dim3 g(cdiv(a.M, N3_BM), cdiv(a.N, N3_BN));
+  LAUNCH((gemm_nt3_kernel<EPI>), g, dim3(N3_T), lds, st, a, sc);
+  return (int)hipGetLastError();
+}
+
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   if (epi == EPI_STORE) a.R = nullptr;
   const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
@@ -812,8 +866,8 @@ static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
 }
 
 static int tn_variant() {      // MPMAE_TN=1 forces the register-transposing kernel (A/B measurements)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("MPMAE_TN"); v = e ? atoi(e) : 2; }
+  int v;
+  v = g_opt[MPMAE_OPT_TN];
   return v;
 }
 
@@ -843,11 +897,11 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   else if (WX % 80 == 0) { nt = 5; kt = 5; }
   else { nt = 4; kt = 4; }
   const int tiles = cdiv(WX, 16 * nt) * cdiv(WY, 64 * kt);
-  static int target = -1, minrows = -1;
-  if (target < 0) { const char* e = getenv("MPMAE_TN_BLOCKS"); target = e ? atoi(e) : 512; }
-  if (minrows < 0) { const char* e = getenv("MPMAE_TN_MINROWS"); minrows = e ? atoi(e) : 256; }
-  static int bigt = -1;
-  if (bigt < 0) { const char* e = getenv("MPMAE_TN_BLOCKS_BIG"); bigt = e ? atoi(e) : 256; }   // measured in-step: 512 -> 5.59, 256 -> 5.54, 128 -> 5.86 ms
+  int target = -1, minrows = -1;
+  target = g_opt[MPMAE_OPT_TN_BLOCKS];
+  minrows = g_opt[MPMAE_OPT_TN_MINROWS];
+  int bigt;
+  bigt = g_opt[MPMAE_OPT_TN_BLOCKS_BIG];   // measured in-step: 512 -> 5.59, 256 -> 5.54, 128 -> 5.86 ms
   // large dW (stage 2+, decoder, heads): every split writes and the second stage re-reads a full fp32 copy of dW
   const int tgt = (bigt > 0 && (size_t)a.Nn * a.Kk >= 65536) ? bigt : target;
   int splits = cdiv(tgt, tiles);
@@ -926,8 +980,8 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
     float* o0 = single1 ? ws : s0;
     float* o1 = single1 ? ws + (size_t)nblk * H : s1;
     int vpl = cdiv(H / 8, 64), ysplit = 1;
-    static int cs_split = -1;
-    if (cs_split < 0) { const char* e = getenv("MPMAE_CS_SPLIT"); cs_split = e ? atoi(e) : 1; }
+    int cs_split;
+    cs_split = g_opt[MPMAE_OPT_CS_SPLIT];
     if (cs_split && nblk * 2 <= 1024 && vpl > 1) { ysplit = vpl; vpl = 1; }      // few row slabs: split the columns over gridDim.y
     const size_t lds = (size_t)4 * (mode + 1) * H * sizeof(float);
 #define CS3(TT, VV) LAUNCH((colstats_v3_kernel<TT, VV>), dim3(nblk, ysplit), dim3(256), lds, S_(s), (const TT*)h, (const TT*)dz, mode, o0, o1, M, H, rpw)
@@ -1019,7 +1073,6 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
 }
 
 // chunked variants (rsc.cuh): weights streamed through LDS, any M
-static int rsc_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 template <int KC, int RT, int NC, int KCH, int RTN = RT, int PFN = 0>
 static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
@@ -1038,7 +1091,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   if (which == 0 || which == 1) {
     if (a.fin_sum) return (int)hipErrorInvalidValue;
     // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
-    static int target = rsc_env("MPMAE_RSC_BLOCKS", 1536);
+    const int target = g_opt[MPMAE_OPT_RSC_BLOCKS];
     int nsplit = 1;
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
@@ -1068,7 +1121,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     const int rpg = a.rpg > 0 ? a.rpg : a.M;
     const int rowblocks = cdiv(a.M, 64 * RTN);
     constexpr int NP = ((KC + 15) / 16) * 16;
-    static int pf_on = rsc_env("MPMAE_RSC_PF", 1);
+    const int pf_on = g_opt[MPMAE_OPT_RSC_PF];
     const bool pf = PFN && pf_on && rpg >= a.M;       // LDS-staged GRN vectors (+ early issue): single GRN group only
     const bool dzr = a.dz_dout != nullptr;            // which 5: dz recomputed from dout; which 4: h recomputed from xn (never read)
     if (dzr && which == 4 && (!a.dz_bias || ((uintptr_t)a.dz_bias & 15))) return (int)hipErrorInvalidValue;
@@ -1106,14 +1159,14 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
 int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) {
-    static int nc32 = rsc_env("MPMAE_RSC_NC32", 1);     // 32-column chunks: the N range splits 4 ways (measured 27.7 -> 24.1 us)
+    const int nc32 = g_opt[MPMAE_OPT_RSC_NC32];     // 32-column chunks: the N range splits 4 ways (measured 27.7 -> 24.1 us)
     if (nc32) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));
     return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
   }
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
-  static int small = rsc_env("MPMAE_RSC_SMALL", 1);      // 0: keep the LDS-resident-weights kernels for which 0-3
+  const int small = g_opt[MPMAE_OPT_RSC_SMALL];      // 0: keep the LDS-resident-weights kernels for which 0-3
   if (which > 3 || (small && which < 2)) {
-    static int v40 = rsc_env("MPMAE_RSC_N40", 2), v80 = rsc_env("MPMAE_RSC_N80", 1);
+    const int v40 = g_opt[MPMAE_OPT_RSC_N40], v80 = g_opt[MPMAE_OPT_RSC_N80];
     if (a->C == 40 && a->H == 160) {
       if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2, 6>(which, *a, S_(s));
       if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1, 6>(which, *a, S_(s));
@@ -1130,6 +1183,25 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (a->C == 40 && a->H == 160) return launch_rs<40, 160>(which, *a, S_(s));
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
   if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));
+  return (int)hipErrorInvalidValue;
+}
+
+int mpmae_quant_mx(const void* x, int ld, int rows, int K, void* q, uint32_t* scales, int lds, mpmae_stream_t s) {
+  if (!x || !q || !scales || rows < 1 || K < 128 || (K % 128) || (ld & 7) || lds < rows || (((uintptr_t)x | (uintptr_t)q) & 15))
+    return (int)hipErrorInvalidValue;
+  const long long blocks = (long long)rows * (K / 32);
+  LAUNCH(quant_mx_kernel, dim3(grid1d(blocks, 256, 8192)), dim3(256), 0, S_(s), (const bf16_t*)x, ld, rows, K, (unsigned char*)q, scales, lds);
+  RET();
+}
+
+int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* a, const uint32_t* sa, int lsa, const uint32_t* sb, int lsb, mpmae_stream_t s) {
+  if (!a || !sa || !sb || a->M < 1 || a->N < 1 || a->K < 128 || (a->K % 128) || (a->lda & 15) || (a->ldb & 15) || (a->ldc & 7) || (a->N & 7) ||
+      lsa < a->M || lsb < a->N || (((uintptr_t)a->A | (uintptr_t)a->B | (uintptr_t)a->C) & 15))
+    return (int)hipErrorInvalidValue;
+  if (epi == EPI_RESID && (!a->R || (a->ldr & 7))) return (int)hipErrorInvalidValue;
+  const Nt3Scales sc{sa, sb, lsa, lsb};
+  if (epi == EPI_STORE) { GemmP g = *a; g.R = nullptr; return launch_nt3_k<EPI_STORE>(g, sc, S_(s)); }
+  if (epi == EPI_RESID) return launch_nt3_k<EPI_RESID>(*a, sc, S_(s));
   return (int)hipErrorInvalidValue;
 }
 
@@ -1159,8 +1231,8 @@ int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t 
   p.x = a->x; p.xhat1 = a->xhat1; p.rstd1 = a->rstd1; p.xhat2 = a->xhat2; p.rstd2 = a->rstd2; p.out = a->out;
   p.g1 = a->g1; p.b1 = a->b1; p.w = a->w; p.wb = a->wb; p.g2 = a->g2; p.b2 = a->b2;
   p.act_in = a->act_in; p.act_out = a->act_out; p.ws = a->ws; p.M = a->M; p.C = a->C;
-  static int stcap = -1;
-  if (stcap < 0) { const char* e = getenv("MPMAE_STB_BLOCKS"); stcap = e ? atoi(e) : 512; }
+  int stcap;
+  stcap = g_opt[MPMAE_OPT_STB_BLOCKS];
   int blocks = grid1d((long long)cdiv(a->M, rpw) * 64, 256, bwd ? stcap : 4096);
   if (bwd) {
     if (!a->ws || !a->dg1 || !a->db1 || !a->dw || !a->dwb || !a->dg2 || !a->db2) return (int)hipErrorInvalidValue;

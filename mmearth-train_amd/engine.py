@@ -46,7 +46,11 @@ class Engine:
         self.lib = _lib.load()
         self.cfg = cfg
         self.N = N = int(batch_size)
-        self.dt = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}[dtype]
+        # "fp8": the bf16 program with the decoder block's pointwise layers (K % 128 == 0) on the MX-fp8 MFMA path: e4m3
+        # operands + E8M0 block scales for pwconv1 / pwconv2 forward and data gradient; weight gradients, statistics,
+        # normalisations, losses and the optimizer stay as in bf16 mode (BASELINE configs[4])
+        self.fp8 = dtype in ("fp8", "mxfp8")
+        self.dt = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp8": BF16, "mxfp8": BF16}[dtype]
         self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
         self.device = torch.device(device)
         self.track_activity = track_activity
@@ -80,12 +84,18 @@ class Engine:
         self.Mfull = N * self.keep * self.p * self.p
         self.D = cfg.decoder_embed_dim
         self._keepalive = []
+        self.mx, self._mx_wq = {}, {}
         self._build_params()
         self._alloc()
         self._build_prep()
         self.fwd_ops, self.bwd_ops = [], []
         self._build_forward()
         self._build_backward()
+        if self._mx_wq:            # MX copies of the decoder weights: right behind the weight staging at the head of the forward program
+            wq = []
+            for wname, (w, buf) in self._mx_wq.items():
+                self._quant(wq, "prep:" + wname + ".quant", w["t"], w["ld"], buf)
+            self.fwd_ops[1:1] = wq
         self.step_count = 0
 
     # ------------------------------------------------------------------ params
@@ -458,6 +468,40 @@ class Engine:
                  kind=f"wgrad<{ppro},{qpro}>", nbytes=p_bytes + q_bytes + N_ * K_ * 4, flops=2 * M_ * N_ * K_,
                  lane=lane, wait=wait, signal=signal)
 
+    # ---- MX-fp8 pointwise path (decoder block) ---------------------------------------------------------------
+    def _mx_buf(self, name, rows, K):
+        """e4m3 matrix [rows][K] + slab-major block scales [K/128][rows] (include/mpmae_hip.h, mpmae_quant_mx)."""
+        if name not in self.mx:
+            self.mx[name] = dict(q=torch.empty(rows * K, dtype=torch.uint8, device=self.device),
+                                 s=torch.zeros((K // 128) * rows, dtype=torch.int32, device=self.device), rows=rows, K=K)
+        return self.mx[name]
+
+    def _quant(self, lst, name, src, ld, buf):
+        self._op(lst, name, self.lib.mpmae_quant_mx, _p(src), ld, buf["rows"], buf["K"], _p(buf["q"]), _p(buf["s"]), buf["rows"],
+                 kind="quant_mx", nbytes=buf["rows"] * buf["K"] * 3)
+
+    def _gemm_mx(self, lst, name, epi, qa, qb, **kw):
+        a = _lib.GemmArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.A, a.B = qa["q"].data_ptr(), qb["q"].data_ptr()
+        a.lda, a.ldb, a.rpg = qa["K"], qb["K"], max(int(a.M), 1)
+        self._keepalive.append(a)
+        M_, N_, K_ = int(a.M), int(a.N), int(a.K)
+        self._op(lst, name, self.lib.mpmae_gemm_mx, EPI[epi], C.byref(a), _p(qa["s"]), qa["rows"], _p(qb["s"]), qb["rows"],
+                 kind=f"gemm_mx<{epi}>", nbytes=M_ * K_ + N_ * K_ + M_ * N_ * 2 * (2 if epi == "RESID" else 1), flops=2 * M_ * N_ * K_)
+
+    def _mx_block(self, blk):
+        return self.fp8 and not blk["sparse"] and blk["C"] % 128 == 0 and not self.grouped_epi
+
+    def _mx_weight(self, wname):
+        """Staged bf16 weight [N][K] -> e4m3 + scales, re-quantised once per step right after weight staging (fwd op list)."""
+        w = self.w[wname]
+        buf = self._mx_buf("w:" + wname, w["rows"], w["ld"])
+        if wname not in self._mx_wq:
+            self._mx_wq[wname] = (w, buf)
+        return buf
+
     def _rs_ok(self, blk):
         if self.dt != BF16 or not blk["sparse"] or self.disable_rs:
             return False
@@ -597,6 +641,12 @@ class Engine:
             self._gemm(lst, tag + ":pw1", "NONE", "GELU_SUMSQ", A=blk["xn"], B=self.w[tag + ".W1"]["t"],
                        bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
                        rpg=rpg, s0=blk["G2"], act=act)
+        elif self._mx_block(blk):
+            qx, qw = self._mx_buf(tag + ".xn", M, Cc), self._mx_weight(tag + ".W1")
+            self._quant(lst, tag + ":xn.quant", blk["xn"], Cc, qx)
+            self._gemm_mx(lst, tag + ":pw1", "STORE", qx, qw, bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, ldc=H, act=act)
+            self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H,
+                     rpg, kind="colstats", nbytes=M * H * esz)
         else:
             self._gemm(lst, tag + ":pw1", "NONE", "STORE", A=blk["xn"], B=self.w[tag + ".W1"]["t"], bias=P[nm["b1"]],
                        C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H, act=act)
@@ -624,6 +674,10 @@ class Engine:
             self._rs(lst, tag + ":pw2", 2, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["z"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], out=blk["out"], R=x,
                      act=act)
+        elif self._mx_block(blk):
+            qz, qw = self._mx_buf(tag + ".z", M, H), self._mx_weight(tag + ".W2")
+            self._quant(lst, tag + ":z.quant", blk["z"], H, qz)
+            self._gemm_mx(lst, tag + ":pw2", "RESID", qz, qw, bias=P[nm["b2"]], C=blk["out"], R=x, M=M, N=Cc, K=H, ldc=Cc, ldr=Cc, act=act)
         else:
             self._gemm(lst, tag + ":pw2", "NONE", "RESID", A=blk["z"], B=self.w[tag + ".W2"]["t"], bias=P[nm["b2"]],
                        C=blk["out"], R=x, M=M, N=Cc, K=H, lda=H, ldb=self.w[tag + ".W2"]["ld"], ldc=Cc, ldr=Cc, act=act)
@@ -653,6 +707,10 @@ class Engine:
         elif blk["sparse"] or self.grouped_epi:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
                        K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
+        elif self._mx_block(blk):
+            qd, qw = self._mx_buf(tag + ".dout", M, Cc), self._mx_weight(tag + ".W2T")
+            self._quant(lst, tag + ":dout.quant", dout, Cc, qd)
+            self._gemm_mx(lst, tag + ":pw2.dgrad", "STORE", qd, qw, C=dz, M=M, N=H, K=Cc, ldc=H)
         else:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
                        ldb=w2t["ld"], ldc=H)
@@ -684,6 +742,10 @@ class Engine:
             self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
                      W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
                      s0=Gd[nm["ln_w"]], s1=Gd[nm["ln_b"]])
+        elif self._mx_block(blk):
+            qd, qw = self._mx_buf(tag + ".dh", M, H), self._mx_weight(tag + ".W1T")
+            self._quant(lst, tag + ":dh.quant", dz, H, qd)
+            self._gemm_mx(lst, tag + ":pw1.dgrad", "STORE", qd, qw, C=dxn, M=M, N=Cc, K=H, ldc=Cc)
         else:
             self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
                        ldb=w1t["ld"], ldc=Cc)

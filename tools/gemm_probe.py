@@ -1,5 +1,6 @@
-"""Developer timing of mpmae_gemm (bf16 NT fast path) at the dense decoder / head shapes, beside the vendor GEMM through torch."""
-import ctypes as C, sys, os, torch
+"""Developer timing / check of the NT GEMM paths at the decoder, head and wide-stage shapes: the bf16 kernels (mpmae_gemm), the vendor
+GEMM through torch, and the MX-fp8 variant (mpmae_quant_mx + mpmae_gemm_mx); statistics epilogues against fp32 column sums."""
+import ctypes as C, math, sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mmearth_train_amd import _lib
 lib = _lib.load()
@@ -17,19 +18,68 @@ def t(fn, n=30):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-shapes = [(12544, 2048, 512, "dec pw1"), (12544, 512, 2048, "dec pw2"), (12544, 2048, 512, "dec pw2.dgrad"),
-          (12544, 512, 2048, "dec pw1.dgrad"), (12544, 512, 2000, "head pix dgrad"), (12544, 2000, 512, "head pix fwd"),
-          (4864, 1280, 320, "s3 pw1"), (4864, 320, 1280, "s3 pw2"), (12544, 2816, 512, "head pix fwd (real)"),
-          (12544, 512, 2816, "head pix dgrad (real)"), (20480, 160, 320, "down1 conv"), (81920, 80, 160, "down0 conv"), (5120, 320, 640, "down2 conv")]
+def rel(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30)).item()
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+shapes = [(12544, 2048, 512, "dec pw1"), (12544, 512, 2048, "dec pw2"), (12544, 2816, 512, "head pix fwd"),
+          (12544, 512, 2816, "head pix dgrad"), (77824, 768, 192, "tiny s1 pw1"), (77824, 192, 768, "tiny s1 pw2"),
+          (19456, 1536, 384, "tiny s2 pw1"), (19456, 384, 1536, "tiny s2 pw2"), (4864, 3072, 768, "tiny s3 pw1"), (4864, 768, 3072, "tiny s3 pw2"),
+          (4000, 1280, 320, "ragged M")]
+ws = torch.empty(16 << 20, device="cuda")
 for M, N, K, name in shapes:
+    torch.manual_seed(M + N + K)
     a = torch.randn(M, K, device="cuda", dtype=bf); w = torch.randn(N, K, device="cuda", dtype=bf) / K ** 0.5
     bias = torch.randn(N, device="cuda"); c = torch.empty(M, N, device="cuda", dtype=bf)
+    r = torch.randn(M, N, device="cuda", dtype=bf)
+    act = (torch.rand(M, device="cuda") > 0.05).to(torch.uint8)
     g = _lib.GemmArgs()
     g.A, g.B, g.bias, g.C = a.data_ptr(), w.data_ptr(), bias.data_ptr(), c.data_ptr()
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
-    assert lib.mpmae_gemm(1, 0, 0, C.byref(g), st) == 0
+    g.ws, g.ws_floats = ws.data_ptr(), ws.numel()
     ref = torch.nn.functional.linear(a.float(), w.float(), bias)
-    err = ((c.float() - ref).abs().max() / ref.abs().max()).item()
+    assert lib.mpmae_gemm(1, 0, 0, C.byref(g), st) == 0
+    err0 = rel(c.float(), ref)
     us = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
     usv = t(lambda: torch.nn.functional.linear(a, w))
-    print(f"{name:16s} M={M} N={N} K={K}: mine {us:7.1f} us {2*M*N*K/us/1e6:6.1f} TF/s | vendor {usv:7.1f} us {2*M*N*K/usv/1e6:6.1f} TF/s | rel err {err:.1e}")
+    print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}")
+    # epilogues: residual + row mask, GELU^2 sums, dz statistics
+    g.R, g.ldr, g.act = r.data_ptr(), N, act.data_ptr()
+    assert lib.mpmae_gemm(1, 0, 2, C.byref(g), st) == 0
+    live = act.bool()[:, None]
+    e_res = rel(c.float(), (ref + r.float()) * live)
+    s0, s1 = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    g.s0, g.s1 = s0.data_ptr(), s1.data_ptr()
+    assert lib.mpmae_gemm(1, 0, 1, C.byref(g), st) == 0          # GELU_SUMSQ
+    hq = (ref * live).to(bf).float()
+    e_g2 = rel(s0, (gelu(hq) ** 2).sum(0))
+    s0.zero_(); g.act = 0
+    assert lib.mpmae_gemm(1, 0, 3, C.byref(g), st) == 0          # DZ_STATS: R = h
+    dzq = ref.to(bf).float()
+    e_s0, e_s1 = rel(s0, dzq.sum(0)), rel(s1, (dzq * gelu(r.float())).sum(0))
+    print(f"{'':15s} epilogues: resid {e_res:.1e}  gelu^2 sums {e_g2:.1e}  dz sums {e_s0:.1e} {e_s1:.1e}")
+    if K % 128 == 0:
+        qa, qw = torch.empty(M, K, dtype=torch.uint8, device="cuda"), torch.empty(N, K, dtype=torch.uint8, device="cuda")
+        sa, sw = torch.zeros(K // 128, M, dtype=torch.int32, device="cuda"), torch.zeros(K // 128, N, dtype=torch.int32, device="cuda")
+        assert lib.mpmae_quant_mx(a.data_ptr(), K, M, K, qa.data_ptr(), sa.data_ptr(), M, st) == 0
+        assert lib.mpmae_quant_mx(w.data_ptr(), K, N, K, qw.data_ptr(), sw.data_ptr(), N, st) == 0
+        g8 = _lib.GemmArgs()
+        g8.A, g8.B, g8.bias, g8.C = qa.data_ptr(), qw.data_ptr(), bias.data_ptr(), c.data_ptr()
+        g8.M, g8.N, g8.K, g8.lda, g8.ldb, g8.ldc, g8.rpg = M, N, K, K, K, N, M
+        assert lib.mpmae_gemm_mx(0, C.byref(g8), sa.data_ptr(), M, sw.data_ptr(), N, st) == 0
+        torch.cuda.synchronize()
+        # dequantised operands on the host side of the check: exact products of what the kernel multiplies
+        def deq(q, s, rows):
+            e = q.view(torch.float8_e4m3fn).float().view(rows, K // 32, 32)
+            sc = s.view(K // 128, rows).t().reshape(-1).clone().view(torch.uint8).view(rows, K // 128, 4).reshape(rows, K // 32).float() - 127
+            return (e * torch.exp2(sc)[:, :, None]).view(rows, K)
+        da, dw = deq(qa, sa, M), deq(qw, sw, N)
+        ref8 = da @ dw.t() + bias
+        us8 = t(lambda: lib.mpmae_gemm_mx(0, C.byref(g8), sa.data_ptr(), M, sw.data_ptr(), N, st))
+        usq = t(lambda: lib.mpmae_quant_mx(a.data_ptr(), K, M, K, qa.data_ptr(), sa.data_ptr(), M, st))
+        print(f"{'':15s} mx-fp8: {us8:6.1f} us {2*M*N*K/us8/1e6:6.0f} TF (+ quant A {usq:5.1f} us) | vs dequantised fp32 product {rel(c.float(), ref8):.1e}"
+              f" | quantisation error of A {rel(da, a.float()):.1e}, end to end vs bf16 product {rel(c.float(), ref):.1e}")
