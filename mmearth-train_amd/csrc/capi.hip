@@ -15,6 +15,7 @@
 #include "rsc.cuh"
 #include "stemtail.cuh"
 #include "gemm_nt3.cuh"
+#include "dwband.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -90,7 +91,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_DW6_T4 */ 320,
     /* MPMAE_OPT_DW6_T2 */ 320,
     /* MPMAE_OPT_DW6_GC */ 1,
-    /* MPMAE_OPT_DW */ 6,
+    /* MPMAE_OPT_DW */ 7,
     /* MPMAE_OPT_DWW_S1_NB */ 0,
     /* MPMAE_OPT_DWW_NB */ 128,
     /* MPMAE_OPT_DWW */ 5,
@@ -483,8 +484,27 @@ static bool dw_v4_ok(int C, int S) {
   return C % (64 / S) == 0;
 }
 
+template <int S, int C, int BR>
+static int launch_dw_band(const DwP& a, hipStream_t st) {
+  using D = DwBand<S, C, BR>;
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute((const void*)dwconv7_band_kernel<S, C, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS) != hipSuccess)
+      return (int)hipGetLastError();
+    once = true;
+  }
+  LAUNCH((dwconv7_band_kernel<S, C, BR>), dim3(a.g.N, cdiv(a.g.grid, BR)), dim3(512), D::LDS, st, a);
+  return (int)hipGetLastError();
+}
+
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dt == 1 && dw_variant() >= 7 && a->g.grid == 7 && a->g.inv && (((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->add) & 15) == 0) {
+    // band kernel (dwband.cuh): (sample, patch row) per workgroup, all channels, whole-line loads. Measured at bs 256: stage 0
+    // (S = 8, C = 40) 47 / 60 us forward / data gradient against 60 / 67 us for the per-sample kernels; at stage 1 (S = 4, C = 80)
+    // it LOSES (36 / 40 vs 25 / 27 us) and with two patch rows per workgroup (one workgroup per CU) it loses everywhere
+    if (a->g.S == 8 && a->C == 40) return launch_dw_band<8, 40, 1>(*a, S_(s));
+  }
   if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
       (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->out | (uintptr_t)a->add) & 3) == 0) {
     dim3 g(a->g.N, cdiv(a->C, 64));
@@ -631,6 +651,11 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
 int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const float* b, int Mout, int C, int S, int k,
                        const uint8_t* act_in, const uint8_t* act_out, mpmae_stream_t s) {
   if (k < 1 || k > 2) return (int)hipErrorInvalidValue;
+  if (k == 2 && dt == 1 && (C & 7) == 0) {
+    LAUNCH(dwstride2_fwd_kernel<bf16_t>, dim3(grid1d((long long)Mout * (C / 8), 256, 8192)), dim3(256), 0, S_(s), (const bf16_t*)in, (bf16_t*)out, w, b,
+           Mout, C, S, act_in, act_out);
+    RET();
+  }
   const int g = grid1d((long long)Mout * C);
   if (dt == 0) LAUNCH(dwstride_fwd_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)in, (float*)out, w, b, Mout, C, S, k, act_in, act_out);
   else LAUNCH(dwstride_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)in, (bf16_t*)out, w, b, Mout, C, S, k, act_in, act_out);
@@ -650,6 +675,14 @@ int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, cons
     if (dt == 0) LAUNCH(dwstride1_bwd_kernel<float>, dim3(g1), dim3(256), 0, S_(s), (const float*)dout, (const float*)in, (float*)din, w, ws, Mout, C, act_in);
     else LAUNCH(dwstride1_bwd_kernel<bf16_t>, dim3(g1), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, act_in);
     launch_reduce(3, ws, g1, (int)per, dw, db, C, 0, 0, 0, S_(s));
+    RET();
+  }
+  if (k == 2 && dt == 1 && (C & 7) == 0 && C / 8 <= 256 && ws && ws_floats >= per) {      // vectorised 2x2/2 stem (patch 16)
+    int g2 = cdiv(Mout, (256 / (C / 8)) * 4);
+    if (g2 > 2048) g2 = 2048;
+    while ((size_t)g2 * per > ws_floats && g2 > 1) g2 /= 2;
+    LAUNCH(dwstride2_bwd_kernel<bf16_t>, dim3(g2), dim3(256), 0, S_(s), (const bf16_t*)dout, (const bf16_t*)in, (bf16_t*)din, w, ws, Mout, C, S, act_in);
+    launch_reduce(3, ws, g2, (int)per, dw, db, 4 * C, 0, 0, 0, S_(s));
     RET();
   }
   int g = 512;

@@ -292,6 +292,95 @@ __global__ __launch_bounds__(256) void dwstride1_bwd_kernel(const T* __restrict_
   }
 }
 
+// k == 2 (patch 16: the depthwise stem is a 2x2 stride-2 depthwise convolution, convnextv2_sparse.py:121-127), C % 8 == 0:
+// thread = (row lane, 8-channel vector), 16-byte accesses; the four children of output point (nk, iy, ix) are input
+// points (2 iy + kh, 2 ix + kw) of the same patch, tap index kw * 2 + kh (ME kernel order). Forward and backward
+// (din, and the dw / db partials of the block folded through LDS -> slab ws[block][5][C]).
+template <typename T>
+__global__ __launch_bounds__(256) void dwstride2_fwd_kernel(const T* __restrict__ in, T* __restrict__ out,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            int Mout, int C, int S, const uint8_t* __restrict__ act_in,
+                                                            const uint8_t* __restrict__ act_out) {
+  const int vpr = C / 8;
+  const long long total = (long long)Mout * vpr;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / vpr), v = (int)(i - (long long)m * vpr);
+    const int P = S * S, nk = m / P, q = m - nk * P, iy = q / S, ix = q - iy * S;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = b[v * 8 + e];          // parameters are only 4-byte aligned inside the flat buffer
+#pragma unroll
+    for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int src = nk * (4 * P) + (2 * iy + kh) * (2 * S) + (2 * ix + kw);
+        float x[8], wv[8];
+        ld8<T>(in + (size_t)src * C + v * 8, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wv[e] = w[(kw * 2 + kh) * C + v * 8 + e];
+        const bool live = !act_in || act_in[src];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += live ? x[e] * wv[e] : 0.f;
+      }
+    if (act_out && !act_out[m]) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    }
+    st8<T>(out + (size_t)m * C + v * 8, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwstride2_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ in,
+                                                            T* __restrict__ din, const float* __restrict__ w,
+                                                            float* __restrict__ ws, int Mout, int C, int S,
+                                                            const uint8_t* __restrict__ act_in) {
+  __shared__ float red[256 * 8];
+  const int vpr = C / 8, rl_n = 256 / vpr;
+  const int v = threadIdx.x % vpr, rl = threadIdx.x / vpr;
+  float adw[4][8], adb[8], wv[4][8];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { adw[t][e] = 0.f; wv[t][e] = (rl < rl_n) ? w[t * C + v * 8 + e] : 0.f; }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) adb[e] = 0.f;
+  if (rl < rl_n) {
+    for (int m = blockIdx.x * rl_n + rl; m < Mout; m += gridDim.x * rl_n) {
+      const int P = S * S, nk = m / P, q = m - nk * P, iy = q / S, ix = q - iy * S;
+      float g[8];
+      ld8<T>(dout + (size_t)m * C + v * 8, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) adb[e] += g[e];
+#pragma unroll
+      for (int kw = 0; kw < 2; ++kw)
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const int t = kw * 2 + kh;
+          const int src = nk * (4 * P) + (2 * iy + kh) * (2 * S) + (2 * ix + kw);
+          const bool live = !act_in || act_in[src];
+          float x[8], o[8];
+          ld8<T>(in + (size_t)src * C + v * 8, x);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { o[e] = live ? g[e] * wv[t][e] : 0.f; adw[t][e] += live ? g[e] * x[e] : 0.f; }
+          st8<T>(din + (size_t)src * C + v * 8, o);
+        }
+    }
+  }
+  // fold the row lanes of the block, one statistic at a time (4 taps + bias) -> slab ws[block][5][C]
+  for (int t = 0; t < 5; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = (t < 4) ? adw[t < 4 ? t : 0][e] : adb[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a = 0.f;
+      for (int q = 0; q < rl_n; ++q) a += red[(q * vpr + c / 8) * 8 + (c & 7)];
+      ws[((size_t)blockIdx.x * 5 + t) * C + c] = a;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------
 // decoder input: rows of masked patches take the mask token (fcmae.py:253-255); rows of
 // visible patches were written by the proj GEMM (EPI_SCATTER_ROWS).

@@ -29,6 +29,32 @@ from .synth import flat_param_spec, state_dict_spec
 
 F32, BF16 = 0, 1
 
+# Launch-program options (A/B switches of the step's structure): defaults are the measured-best choices on MI355X. Override per
+# engine with Engine(options={...}); the developer variable MPMAE_ENGINE_OPTS="name=value,..." is read HERE on the host side
+# (the C library itself reads no environment, include/mpmae_hip.h mpmae_set_option).
+ENGINE_OPTIONS = dict(
+    down_grouped=1,         # LayerNorm writes the grouped operand of the 2x2/2 convolution
+    grouped_epi=0,          # per-sample GRN sums of the decoder in the GEMM epilogues (measured slower)
+    rsc_small=1,            # chunked row-streaming kernels at C = 40 / 80 too
+    grn_fold=1,             # GRN finalisation recomputed in the fused kernels' prologues
+    rsc_pf=1,               # LDS-staged GRN vectors in the narrow kernels (needed by grn_fold)
+    dzr=1,                  # dz never materialised at small C
+    lanes=1,                # weight gradients on a side HIP stream
+    heads_merged=1,         # one GEMM / weight gradient per head family
+    stem_im2col=1,          # 3x3 stem convolution through a materialised im2col
+    stem_fused=1,           # fused stem tail (patch 8)
+    loss_multi=1,           # one launch per loss kind
+    img_side=1,             # image-level head chain on the side lane
+    rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
+    dw_lane=1,              # lane of the depthwise weight gradients
+    dz_ring=3,            # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh)
+    ring=4,                 # depth of the dd / dx scratch rings
+    rs_maxc=100000,         # largest C on the row-streaming kernels
+    grn_fold_minc=0,        # smallest C with folded GRN finalisation
+    hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
+    dzr_maxc=80,            # largest C recomputing dz
+)
+
 
 def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
@@ -40,10 +66,18 @@ def _rup(x, m):
 
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
-                 track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None, lanes=None):
+                 track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None, lanes=None, options=None):
         if cfg.decoder_depth != 1:
             raise NotImplementedError("decoder_depth != 1")
         self.lib = _lib.load()
+        self.opt = dict(ENGINE_OPTIONS)
+        for kv in filter(None, os.environ.get("MPMAE_ENGINE_OPTS", "").split(",")):
+            k, v = kv.split("=")
+            self.opt[k.strip()] = int(v)
+        self.opt.update(options or {})
+        unknown = set(self.opt) - set(ENGINE_OPTIONS)
+        if unknown:
+            raise KeyError(f"unknown engine options {sorted(unknown)}")
         self.cfg = cfg
         self.N = N = int(batch_size)
         # "fp8": the bf16 program with the decoder block's pointwise layers (K % 128 == 0) on the MX-fp8 MFMA path: e4m3
@@ -56,22 +90,22 @@ class Engine:
         self.track_activity = track_activity
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
-        self.disable_rsc = os.environ.get("MPMAE_RSC", "1") == "0"
-        self.down_grouped = os.environ.get("MPMAE_DOWN_GROUPED", "1") != "0"
+        self.disable_rsc = (not self.opt["rsc"])
+        self.down_grouped = bool(self.opt["down_grouped"])
         # per-sample GRN sums of the dense decoder block in the GEMM epilogues instead of separate colstats passes: works
         # (parity-tested) but measured SLOWER, 5.50 vs 5.42 ms/step - the statistics epilogue costs the 1568-workgroup
         # decoder GEMMs more than the two column passes it removes; off by default
-        self.grouped_epi = self.dt == BF16 and os.environ.get("MPMAE_GROUPED_EPI", "0") != "0" and cfg.num_patches >= 43
-        self.rsc_small = os.environ.get("MPMAE_RSC_SMALL", "1") != "0"     # fused GRN prologues at C = 40 / 80 too
+        self.grouped_epi = self.dt == BF16 and bool(self.opt["grouped_epi"]) and cfg.num_patches >= 43
+        self.rsc_small = bool(self.opt["rsc_small"])     # fused GRN prologues at C = 40 / 80 too
         # GRN finalisation recomputed in the prologue of the fused kernels (no separate launches on the main lane)
-        self.grn_fold = os.environ.get("MPMAE_GRN_FOLD", "1") != "0" and os.environ.get("MPMAE_RSC_PF", "1") != "0"
-        self.dz_recompute = os.environ.get("MPMAE_DZR", "1") != "0"
+        self.grn_fold = bool(self.opt["grn_fold"]) and bool(self.opt["rsc_pf"])
+        self.dz_recompute = bool(self.opt["dzr"])
         # weight gradients on a side HIP stream (lanes=False / MPMAE_LANES=0: single in-order stream)
-        self.concurrent = ((self.device.type == "cuda") and os.environ.get("MPMAE_LANES", "1") != "0"
+        self.concurrent = ((self.device.type == "cuda") and bool(self.opt["lanes"])
                            and (lanes is None or bool(lanes)))
         self.single_stream = False                 # set while capturing HIP graphs (see dist.StepRunner._capture)
         self.lanes = self.concurrent and (block_mode or ("mat" if self.dt == BF16 else "fused")) == "mat"
-        self.dw_lane = int(os.environ.get("MPMAE_DW_LANE", "1"))
+        self.dw_lane = int(self.opt["dw_lane"])
         self._side_readers = {}
         self._evseq = 0
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
@@ -251,10 +285,10 @@ class Engine:
         # backward scratch
         maxMH = max(b["M"] * b["H"] for b in self.blocks + [self.dec])
         maxMC = max(max(b["M"] * b["C"] for b in self.blocks + [self.dec]), self.Mfull * C0)
-        self.scr_dz2 = [self._t(maxMH), self._t(maxMH)]   # dz / dh, alternating per block (side lane reads dh)
+        self.scr_dz2 = [self._t(maxMH) for _ in range(int(self.opt["dz_ring"]))]   # dz / dh, one per block in turn (side lane reads dh)
         self.scr_dz = self.scr_dz2[0]
         self.scr_dxn = self._t(maxMC)
-        self.ring = int(os.environ.get("MPMAE_RING", "3"))      # depth of the dd / dx rings (2 = ping-pong)
+        self.ring = int(self.opt["ring"])      # depth of the dd / dx rings (2 = ping-pong)
         self.scr_dd2 = [self._t(maxMC) for _ in range(self.ring)]   # dd, one per block in turn (side lane reads it)
         self.scr_dd = self.scr_dd2[0]
         # dx ring: a block's dout is still read by its pw2 weight gradient (side lane) while later blocks run; with
@@ -342,7 +376,7 @@ class Engine:
         for fam, mods in (("pix", cfg.pix_mods), ("img", cfg.img_mods)):
             ws_ = [P[f"pred_dict.{m.name}.weight"] for m in mods]
             bs_ = [P[f"pred_dict.{m.name}.bias"] for m in mods]
-            ok = bool(mods) and os.environ.get("MPMAE_HEADS_MERGED", "1") != "0"
+            ok = bool(mods) and bool(self.opt["heads_merged"])
             for ts in (ws_, bs_):
                 ok = ok and all(a.data_ptr() + a.numel() * 4 == b_.data_ptr() for a, b_ in zip(ts, ts[1:]))
             self.heads_merged[fam] = ok
@@ -517,7 +551,7 @@ class Engine:
         2/3 on materialised z / dh) or "fused" (which 4/5, GRN application and its backward in the operand
         prologue). Measured on MI355X at bs 256: fused wins for C <= 160; at C = 320 (M = 4864 rows, 76
         workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
-        if not self._rs_ok(blk) or blk["C"] > int(os.environ.get("MPMAE_RS_MAXC", "100000")):
+        if not self._rs_ok(blk) or blk["C"] > int(self.opt["rs_maxc"]):
             return False, None
         if self._rsc_ok(blk):
             return True, ("fused" if blk["C"] <= 160 else None)
@@ -653,7 +687,7 @@ class Engine:
             self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H,
                      rpg, kind="colstats", nbytes=M * H * esz)
         fold = blk["grn_fold"] = (rs_n == "fused" and G == 1 and self.grn_fold
-                                  and Cc >= int(os.environ.get("MPMAE_GRN_FOLD_MINC", "0")))
+                                  and Cc >= int(self.opt["grn_fold_minc"]))
         if not fold:
             self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                      _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
@@ -661,7 +695,7 @@ class Engine:
             fin = dict(fin_sum=blk["G2"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"], fin_ainv=blk["Ainv"],
                        fin_out=blk["scale"], fin_eps=eps) if fold else {}   # GRN finalisation folded into the prologue
             # optional (off: 5.146 vs 5.152 ms, noise): h recomputed from xn, 26 MB instead of 105 MB read per stage-0 block
-            hr = fold and Cc <= int(os.environ.get("MPMAE_HR_MAXC", "0"))
+            hr = fold and Cc <= int(self.opt["hr_maxc"])
             hkw = dict(dz_dout=blk["xn"], dz_w2t=self.w[tag + ".W1"]["t"], dz_ldw2=self.w[tag + ".W1"]["ld"], dz_bias=P[nm["b1"]]) if hr else {}
             self._rs(lst, tag + ":grn.apply+pw2", 4, blk, ((1 if hr else 2) * M * H + (3 if hr else 2) * M * Cc) * esz,
                      (4 if hr else 2) * M * Cc * H, A=blk["h"],
@@ -692,14 +726,14 @@ class Engine:
         tag = blk["prefix"]
         esz = 4 if dt == F32 else 2
         t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1      # dz / dd alternate per block: the side lane reads them
-        dz = self.scr_dz2[t & 1][:M * H]
+        dz = self.scr_dz2[t % len(self.scr_dz2)][:M * H]
         dxn = self.scr_dxn[:M * Cc]
         dd = self.scr_dd2[t % len(self.scr_dd2)][:M * Cc]
         w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
         rs, rs_n = blk.get("rs", False), blk.get("rs_n")
         # HBM-bound stages: dz is never materialised - pw2.dgrad only produces the GRN statistics and the fused
         # pw1.dgrad kernel recomputes dz = dout W2 chunk by chunk (MpmaeRsArgs.dz_*)
-        dzr = (rs and rs_n == "fused" and Cc <= int(os.environ.get("MPMAE_DZR_MAXC", "80")) and blk.get("grn_fold", False)
+        dzr = (rs and rs_n == "fused" and Cc <= int(self.opt["dzr_maxc"]) and blk.get("grn_fold", False)
                and self.dz_recompute)
         if rs:
             self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + (1 if dzr else 2) * M * H) * esz, 2 * M * Cc * H, A=dout,
@@ -827,7 +861,7 @@ class Engine:
             for i in range(1, 4):
                 self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2)
         wt = self.w["stem.Wt"]
-        self.stem_im2col = os.environ.get("MPMAE_STEM_IM2COL", "1") != "0"
+        self.stem_im2col = bool(self.opt["stem_im2col"])
         if self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
             self.ldk = _rup(9 * cfg.in_chans, 8)
             self.col = self._t(self.Mfull * self.ldk)
@@ -841,7 +875,7 @@ class Engine:
                        C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
                        vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
                        grid=self.grid, H=cfg.img_size)
-        self.stem_fused = (k == 1 and C0 % 8 == 0 and os.environ.get("MPMAE_STEM_FUSED", "1") != "0")
+        self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
         if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
             a.x, a.out = self.c1.data_ptr(), self.x0.data_ptr()
@@ -980,7 +1014,7 @@ class Engine:
                 self.loss_args[om.name] = a
                 self._op(f, f"loss:{om.name}", lib.mpmae_loss_img, dt, 0, C.byref(a))
         # one launch per loss KIND instead of one per modality (12 small latency-bound kernels -> 3)
-        self.loss_multi = os.environ.get("MPMAE_LOSS_MULTI", "1") != "0"
+        self.loss_multi = bool(self.opt["loss_multi"])
         if self.loss_multi:
             while f and f[-1][0].startswith("loss:"):
                 f.pop()
@@ -998,7 +1032,7 @@ class Engine:
         # image-level head chain (LN, pooling, linear heads, their losses) on the side lane next to the pixel heads and
         # their losses: both only read the decoder output
         self._fwd_join_keys = []
-        if self.lanes and self.loss_multi and os.environ.get("MPMAE_IMG_SIDE", "1") != "0":
+        if self.lanes and self.loss_multi and bool(self.opt["img_side"]):
             names = [op[0] for op in f]
             side_names = {"head:ln", "head:pool", "head:img"} | {n for n in names if n.startswith("loss:img")}
             idx = [i for i, n in enumerate(names) if n in side_names]

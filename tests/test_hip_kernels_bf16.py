@@ -366,3 +366,38 @@ def test_nt_gemm_register_staged_variant_and_scatter_rows(M, N, K, eng):
         other = torch.ones(e.N * e.L, dtype=torch.bool, device=DEV)
         other[rows] = False
         assert (dst[other] == 3.0).all()            # masked positions are left to mpmae_fill_mask_token
+
+
+@pytest.mark.parametrize("Cc,S,NK", [(96, 8, 5), (40, 8, 3), (192, 4, 4)])
+def test_depthwise_stem_2x2_stride2_bf16(Cc, S, NK):
+    """mpmae_dwstride_fwd / _bwd with k = 2 (patch 16, convnextv2_sparse.py:121-127) in bf16: out point (nk, iy, ix) = bias + sum over its
+    2x2 children (2 iy + kh, 2 ix + kw) of the same patch, tap kw * 2 + kh; inactive children contribute nothing, inactive outputs are 0."""
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    torch.manual_seed(Cc + S)
+    Mout, Min = NK * S * S, NK * 4 * S * S
+    P = lambda t: C.c_void_p(t.data_ptr())
+    act_in = (torch.rand(Min, device=DEV) > 0.1).to(torch.uint8)
+    xin = (torch.randn(Min, Cc, device=DEV)).to(bf) * act_in.bool()[:, None]
+    # parent active iff any child is (what mpmae_activity_pool produces)
+    a4 = act_in.view(NK, S, 2, S, 2)
+    act_out = (a4.amax(dim=(2, 4)) > 0).to(torch.uint8).reshape(Mout).contiguous()
+    w = torch.randn(4, Cc, device=DEV) * 0.5
+    b = torch.randn(Cc, device=DEV) * 0.1
+    out = torch.empty(Mout, Cc, device=DEV, dtype=bf)
+    assert lib.mpmae_dwstride_fwd(1, P(xin), P(out), P(w), P(b), Mout, Cc, S, 2, P(act_in), P(act_out), _st()) == 0
+    xv = xin.float().view(NK, S, 2, S, 2, Cc)                                   # [nk, iy, kh, ix, kw, c]
+    wv = w.view(2, 2, Cc)                                                      # [kw, kh, c]
+    ref = torch.einsum("nyhxwc,whc->nyxc", xv, wv).reshape(Mout, Cc) + b
+    ref = ref * act_out.bool()[:, None]
+    _assert_bf16_close(out, ref, "stem dw fwd")
+    dout = (torch.randn(Mout, Cc, device=DEV) * 0.3).to(bf) * act_out.bool()[:, None]
+    din = torch.empty(Min, Cc, device=DEV, dtype=bf)
+    dw, db = torch.zeros(4, Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    ws = torch.empty(8 << 20, device=DEV)
+    assert lib.mpmae_dwstride_bwd(1, P(dout), P(xin), P(din), P(w), P(dw), P(db), Mout, Cc, S, 2, P(act_in), P(ws), ws.numel(), _st()) == 0
+    g = dout.float().view(NK, S, S, Cc)
+    rdin = torch.einsum("nyxc,whc->nyhxwc", g, wv).reshape(Min, Cc) * act_in.bool()[:, None]
+    _assert_bf16_close(din, rdin, "stem dw din")
+    rdw = torch.einsum("nyxc,nyhxwc->whc", g, xv * act_in.view(NK, S, 2, S, 2, 1)).reshape(4, Cc)
+    assert _rel(dw, rdw) < 3e-4 and _rel(db, dout.float().sum(0)) < 3e-4
