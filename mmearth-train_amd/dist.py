@@ -6,15 +6,16 @@ Reference behaviour reproduced (/root/reference): DistributedDataParallel gradie
 all-reduce for logging (engine_pretrain.py:104 -> helpers.py:393-401). Not reproduced on
 purpose: DDP's 25 MB bucketing heuristics and its per-iteration host syncs.
 
-The flat fp32 gradient buffer is cut into three contiguous buckets that become final at known
-points of the backward program (parameters are laid out in state-dict order):
-    bucket 0  [proj ... end]            ready after heads + decoder + proj backward
-    bucket 1  [stages.2, stages.3]      ready after the stage-3 and stage-2 blocks
-    bucket 2  [0 ... stages.2)          initial conv, stem, downsample layers, stages 0-1 (last)
-Each bucket is all-reduced (SUM) as soon as its segment of the backward program has been
-enqueued; averaging (1/world) is folded into the AdamW kernel's grad_scale. With HIP graphs the
-forward, every backward segment and the optimizer are separate captured graphs, so a step is
-six graph launches plus three collectives.
+The flat fp32 gradient buffer is cut into four contiguous buckets that become final at known
+points of the backward program (parameters are laid out in state-dict order, heads regrouped last):
+    bucket 0  [pred_dict ... end]       7.6 MB (atto all_mod)  ready after the head weight gradients - the FIRST thing backward does
+    bucket 1  [proj ... pred_dict)      9.2 MB   proj, mask token, shared decoder block: ready after proj.wgrad
+    bucket 2  [stages.2, stages.3]     11.7 MB   ready after the stage-3 and stage-2 blocks
+    bucket 3  [0 ... stages.2)          1.9 MB   initial conv, stem, downsample layers, stages 0-1 (last)
+Each bucket is all-reduced (SUM) on a communication stream as soon as its segment of the backward program
+has been enqueued; averaging (1/world) is folded into the AdamW kernel's grad_scale. `allreduce_dtype=
+torch.bfloat16` sends the buckets as bf16 (half the xGMI bytes; the sum then carries bf16 rounding). With HIP
+graphs the forward, every backward segment and the optimizer are separate captured graphs.
 """
 import os
 
@@ -73,34 +74,49 @@ def shutdown():
 
 # ----------------------------------------------------------------------------- bucket planning
 def plan_buckets(offsets, n_params):
-    """offsets: OrderedDict key -> (offset, numel) in flat order. Returns [(lo, hi)] x 3 in the
+    """offsets: OrderedDict key -> (offset, numel) in flat order. Returns [(lo, hi)] x 4 in the
     order the buckets become ready during backward."""
     keys = list(offsets.keys())
     first_proj = next(k for k in keys if not k.startswith("encoder."))
     first_s2 = next(k for k in keys if k.startswith("encoder.stages.2."))
-    lo_proj = offsets[first_proj][0]
-    lo_s2 = offsets[first_s2][0]
-    # everything from stages.2 up to the first non-encoder tensor must be stages.2/.3 only
+    first_pred = next(k for k in keys if k.startswith("pred_dict."))
+    lo_proj, lo_s2, lo_pred = offsets[first_proj][0], offsets[first_s2][0], offsets[first_pred][0]
     for k in keys:
         o = offsets[k][0]
-        if lo_s2 <= o < lo_proj:
+        if lo_s2 <= o < lo_proj:      # everything from stages.2 up to the first non-encoder tensor must be stages.2/.3 only
             assert k.startswith("encoder.stages.2.") or k.startswith("encoder.stages.3."), k
-    return [(lo_proj, n_params), (lo_s2, lo_proj), (0, lo_s2)]
+        if lo_proj <= o < lo_pred:    # proj, mask token, the shared decoder block
+            assert k.startswith(("proj.", "mask_token", "decoder_dict.")), k
+        if o >= lo_pred:              # heads, their shared LayerNorm, the uncertainty weights
+            assert k.startswith(("pred_dict.", "layer_norm_tmp.", "loss_fn.")), k
+    return [(lo_pred, n_params), (lo_proj, lo_pred), (lo_s2, lo_proj), (0, lo_s2)]
 
 
 def split_bwd_segments(bwd_ops):
-    """Cut the backward launch list where each bucket becomes final. Returns 3 lists of ops."""
+    """Cut the backward launch list where each bucket becomes final. Returns 4 lists of ops."""
     names = [op[0] for op in bwd_ops]
+    i0 = next(i for i, n in enumerate(names) if n.startswith("decoder_dict."))
     i1 = next(i for i, n in enumerate(names) if n.startswith("encoder.stages.3."))
     i2 = next(i for i, n in enumerate(names) if n.startswith("encoder.downsample_layers.1"))
-    assert 0 < i1 < i2 < len(names)
-    return [bwd_ops[:i1], bwd_ops[i1:i2], bwd_ops[i2:]]
+    assert 0 < i0 < i1 < i2 < len(names)
+    assert not any(n.startswith(("head", "dloss")) for n in names[i0:]), "head gradients must be final before the decoder segment"
+    return [bwd_ops[:i0], bwd_ops[i0:i1], bwd_ops[i1:i2], bwd_ops[i2:]]
 
 
 def allreduce_buckets_sync(gflat, buckets):
     """Reference implementation of the exchange (used by the CPU/gloo tests and as the eager path)."""
     for lo, hi in buckets:
         dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
+
+
+class _EventWork:
+    """`.wait()` of a chain that finished on the communication stream: the current stream waits for its event."""
+
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
 
 
 # ----------------------------------------------------------------------------- step runner
@@ -112,7 +128,8 @@ class StepRunner:
     if capture is not possible; measured slower than "program" because graph branches do not
     overlap as well as real streams); "eager" is the Python loop over the C-ABI calls."""
 
-    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None, update_freq=1):
+    def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None, update_freq=1,
+                 allreduce_dtype=None):
         self.eng = engine
         self.world = world_size
         self.lr = lr
@@ -132,6 +149,9 @@ class StepRunner:
         self.comm_stream = (torch.cuda.Stream(device=engine.device)
                             if world_size > 1 and engine.device.type == "cuda" else None)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
+        # optional low-precision exchange: one staging buffer per bucket in the wire dtype
+        self.wire = ([torch.empty(hi - lo, dtype=allreduce_dtype, device=engine.device) for lo, hi in self.buckets]
+                     if allreduce_dtype not in (None, torch.float32) else None)
         self.graphs = None
         self.prog = None
         # mode: "program" = native launch program replayed from C on one HIP stream per lane (default on GPU),
@@ -212,13 +232,26 @@ class StepRunner:
     def _launch_allreduce(self, b, works):
         lo, hi = self.buckets[b]
         if self.comm_stream is None:         # host tensors (gloo logic tests): the collective is synchronous
-            dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM)
+            if self.wire is not None:
+                self.wire[b].copy_(self.eng.gflat[lo:hi])
+                dist.all_reduce(self.wire[b], op=dist.ReduceOp.SUM)
+                self.eng.gflat[lo:hi].copy_(self.wire[b])
+            else:
+                dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
-            works.append(dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if self.wire is not None:        # cast -> all-reduce -> cast back, all on the communication stream
+                self.wire[b].copy_(self.eng.gflat[lo:hi])
+                dist.all_reduce(self.wire[b], op=dist.ReduceOp.SUM)
+                self.eng.gflat[lo:hi].copy_(self.wire[b])
+                ev2 = torch.cuda.Event()
+                ev2.record(self.comm_stream)
+                works.append(_EventWork(ev2))
+            else:
+                works.append(dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def step(self):
         """One micro-step. Returns True when it ended with an optimizer update."""

@@ -223,13 +223,15 @@ class _FakeEngine:
         self.device = torch.device("cpu")
         self.n_params = n
         self.offsets = OrderedDict([("encoder.initial_conv.0.kernel", (0, 200)), ("encoder.stages.2.0.dwconv.kernel", (200, 300)),
-                                    ("encoder.stages.3.0.dwconv.kernel", (500, 100)), ("proj.weight", (600, 600))])
+                                    ("encoder.stages.3.0.dwconv.kernel", (500, 100)), ("proj.weight", (600, 300)),
+                                    ("pred_dict.sentinel2.weight", (900, 300))])
         self.gflat = torch.zeros(n)
         self.pflat = torch.zeros(n)
         self.mflat, self.vflat = torch.zeros(n), torch.zeros(n)
         self.total = torch.zeros(1)
         self.rank, self.log, self.k = rank, [], 0
-        self.bwd_ops = [("dloss", None, (), {}), ("proj.wgrad", None, (), {}), ("encoder.stages.3.0:x", None, (), {}),
+        self.bwd_ops = [("dloss", None, (), {}), ("head:pix.wgrad", None, (), {}), ("decoder_dict.sentinel2.0:x", None, (), {}),
+                        ("proj.wgrad", None, (), {}), ("encoder.stages.3.0:x", None, (), {}),
                         ("encoder.stages.2.0:x", None, (), {}), ("encoder.downsample_layers.1:x", None, (), {}),
                         ("encoder.stages.0.0:x", None, (), {})]
         self._scale = 1.0
@@ -248,8 +250,8 @@ class _FakeEngine:
     def _run(self, ops, st):
         for name, *_ in ops:
             self.log.append(name)
-            lo, hi = {"proj.wgrad": (600, 1200), "encoder.stages.3.0:x": (500, 600), "encoder.stages.2.0:x": (200, 500),
-                      "encoder.stages.0.0:x": (0, 200)}.get(name, (0, 0))
+            lo, hi = {"head:pix.wgrad": (900, 1200), "proj.wgrad": (600, 900), "encoder.stages.3.0:x": (500, 600),
+                      "encoder.stages.2.0:x": (200, 500), "encoder.stages.0.0:x": (0, 200)}.get(name, (0, 0))
             self.gflat[lo:hi] += self._scale * (self.rank + 1) * self.k
 
     def set_hyper(self, lr, t, grad_scale=1.0):
@@ -275,14 +277,15 @@ def test_runner_accumulates_over_update_freq_micro_steps():
     assert torch.allclose(eng.pflat[:200], torch.full((200,), -0.5 * ((1 + 2 + 3) / 3.0 + (4 + 5 + 6) / 3.0)))
 
 
-def _w8(rank, world, port, q):
+def _w8(rank, world, port, q, wire=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from mmearth_train_amd import dist as mdist
     mdist.init(backend="gloo")
     eng = _FakeEngine(rank)
-    run = mdist.StepRunner(eng, world_size=world, lr=1.0, mode="eager", update_freq=2)
-    assert [b for b in run.buckets] == [(600, 1200), (200, 600), (0, 200)]
-    assert [[o[0] for o in s] for s in run.segments] == [["dloss", "proj.wgrad"], ["encoder.stages.3.0:x", "encoder.stages.2.0:x"],
+    run = mdist.StepRunner(eng, world_size=world, lr=1.0, mode="eager", update_freq=2, allreduce_dtype=wire)
+    assert [b for b in run.buckets] == [(900, 1200), (600, 900), (200, 600), (0, 200)]
+    assert [[o[0] for o in s] for s in run.segments] == [["dloss", "head:pix.wgrad"], ["decoder_dict.sentinel2.0:x", "proj.wgrad"],
+                                                          ["encoder.stages.3.0:x", "encoder.stages.2.0:x"],
                                                           ["encoder.downsample_layers.1:x", "encoder.stages.0.0:x"]]
     run.step(); run.step()
     tot = sum(r + 1 for r in range(world))
@@ -294,11 +297,14 @@ def _w8(rank, world, port, q):
     mdist.shutdown()
 
 
-def test_gloo_world8_runner_ordering_and_exchange():
+@pytest.mark.parametrize("wire,port", [(None, 29633), (torch.bfloat16, 29634)])
+def test_gloo_world8_runner_ordering_and_exchange(wire, port):
+    """8 ranks over gloo: segment / bucket order of the real StepRunner, gradient accumulation, the 1/world fold, the scalar loss
+    mean - in fp32 and with the bf16 wire format (the sums below are small integers, exact in bf16)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_w8, args=(r, 8, 29633, q)) for r in range(8)]
+    ps = [ctx.Process(target=_w8, args=(r, 8, port, q, wire)) for r in range(8)]
     for p in ps:
         p.start()
     res = [q.get(timeout=120) for _ in ps]
@@ -306,8 +312,8 @@ def test_gloo_world8_runner_ordering_and_exchange():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     log = res[0][2]
-    assert log == ["fwd", "dloss", "proj.wgrad", "encoder.stages.3.0:x", "encoder.stages.2.0:x", "encoder.downsample_layers.1:x",
-                   "encoder.stages.0.0:x"] * 2 + ["adamw"]
+    assert log == ["fwd", "dloss", "head:pix.wgrad", "decoder_dict.sentinel2.0:x", "proj.wgrad", "encoder.stages.3.0:x",
+                   "encoder.stages.2.0:x", "encoder.downsample_layers.1:x", "encoder.stages.0.0:x"] * 2 + ["adamw"]
 
 
 def test_fused_adamw_state_is_a_torch_adamw_state_dict(lib):

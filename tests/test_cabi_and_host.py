@@ -82,16 +82,25 @@ def test_bucket_plan_and_segments(lib):
     from mmearth_train_amd.config import make_cfg
     from mmearth_train_amd.engine import Engine
     from mmearth_train_amd.dist import plan_buckets, split_bwd_segments
-    eng = Engine(make_cfg(), 2, dtype="bf16", device="cpu")
-    b = plan_buckets(eng.offsets, eng.n_params)
-    assert b[0][1] == eng.n_params and b[2][0] == 0 and b[0][0] == b[1][1] and b[1][0] == b[2][1]
-    segs = split_bwd_segments(eng.bwd_ops)
-    assert sum(len(s) for s in segs) == len(eng.bwd_ops)
-    # every gradient written by a segment lies in a bucket that is reduced at or after that segment
-    names0 = [o[0] for o in segs[0]]
-    assert any(n.startswith("proj") for n in names0) and not any(n.startswith("encoder.") for n in names0)
-    names1 = [o[0] for o in segs[1]]
-    assert all(n.startswith(("encoder.stages.3.", "encoder.stages.2.", "encoder.downsample_layers.2")) for n in names1)
+    from mmearth_train_amd import MODALITIES as MM
+    for subset in ("all_mod", "pix_mod", "S2"):
+        eng = Engine(make_cfg(out_modalities=MM.subset(subset)), 2, dtype="bf16", device="cpu")
+        b = plan_buckets(eng.offsets, eng.n_params)
+        assert len(b) == 4 and b[0][1] == eng.n_params and b[3][0] == 0
+        assert all(b[i][0] == b[i + 1][1] for i in range(3))                      # contiguous, in reverse-forward order
+        segs = split_bwd_segments(eng.bwd_ops)
+        assert sum(len(s) for s in segs) == len(eng.bwd_ops)
+        # every gradient written by a segment lies in a bucket that is reduced at or after that segment
+        names0 = [o[0] for o in segs[0]]
+        assert any(n.startswith("head:") for n in names0) and not any(n.startswith(("decoder_dict.", "encoder.", "proj")) for n in names0)
+        names1 = [o[0] for o in segs[1]]
+        assert any(n.startswith("proj.wgrad") for n in names1) and not any(n.startswith(("encoder.", "head")) for n in names1)
+        names2 = [o[0] for o in segs[2]]
+        assert all(n.startswith(("encoder.stages.3.", "encoder.stages.2.", "encoder.downsample_layers.2")) for n in names2)
+        # the head bucket holds exactly the heads, their shared LayerNorm and the uncertainty weights
+        lo = b[0][0]
+        assert all(k.startswith(("pred_dict.", "layer_norm_tmp.", "loss_fn.")) for k, (o, n) in eng.offsets.items() if o >= lo)
+    assert b[0][1] - b[0][0] > 0
 
 
 def _worker(rank, world, port, q):
@@ -102,7 +111,7 @@ def _worker(rank, world, port, q):
     torch.manual_seed(rank)
     g = torch.randn(1000)
     ref = g.clone()
-    mdist.allreduce_buckets_sync(g, [(600, 1000), (200, 600), (0, 200)])
+    mdist.allreduce_buckets_sync(g, [(800, 1000), (600, 800), (200, 600), (0, 200)])
     allg = [torch.zeros(1000) for _ in range(world)]
     dist.all_gather(allg, ref)
     ok = torch.allclose(g, sum(allg), atol=1e-6)
