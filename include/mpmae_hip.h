@@ -192,6 +192,13 @@ typedef struct MpmaeStemTailArgs {
 } MpmaeStemTailArgs;
 int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* args, mpmae_stream_t stream);
 
+/* ---- input stage ---------------------------------------------------------------------------- */
+/* Aligned random crop of FCMAE.forward (kornia RandomCrop, models/fcmae.py:419-434): dst[n,c,y,x] = src[n,c,ty[n]+y,tx[n]+x]
+ * for one pixel-wise modality ([N,C,H,H] -> [N,C,S,S]; elem_bytes 4 = fp32 bands, 8 = int64 class maps); the same per-sample
+ * windows ty / tx (device int32 [N]) are used for every modality. */
+int mpmae_crop(const void* src, void* dst, int elem_bytes, int N, int C, int H, int S, const int* ty, const int* tx,
+               mpmae_stream_t stream);
+
 /* ---- masks / activity --------------------------------------------------------------------- */
 /* FCMAE.gen_random_mask (models/fcmae.py:214-231) on explicit noise [N,L]: mask f32 [N,L]
  * (1 = removed), vis [N,keep], inv [N,L]. */

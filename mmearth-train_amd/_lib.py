@@ -121,6 +121,7 @@ EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRA
 P = C.POINTER
 SYMBOLS = {
     "mpmae_arch": [],
+    "mpmae_crop": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mpmae_mask_gen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_activity": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_activity_pool": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -1219,6 +1219,14 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   return (int)hipErrorInvalidValue;
 }
 
+int mpmae_crop(const void* src, void* dst, int elem_bytes, int N, int C, int H, int S, const int* ty, const int* tx, mpmae_stream_t s) {
+  if (!src || !dst || !ty || !tx || N < 1 || C < 1 || S < 1 || H < S || (elem_bytes != 4 && elem_bytes != 8)) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)N * C * S * S, 256, 16384);
+  if (elem_bytes == 4) LAUNCH(crop_kernel<uint32_t>, dim3(g), dim3(256), 0, S_(s), (const uint32_t*)src, (uint32_t*)dst, N, C, H, S, ty, tx);
+  else LAUNCH(crop_kernel<unsigned long long>, dim3(g), dim3(256), 0, S_(s), (const unsigned long long*)src, (unsigned long long*)dst, N, C, H, S, ty, tx);
+  RET();
+}
+
 int mpmae_quant_mx(const void* x, int ld, int rows, int K, void* q, uint32_t* scales, int lds, mpmae_stream_t s) {
   if (!x || !q || !scales || rows < 1 || K < 128 || (K % 128) || (ld & 7) || lds < rows || (((uintptr_t)x | (uintptr_t)q) & 15))
     return (int)hipErrorInvalidValue;

@@ -271,3 +271,23 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   if (gridDim.y == 1) *dst += s;
   else atomicAdd(dst, s);
 }
+
+// ---------------------------------------------------------------------------------
+// Aligned random crop of the input stage (kornia RandomCrop in FCMAE.forward, models/fcmae.py:419-434): every pixel-wise
+// modality of sample n is cut at the SAME window (ty[n], tx[n]) - fp32 bands and int64 class maps alike (the reference
+// round-trips the latter through float). dst[n, c, y, x] = src[n, c, ty[n] + y, tx[n] + x]; EB = element bytes (4 / 8).
+// One thread per element, consecutive threads consecutive x: reads are contiguous runs of S elements at an arbitrary
+// (element-aligned) offset, writes are fully coalesced; the destination is the engine's static input buffer, so the crop
+// replaces the device-to-device copy of the input stage instead of adding a pass.
+// ---------------------------------------------------------------------------------
+template <typename E>
+__global__ __launch_bounds__(256) void crop_kernel(const E* __restrict__ src, E* __restrict__ dst, int N, int C, int H, int S,
+                                                   const int* __restrict__ ty, const int* __restrict__ tx) {
+  const long long total = (long long)N * C * S * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % S), y = (int)((i / S) % S);
+    const long long nc = i / ((long long)S * S);
+    const int n = (int)(nc / C);
+    dst[i] = src[(nc * H + ty[n] + y) * H + tx[n] + x];
+  }
+}

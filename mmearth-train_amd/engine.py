@@ -1300,10 +1300,20 @@ class Engine:
         for st in streams[1:]:
             main.wait_stream(st)                   # join
 
-    def set_inputs(self, imgs_dict, noise):
-        """Copy a (cropped) batch and the mask noise into the engine's static device buffers."""
+    def set_inputs(self, imgs_dict, noise, crop=None):
+        """Copy a batch and the mask noise into the engine's static device buffers. crop = (ty, tx): int32 device tensors
+        [N] of per-sample window origins - the pixel-wise modalities (larger tiles than img_size, resident on the device)
+        are cut at the same window by mpmae_crop straight into the static buffers (fcmae.py:419-434)."""
+        S = self.cfg.img_size
         for k, dst in self.inp.items():
-            dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
+            src = imgs_dict[k]
+            if crop is not None and src.dim() == 4 and src.shape[-1] != S:
+                src = src.contiguous()
+                assert src.device == dst.device and src.dtype == dst.dtype and src.shape[:2] == dst.shape[:2], k
+                _lib.check(self.lib.mpmae_crop(_p(src), _p(dst), src.element_size(), src.shape[0], src.shape[1], src.shape[-1], S,
+                                               _p(crop[0]), _p(crop[1]), self._stream()), "crop")
+            else:
+                dst.copy_(src.reshape(dst.shape), non_blocking=True)
         self.noise.copy_(noise, non_blocking=True)
 
     # ------------------------------------------------------------------ forward segments (FCMAE.forward_encoder / _decoder / _loss)

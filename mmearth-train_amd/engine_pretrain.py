@@ -58,7 +58,7 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
                 runner.lr = lr
             eng = runner.eng
             noise = torch.randn(eng.N, eng.L, device=device)
-            eng.set_inputs(model._crop(samples), noise)
+            eng.set_inputs(samples, noise, crop=model._crop_windows(samples))
             runner.step()
             losses_t, total_t = eng.losses, eng.total
         else:

@@ -208,17 +208,26 @@ class FCMAE(nn.Module):
         p = int(mask.shape[1] ** 0.5)
         return mask.reshape(-1, p, p).repeat_interleave(scale, dim=1).repeat_interleave(scale, dim=2)
 
-    def _crop(self, imgs_dict):
-        """Same random crop window per sample for all pixel-wise modalities (kornia RandomCrop,
-        fcmae.py:419-434); identity when the tiles already have img_size."""
-        S = self.img_size
-        H = imgs_dict["sentinel2"].shape[-1]
+    def _crop_windows(self, imgs_dict):
+        """Per-sample crop origins (ty, tx) shared by all pixel-wise modalities (kornia RandomCrop, fcmae.py:419-434), or None
+        when the tiles already have img_size. Drawn on the device; the crop itself is mpmae_crop (Engine.set_inputs)."""
+        S, H = self.img_size, imgs_dict["sentinel2"].shape[-1]
         if H == S:
+            return None
+        N, dev = imgs_dict["sentinel2"].shape[0], self._device
+        return (torch.randint(0, H - S + 1, (N,), device=dev, dtype=torch.int32),
+                torch.randint(0, H - S + 1, (N,), device=dev, dtype=torch.int32))
+
+    def _crop(self, imgs_dict, windows=None):
+        """Reference-shaped cropped dict (what the reference leaves in the caller's imgs_dict); host-side torch indexing,
+        used for the dict hand-back only - the engine crops with the HIP kernel."""
+        windows = windows if windows is not None else self._crop_windows(imgs_dict)
+        if windows is None:
             return imgs_dict
-        N = imgs_dict["sentinel2"].shape[0]
-        dev = imgs_dict["sentinel2"].device
-        ty = torch.randint(0, H - S + 1, (N,), device=dev)
-        tx = torch.randint(0, H - S + 1, (N,), device=dev)
+        S = self.img_size
+        ty, tx = windows[0].long(), windows[1].long()
+        dev = ty.device
+        N = ty.shape[0]
         ar = torch.arange(S, device=dev)
         yy = (ty[:, None] + ar[None, :])[:, None, :, None]
         xx = (tx[:, None] + ar[None, :])[:, None, None, :]
@@ -227,7 +236,7 @@ class FCMAE(nn.Module):
         for k, v in imgs_dict.items():
             if k in PIXEL_WISE_MODALITIES:
                 cc = torch.arange(v.shape[1], device=dev)[None, :, None, None]
-                out[k] = v[nn_, cc, yy, xx]
+                out[k] = v.to(dev)[nn_, cc, yy, xx]
             else:
                 out[k] = v
         return out
@@ -284,14 +293,18 @@ class FCMAE(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, imgs_dict: Dict[AnyStr, Tensor], labels=None, mask_ratio: float = 0.6):
-        cropped = self._crop(imgs_dict)
-        if cropped is not imgs_dict:         # the reference replaces the caller's dict entries by the cropped tiles
-            for k in cropped:
-                imgs_dict[k] = cropped[k]
         N = imgs_dict["sentinel2"].shape[0]
         eng = self._engine = self._get_engine(N, mask_ratio)
+        windows = self._crop_windows(imgs_dict)
         noise = torch.randn(N, self.cfg.num_patches, device=self._device)
-        eng.set_inputs(imgs_dict, noise)
+        if windows is not None:
+            dev_dict = {k: (v.to(self._device) if k in eng.inp else v) for k, v in imgs_dict.items()}
+            eng.set_inputs(dev_dict, noise, crop=windows)
+            for k in imgs_dict:              # the reference replaces the caller's dict entries by the cropped tiles
+                if k in PIXEL_WISE_MODALITIES and k in eng.inp:
+                    imgs_dict[k] = eng.inp[k].clone()
+        else:
+            eng.set_inputs(imgs_dict, noise)
         loss = _StepFn.apply(self, None, *self._plist)
         pred = eng.preds()
         mask = eng.mask.clone()

@@ -172,12 +172,14 @@ def test_main_pretrain_trains_checkpoints_and_auto_resumes(tmp_path):
     cb = torch.load(b / "checkpoint-1.pth", map_location="cpu", weights_only=False)
     assert ca["epoch"] == cb["epoch"] == 1 and set(ca) == {"model", "optimizer", "epoch", "scaler", "args"}
     assert len(ca["model"]) == 290
+    # two separate processes' worth of fp32 atomics (column sums, bias gradients) feed AdamW's g / sqrt(v) at steps 1-4: 1.3e-4 has been
+    # observed between two identical runs, so the bound is 1e-3 (a missed resume of the moments or the step count shows up at > 1e-1)
     for k in ca["model"]:
-        assert _rel(cb["model"][k], ca["model"][k]) < 1e-4, k
+        assert _rel(cb["model"][k], ca["model"][k]) < 1e-3, k
     sa, sb = ca["optimizer"]["state"], cb["optimizer"]["state"]
     assert len(sa) == len(sb) == 180 and float(sa[0]["step"]) == float(sb[0]["step"]) == 4.0      # 2 epochs x 4 micro-steps / 2
     for i in (0, 5, 100, 179):
-        assert _rel(sb[i]["exp_avg"], sa[i]["exp_avg"]) < 1e-3
+        assert _rel(sb[i]["exp_avg"], sa[i]["exp_avg"]) < 3e-3
     c0 = torch.load(a / "checkpoint-0.pth", map_location="cpu", weights_only=False)
     assert _rel(c0["model"]["proj.weight"], ca["model"]["proj.weight"]) > 1e-4                    # it did train
     # consumers: torch AdamW built the reference's way (helpers.auto_load_model), and the hub entry point
@@ -213,3 +215,49 @@ def test_two_rank_step_driver_with_update_freq_2(tmp_path):
         m = re.search(mode + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
         assert m and float(m.group(1)) < 1e-5, r.stdout
         assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
+
+
+def test_on_device_crop_matches_indexing_and_feeds_forward():
+    """Input stage: 64x64 tiles from disk, aligned random 56x56 window per sample shared by all pixel-wise modalities
+    (kornia RandomCrop, fcmae.py:419-434) cut by mpmae_crop into the engine's buffers - fp32 bands and int64 class maps - then the
+    ordinary forward; checked against torch indexing and against the oracle on the cropped tiles the module hands back."""
+    import ctypes as C
+    from mmearth_train_amd import _lib
+    from mmearth_train_amd.synth import make_inputs
+    lib = _lib.load()
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, _, _ = case_data(c, cfg)
+    import dataclasses
+    big = dataclasses.replace(cfg, img_size=64)
+    inputs64, _ = make_inputs(big, 3, seed=91)
+    assert tuple(inputs64["sentinel2"].shape) == (3, 12, 64, 64) and inputs64["esa_worldcover"].dtype == torch.int64
+    # kernel vs indexing, both element sizes
+    ty = torch.tensor([0, 8, 3], dtype=torch.int32, device="cuda:0")
+    tx = torch.tensor([8, 0, 5], dtype=torch.int32, device="cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for k in ("sentinel2", "esa_worldcover"):
+        src = inputs64[k].to("cuda:0").contiguous()
+        dst = torch.empty(src.shape[0], src.shape[1], 56, 56, dtype=src.dtype, device="cuda:0")
+        assert lib.mpmae_crop(src.data_ptr(), dst.data_ptr(), src.element_size(), 3, src.shape[1], 64, 56, ty.data_ptr(), tx.data_ptr(), st) == 0
+        ref = torch.stack([src[n, :, int(ty[n]):int(ty[n]) + 56, int(tx[n]):int(tx[n]) + 56] for n in range(3)])
+        assert torch.equal(dst, ref), k
+    # through the module: the caller's dict ends up holding the cropped tiles, and the step equals the oracle on them
+    model = _module(cfg, sd)
+    dev = {k: v.to("cuda:0") for k, v in inputs64.items()}
+    torch.manual_seed(17)
+    loss, pred, mask, loss_dict, _, _ = model(dev, mask_ratio=0.6)
+    assert tuple(dev["sentinel2"].shape) == (3, 12, 56, 56) and tuple(dev["dynamic_world"].shape) == (3, 1, 56, 56)
+    assert tuple(dev["era5"].shape) == tuple(inputs64["era5"].shape)
+    cropped = OrderedDict((k, v.cpu()) for k, v in dev.items())
+    # each cropped tile is a window of the original, the SAME window for every pixel-wise modality of a sample
+    s2 = inputs64["sentinel2"]
+    for n in range(3):
+        hits = [(y, x) for y in range(9) for x in range(9) if torch.equal(s2[n, :, y:y + 56, x:x + 56].nan_to_num(), cropped["sentinel2"][n].nan_to_num())]
+        assert len(hits) == 1
+        y, x = hits[0]
+        assert torch.equal(inputs64["esa_worldcover"][n, :, y:y + 56, x:x + 56], cropped["esa_worldcover"][n])
+        assert torch.equal(inputs64["sentinel1"][n, :, y:y + 56, x:x + 56].nan_to_num(), cropped["sentinel1"][n].nan_to_num())
+    (oloss, _, omask, _, _, _), _, _ = _oracle(cfg, sd, cropped, model._engine.noise.cpu())
+    assert torch.equal(mask.cpu(), omask)
+    assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
