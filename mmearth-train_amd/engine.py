@@ -47,8 +47,8 @@ ENGINE_OPTIONS = dict(
     img_side=1,             # image-level head chain on the side lane
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
-    dz_ring=3,            # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh)
-    ring=4,                 # depth of the dd / dx scratch rings
+    dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
+    ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
     rs_maxc=100000,         # largest C on the row-streaming kernels
     grn_fold_minc=0,        # smallest C with folded GRN finalisation
     hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
@@ -73,7 +73,10 @@ class Engine:
         self.opt = dict(ENGINE_OPTIONS)
         for kv in filter(None, os.environ.get("MPMAE_ENGINE_OPTS", "").split(",")):
             k, v = kv.split("=")
-            self.opt[k.strip()] = int(v)
+            if k.strip() in _lib.OPT:           # upper-case names are library options (process-wide, mpmae_set_option)
+                _lib.check(self.lib.mpmae_set_option(_lib.OPT[k.strip()], int(v)), "set_option " + k)
+            else:
+                self.opt[k.strip()] = int(v)
         self.opt.update(options or {})
         unknown = set(self.opt) - set(ENGINE_OPTIONS)
         if unknown:
@@ -1375,8 +1378,23 @@ class Engine:
         fwd += list(self.fwd_ops) + [fin(False)]
         zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4), m0)]
         first = [fin(True)] + list(segs[0])
+        # AdamW reads every gradient: when the optimizer is replayed in the SAME mpmae_program_run call as the backward (the
+        # single-GPU step), the side lanes are only joined at the end of that call, so its first op waits for the last op of
+        # every side lane (in-order streams: that implies all of them). Without it the update raced the last weight
+        # gradients whenever the main lane got ahead (seen once the scratch rings stopped throttling it).
+        last_side = {}
+        for sg in segs:
+            for op in sg:
+                if op[3]["lane"] != 0:
+                    last_side[op[3]["lane"]] = op
+        joins = []
+        for ln, op in sorted(last_side.items()):
+            if op[3]["signal"] is None:
+                self._evseq += 1
+                op[3]["signal"] = f"j{self._evseq}"
+            joins.append(op[3]["signal"])
         opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                                 _p(self.hp), _p(self.total)), m0),
+                                                 _p(self.hp), _p(self.total)), dict(lane=0, wait=tuple(joins), signal=None)),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
         return [fwd, zero, first] + [list(sg) for sg in segs[1:]] + [opt]

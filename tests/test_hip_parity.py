@@ -464,3 +464,19 @@ def test_fp8_step_within_stated_bound_of_the_bf16_path():
         if gb[k].numel() >= 8 and gb[k].norm() > 0:
             cs = torch.nn.functional.cosine_similarity(g8[k].reshape(-1), gb[k].reshape(-1), dim=0).item()
             assert cs >= 0.98, (k, cs)
+
+
+def test_optimizer_piece_waits_for_the_weight_gradient_lane():
+    """The single-GPU step replays forward, backward and AdamW in ONE mpmae_program_run call, whose side lanes are only joined at
+    its end: the optimizer piece must therefore wait for the last op of the weight-gradient lane itself. (Latent until round 2:
+    with shallow scratch rings the main lane was throttled enough to hide the race; test_step_drivers_agree_with_python_loop
+    catches it numerically when it is lost, this pins the structure.)"""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], "bf16", sd, inputs, noise)
+    pieces = eng.step_pieces()
+    side = [op for op in eng.bwd_ops if op[3]["lane"] != 0]
+    assert side, "weight gradients are expected on a side lane in bf16 mode"
+    first_opt = pieces[-1][0]
+    assert first_opt[0] == "hp.fetch" and side[-1][3]["signal"] in first_opt[3]["wait"]
