@@ -45,6 +45,7 @@ ENGINE_OPTIONS = dict(
     stem_fused=1,           # fused stem tail (patch 8)
     loss_multi=1,           # one launch per loss kind
     img_side=1,             # image-level head chain on the side lane
+    prep_side=1,            # weight staging of the forward on the side lane
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
@@ -853,7 +854,10 @@ class Engine:
         f = self.fwd_ops
         dims = cfg.dims
         C0, p, k = dims[0], self.p, cfg.stem_k
-        self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max)
+        # weight staging only feeds the first GEMM: on the side lane next to mask / activity / im2col (which only read the inputs)
+        prep_side = self.lanes and bool(self.opt["prep_side"]) and not self.fp8
+        self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max,
+                 **(dict(lane=1, signal="prep_done") if prep_side else {}))
         self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv))
         img = self.inp["sentinel2"]
         if self.track_activity:
@@ -878,6 +882,8 @@ class Engine:
                        C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
                        vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
                        grid=self.grid, H=cfg.img_size)
+        if prep_side:
+            f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + ("prep_done",)
         self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
         if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
@@ -1100,6 +1106,7 @@ class Engine:
         y = self.dec_out
         # loss gradients w.r.t. predictions
         if self.loss_multi:
+            # (the categorical losses on the side lane next to the continuous ones, forward and gradient: 4.99 vs 4.97 ms, not kept)
             for kind, (kind_id, tab, cnt) in self._loss_tabs.items():
                 self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_multi, dt, 1, kind_id, _p(tab), cnt,
                          N if kind == "img" else N * L, kind=f"loss_{kind}_bwd")
