@@ -38,7 +38,7 @@ STEP_ROOFLINE_US = {            # sum over layers of max(
 }
 
 
-def parse():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -59,7 +59,11 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--block-mode", default=None, choices=[None, "fused", "mat"], help="override the per-block program policy")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel-kind time table to stderr")
-    return ap.parse_args()
+    return ap
+
+
+def parse():
+    return build_parser().parse_args()
 
 
 def per_kernel_times(eng, reps=3, by_name=False, split_lanes=False):
@@ -117,7 +121,17 @@ def _latest_pmc():
         return None, None
     path = os.path.join(root, cands[-1], "pmc_traffic.json")
     meta = json.load(open(path)).get("meta", {})
-    return path, f"profiles/{cands[-1]}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; commit {meta.get('commit', 'n/a')})"
+    return path, (f"profiles/{cands[-1]}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; commit {meta.get('commit', 'n/a')}; "
+                  f"bench args '{meta.get('bench_args', '')}')")
+
+
+def _pmc_matches(a):
+    """The committed counters were sampled on ONE workload: only quote them for a run of the same model / size / subset / batch / dtype."""
+    if not PMC_PATH:
+        return False
+    args = json.load(open(PMC_PATH)).get("meta", {}).get("bench_args", "")
+    ref, _ = build_parser().parse_known_args(args.split())
+    return all(getattr(ref, k) == getattr(a, k) for k in ("model", "img", "patch", "subset", "batch", "dtype"))
 
 
 PMC_PATH, PMC_SOURCE = _latest_pmc()
@@ -259,7 +273,7 @@ def main():
                 print(f"{k:58s} {d['ms'] / 3 * 1e3:9.1f} us {gbs:8.0f} GB/s {tfs:8.1f} TF/s", file=sys.stderr)
         key = (a.model, a.img, a.subset)
         step_roof = STEP_ROOFLINE_US.get(key)
-        traffic = pmc_traffic(dom_kind)
+        traffic = pmc_traffic(dom_kind) if _pmc_matches(a) else None      # counters are per workload
         roof = dict(bound="hbm", kernel=dom_kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes=int(avg_bytes),

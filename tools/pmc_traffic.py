@@ -31,6 +31,6 @@ try:
 except Exception:
     commit = os.environ.get("MPMAE_COMMIT", "n/a")
 json.dump(dict(note="avg per launch; fetch doubled per the gfx950 FETCH_SIZE correction; separate --pmc passes",
-               meta=dict(commit=commit), kernels=out), open(sys.argv[3], "w"), indent=1)
+               meta=dict(commit=commit, bench_args=os.environ.get("BENCH_ARGS", "")), kernels=out), open(sys.argv[3], "w"), indent=1)
 for k, d in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches_sampled"])[:30]:
     print(f"{k[:70]:70s} {d['launches_sampled']:5d} launches  fetch {d['fetch_bytes'] / 1e6:8.1f} MB  write {d['write_bytes'] / 1e6:8.1f} MB")

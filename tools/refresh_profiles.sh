@@ -7,7 +7,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format c
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmcf -o f --output-format csv -- python bench.py ${BENCH_ARGS:-} --mode eager --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmcw -o w --output-format csv -- python bench.py ${BENCH_ARGS:-} --mode eager --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 python tools/pmc_traffic.py $O/pmcf/f_counter_collection.csv $O/pmcw/w_counter_collection.csv $O/pmc_traffic.json > $O/pmc_traffic.txt
-python tools/kstats.py $O/stats/st_kernel_stats.csv 20 60 > $O/kernel_time_per_step.txt
+python tools/kstats.py $O/stats/st_kernel_trace.csv 70 > $O/kernel_time_per_step.txt
 python tools/timeline.py $O/stats/st_kernel_trace.csv 3 > $O/timeline.txt
 head -5 $O/kernel_time_per_step.txt; cat $O/timeline.txt | head -8
 ls $O $O/stats
