@@ -345,6 +345,16 @@ int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* args, mpmae_stream_t str
  * pixel kinds, samples for the image kind). All records of a call must share p / L / K-limits. */
 int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count, int gridx,
                      mpmae_stream_t stream);
+/* Forward of the continuous pixel losses in row-band form: one workgroup per sample walks its patch rows with the target band in
+ * LDS (loss.cuh). Same records, outputs and partial layout as mpmae_loss_multi(kind 0, forward). maxC = largest C of the records;
+ * needs H % 4 == 0, (p*p) % 4 == 0 and maxC * (p*H + 4) * 4 <= 150 KB of LDS, else hipErrorInvalidValue (use mpmae_loss_multi). */
+int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
+                             mpmae_stream_t stream);
+/* Categorical pixel losses, wave-per-patch form (forward bwd = 0 / gradient bwd = 1): same records, outputs and partial layout as
+ * mpmae_loss_multi(kind 1). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and
+ * coff % 4 == 0 (vector accesses); 16 * max_pk elements of LDS. */
+int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk,
+                             mpmae_stream_t stream);
 /* acc: per-sample partial {sum, count} pairs laid out [T][N][2] (written by the loss kernels:
  * args->acc points at modality t's [N][2] block). */
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale,

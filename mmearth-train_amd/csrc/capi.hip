@@ -766,6 +766,38 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
   RET();
 }
 
+int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)maxC * (p * H + 4) * 4;
+  const int nvec = maxC * p * (H / 4), npv = maxC * p * p / 4;
+  const int mv = cdiv(nvec, 512), mp = cdiv(npv, 64);
+  if (lds > 150 * 1024 || mv > 12 || mp > 12) return (int)hipErrorInvalidValue;
+  const auto* tab = (const MpmaePixContArgs*)dev_args;
+#define LPR(TT, MV, MP) do { \
+    static size_t cur = 48 * 1024; \
+    if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cont_rows_kernel<TT, MV, MP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+    LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP>), dim3(N, count), dim3(512), lds, S_(s), tab); } while (0)
+  if (mv <= 3 && mp <= 3) { if (dt == 0) LPR(float, 3, 3); else LPR(bf16_t, 3, 3); }
+  else { if (dt == 0) LPR(float, 12, 12); else LPR(bf16_t, 12, 12); }
+#undef LPR
+  RET();
+}
+
+int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {
+  if (!dev_args || count < 1 || N < 1 || max_pk < 4 || (max_pk & 3)) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)16 * max_pk * (dt == 0 ? 4 : 2);
+  if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
+  const auto* tab = (const MpmaePixCatArgs*)dev_args;
+#define LCW(TT, BW) do { \
+    static size_t cur = 48 * 1024; \
+    if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cat_waves_kernel<TT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+    LAUNCH((loss_pix_cat_waves_kernel<TT, BW>), dim3(N, count), dim3(1024), lds, S_(s), tab, max_pk); } while (0)
+  if (dt == 0) { if (bwd) LCW(float, true); else LCW(float, false); }
+  else { if (bwd) LCW(bf16_t, true); else LCW(bf16_t, false); }
+#undef LCW
+  RET();
+}
+
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
                         float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
   if (T > 16 || T < 1) return (int)hipErrorInvalidValue;

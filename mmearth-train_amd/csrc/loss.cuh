@@ -3,6 +3,7 @@
 // Predictions are channels-last rows: pixel heads [N*L, ld] (modality slice at column `coff`,
 // column j = (ph*p+pw)*C + c), image heads [N, ld].
 #pragma once
+#include <type_traits>
 #include "common.cuh"
 
 __device__ __forceinline__ float block_sum256(float v, float* sh) {
@@ -31,12 +32,49 @@ __device__ __forceinline__ void loss_pix_cont_patch(const PixContP& q, int b, fl
     T* dp = reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff;
     const float pl = q.patch_l[b];
     const bool counted = masked && pl != 0.f && !isnan(pl);
+    // prediction order, 4 elements per thread and access (J = p*p*C is a multiple of 4 whenever p is even; the slice starts at a
+    // multiple of 4 columns): the prediction read and the gradient write are contiguous 8 / 16-byte vectors, the planar fp32 target
+    // is gathered (its 32-byte runs stay in L1 across the 4 elements' neighbours). Scalar fallback for odd shapes.
+    const bool vec4 = (J & 3) == 0 && (q.coff & 3) == 0 && (q.ld & 3) == 0;
     if (!counted) {
-      for (int j = threadIdx.x; j < J; j += blockDim.x) stf<T>(dp + j, 0.f);
+      if (vec4) {
+        for (int j = 4 * threadIdx.x; j < J; j += 4 * blockDim.x) {
+          if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(dp + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+          else *reinterpret_cast<uint2*>(dp + j) = make_uint2(0u, 0u);
+        }
+      } else {
+        for (int j = threadIdx.x; j < J; j += blockDim.x) stf<T>(dp + j, 0.f);
+      }
       return;
     }
     const float k = q.coef[0] * q.mask[b] * 2.f / q.patch_cnt[b];
     const float mean = q.patch_mean[b], rstd = q.patch_rstd[b];
+    const float* tg = q.target + ((size_t)n * C * q.H + py * p) * q.H + px * p;
+    if (vec4) {
+      for (int j0 = 4 * threadIdx.x; j0 < J; j0 += 4 * blockDim.x) {
+        float pv[4], o[4];
+        if constexpr (std::is_same<T, float>::value) {
+          const float4 r4 = *reinterpret_cast<const float4*>(pred + j0);
+          pv[0] = r4.x; pv[1] = r4.y; pv[2] = r4.z; pv[3] = r4.w;
+        } else {
+          const uint2 r2 = *reinterpret_cast<const uint2*>(pred + j0);
+          pv[0] = __uint_as_float(r2.x << 16); pv[1] = __uint_as_float(r2.x & 0xffff0000u);
+          pv[2] = __uint_as_float(r2.y << 16); pv[3] = __uint_as_float(r2.y & 0xffff0000u);
+        }
+        int r = j0 / C, c = j0 - r * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ph = r / p, pw = r - ph * p;
+          const float t = (nan_to_num0(tg[((size_t)c * q.H + ph) * q.H + pw]) - mean) * rstd;
+          const float d = pv[e] - t;
+          o[e] = isnan(d * d) ? 0.f : k * d;
+          if (++c == C) { c = 0; ++r; }
+        }
+        if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(dp + j0) = make_float4(o[0], o[1], o[2], o[3]);
+        else *reinterpret_cast<uint2*>(dp + j0) = make_uint2(f2bf2(o[0], o[1]), f2bf2(o[2], o[3]));
+      }
+      return;
+    }
     for (int i = threadIdx.x; i < J; i += blockDim.x) {
       const int c = i / (p * p), r = i - c * p * p, ph = r / p, pw = r - ph * p;
       float t = nan_to_num0(q.target[((size_t)(n * C + c) * q.H + py * p + ph) * q.H + px * p + pw]);
@@ -242,6 +280,129 @@ __global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_multi_kernel(co
   loss_pix_cont_body<T, BWD>(q, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------
+// Forward of the continuous pixel losses, row-band form (round 2). The wave-per-patch kernel above walks the prediction row with
+// 2-byte gathers at stride C and the planar fp32 target in 32-byte pieces: 91 us for 70 MB. Here a workgroup is one SAMPLE that
+// walks its patch ROWS: the target band of a row (C planes x p image rows x H floats, every image row one contiguous run) is
+// prefetched into registers with 16-byte loads while the previous row is being reduced, cleaned of NaN / Inf once and parked in
+// LDS ([C][p*H + 4] floats); a wave then owns one patch of the row: its prediction slice is ONE contiguous run (4 elements per
+// lane and load), the per-patch target statistics come from conflict-free planar reads of the band, and the squared error pairs
+// prediction element j = (ph*p + pw)*C + c with band[c][ph][px*p + pw]. Outputs are those of loss_pix_cont_patch_wave
+// (patch_l / cnt / mean / rstd per patch, one {sum, count} partial per sample, fixed summation order).
+// grid = (N, modalities); block = 512; dynamic LDS = max_C * (p*H + 4) * 4 bytes. MAXV / MAXP: float4 of the band per thread /
+// 4-element prediction vectors per lane and patch (3 / 3 at 56/8 with C <= 12, 11 / 12 at 112/16).
+// ---------------------------------------------------------------------------------
+template <typename T, int MAXV, int MAXP>
+__global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP* __restrict__ tab) {
+  const PixContP q = tab[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) float lpc_band[];
+  __shared__ float part[8][2];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = q.p, C = q.C, H = q.H, G = q.grid, PP = p * p, J = PP * C;
+  const int H4 = H >> 2, CP = p * H + 4, nvec = C * p * H4, npv = J >> 2;
+  const float* tg_n = q.target + (size_t)n * C * H * H;
+  float4 pre[MAXV];
+  auto prefetch = [&](int py) {
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = min(tid + 512 * i, nvec - 1);             // unconditional, clamped: no branch between the loads
+      const int c = v / (p * H4), rem = v - c * (p * H4), ph = rem / H4, x4 = rem - ph * H4;
+      pre[i] = *reinterpret_cast<const float4*>(tg_n + ((size_t)c * H + py * p + ph) * H + x4 * 4);
+    }
+  };
+  prefetch(0);
+  float as = 0.f, ac = 0.f;
+  for (int py = 0; py < G; ++py) {
+    __syncthreads();                                            // every wave is done with the previous band
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = tid + 512 * i;
+      if (v < nvec) {
+        const int c = v / (p * H4), rem = v - c * (p * H4), ph = rem / H4, x4 = rem - ph * H4;
+        float4 t = pre[i];
+        t.x = nan_to_num0(t.x); t.y = nan_to_num0(t.y); t.z = nan_to_num0(t.z); t.w = nan_to_num0(t.w);
+        *reinterpret_cast<float4*>(lpc_band + c * CP + ph * H + x4 * 4) = t;
+      }
+    }
+    __syncthreads();
+    if (py + 1 < G) prefetch(py + 1);
+    for (int px = wave; px < G; px += 8) {
+      const int b = n * q.L + py * G + px;
+      const float mk = q.mask[b];
+      if (mk == 0.f) {
+        if (lane == 0) { q.patch_l[b] = 0.f; q.patch_cnt[b] = 0.f; q.patch_mean[b] = 0.f; q.patch_rstd[b] = 1.f; }
+        continue;
+      }
+      // the patch's prediction slice: contiguous, 4 elements per lane and load, all in flight before the statistics
+      const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+      float pv[MAXP][4];
+#pragma unroll
+      for (int u = 0; u < MAXP; ++u) {
+        const int v = min(lane + 64 * u, npv - 1);
+        if constexpr (std::is_same<T, float>::value) {
+          const float4 r = *reinterpret_cast<const float4*>(pred + 4 * v);
+          pv[u][0] = r.x; pv[u][1] = r.y; pv[u][2] = r.z; pv[u][3] = r.w;
+        } else {
+          const uint2 r = *reinterpret_cast<const uint2*>(pred + 4 * v);
+          pv[u][0] = __uint_as_float(r.x << 16); pv[u][1] = __uint_as_float(r.x & 0xffff0000u);
+          pv[u][2] = __uint_as_float(r.y << 16); pv[u][3] = __uint_as_float(r.y & 0xffff0000u);
+        }
+      }
+      const float* bp = lpc_band + px * p;
+      float mean = 0.f, rstd = 1.f;
+      if (q.norm_pix) {                                          // planar walk: 8 consecutive lanes = one image row of the patch
+        float s1 = 0.f;
+        for (int i = lane; i < J; i += 64) {
+          const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+          s1 += bp[c * CP + ph * H + pw];
+        }
+        mean = wave_sum(s1) / J;
+        float s2 = 0.f;
+        for (int i = lane; i < J; i += 64) {
+          const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+          const float d = bp[c * CP + ph * H + pw] - mean;
+          s2 += d * d;
+        }
+        rstd = 1.f / sqrtf(wave_sum(s2) / (J - 1) + 1.0e-6f);     // unbiased (torch .var default)
+      }
+      float se = 0.f, cnt = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXP; ++u) {
+        const int v = lane + 64 * u;
+        if (v < npv) {
+          int r = (4 * v) / C, c = 4 * v - r * C;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int ph = r / p, pw = r - ph * p;
+            const float t = (bp[c * CP + ph * H + pw] - mean) * rstd;
+            const float d = pv[u][e] - t;
+            const float e2 = d * d;
+            if (!isnan(e2)) { se += e2; cnt += 1.f; }
+            if (++c == C) { c = 0; ++r; }
+          }
+        }
+      }
+      se = wave_sum(se); cnt = wave_sum(cnt);
+      const float lp = se / cnt;                                 // 0/0 -> NaN -> dropped below
+      const float qv = lp * mk;
+      const bool counted = !isnan(qv) && qv != 0.f;
+      if (lane == 0) {
+        q.patch_l[b] = counted ? lp : 0.f;
+        q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
+      }
+      if (counted) { as += qv; ac += 1.f; }
+    }
+  }
+  if (lane == 0) { part[wave][0] = as; part[wave][1] = ac; }
+  __syncthreads();
+  if (tid == 0) {
+    float ts = 0.f, tc = 0.f;
+    for (int w = 0; w < 8; ++w) { ts += part[w][0]; tc += part[w][1]; }       // fixed order: deterministic
+    q.acc[2 * n] = ts;
+    q.acc[2 * n + 1] = tc;
+  }
+}
+
 typedef MpmaePixCatArgs PixCatP;
 
 template <typename T, bool BWD>
@@ -326,6 +487,80 @@ template <typename T, bool BWD>
 __global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_multi_kernel(const PixCatP* __restrict__ tab) {
   const PixCatP q = tab[blockIdx.y];
   loss_pix_cat_body<T, BWD>(q, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------
+// Categorical pixel losses, wave-per-patch form (round 2), forward and gradient. The kernels above give a lane one pixel and let it
+// read / write its K logits with 2-byte accesses at stride 2K bytes. Here a workgroup is one sample, a wave owns one masked patch
+// at a time: the patch's logits are ONE contiguous run of p*p*K elements, copied into a per-wave LDS slot with 4-element vectors,
+// every lane then takes its pixels' K logits from LDS (log-sum-exp, cross entropy); the gradient is written back into the slot and
+// leaves as contiguous vectors. grid = (N, modalities); block = 1024 (16 waves); dynamic LDS = 16 * slot_elems * sizeof(T).
+// ---------------------------------------------------------------------------------
+template <typename T, bool BWD>
+__global__ __launch_bounds__(1024) void loss_pix_cat_waves_kernel(const PixCatP* __restrict__ tab, int slot_elems) {
+  const PixCatP q = tab[blockIdx.y];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lcw_smem[];
+  __shared__ float part[16][2];
+  typedef typename std::conditional<std::is_same<T, float>::value, float4, uint2>::type V4;     // 4 elements
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T* st = reinterpret_cast<T*>(lcw_smem) + (size_t)wave * slot_elems;
+  const int p = q.p, K = q.K, PP = p * p, PK = PP * K, nv = PK >> 2;
+  const float kk = BWD ? q.coef[0] : 0.f;
+  float se = 0.f, cnt = 0.f;
+  for (int l = wave; l < q.L; l += 16) {
+    const int b = n * q.L + l;
+    const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+    T* dp = BWD ? reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff : nullptr;
+    if (q.mask[b] != 1.f) {
+      if constexpr (BWD) {
+        V4 z4;
+        if constexpr (std::is_same<T, float>::value) z4 = make_float4(0.f, 0.f, 0.f, 0.f); else z4 = make_uint2(0u, 0u);
+        for (int v = lane; v < nv; v += 64) *reinterpret_cast<V4*>(dp + 4 * v) = z4;
+      }
+      continue;
+    }
+    for (int v = lane; v < nv; v += 64) *reinterpret_cast<V4*>(st + 4 * v) = *reinterpret_cast<const V4*>(pred + 4 * v);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // the slot is private to this wave: in-order LDS, no barrier
+    const int py = l / q.grid, px = l - py * q.grid;
+    for (int pix = lane; pix < PP; pix += 64) {
+      const int ph = pix / p, pw = pix - ph * p;
+      const int t = (int)q.target[((size_t)n * q.H + py * p + ph) * q.H + px * p + pw];
+      float z[16], mx = -INFINITY, zt = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        z[c] = c < K ? ldf<T>(st + pix * K + c) : -INFINITY;
+        mx = fmaxf(mx, z[c]);
+        zt = c == t ? z[c] : zt;
+      }
+      float sm = 0.f;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sm += c < K ? __expf(z[c] - mx) : 0.f;
+      const float lse = mx + __logf(sm);
+      if constexpr (BWD) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c < K) stf<T>(st + pix * K + c, t != -1 ? kk * (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) : 0.f);
+      } else if (t != -1) {
+        se += lse - zt;
+        cnt += 1.f;
+      }
+    }
+    if constexpr (BWD) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int v = lane; v < nv; v += 64) *reinterpret_cast<V4*>(dp + 4 * v) = *reinterpret_cast<const V4*>(st + 4 * v);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the slot is reused by this wave's next patch
+    }
+  }
+  if constexpr (!BWD) {
+    se = wave_sum(se); cnt = wave_sum(cnt);
+    if (lane == 0) { part[wave][0] = se; part[wave][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float ts = 0.f, tc = 0.f;
+      for (int w = 0; w < 16; ++w) { ts += part[w][0]; tc += part[w][1]; }       // fixed order: deterministic
+      q.acc[2 * n] = ts; q.acc[2 * n + 1] = tc;
+    }
+  }
 }
 
 typedef MpmaeImgArgs ImgP;

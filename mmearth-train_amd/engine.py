@@ -44,6 +44,7 @@ ENGINE_OPTIONS = dict(
     stem_im2col=1,          # 3x3 stem convolution through a materialised im2col
     stem_fused=1,           # fused stem tail (patch 8)
     loss_multi=1,           # one launch per loss kind
+    loss_rows=1,            # continuous pixel losses: row-band forward kernel
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
@@ -1036,6 +1037,23 @@ class Engine:
                 arr = (typ * len(mods))(*[self.loss_args[om.name] for om in mods])
                 tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
                 self._loss_tabs[kind] = (kind_id, tab, len(mods))
+                maxc = max(om.chans for om in mods)
+                if (kind == "pix_cont" and bool(self.opt["loss_rows"]) and cfg.img_size % 4 == 0 and (self.p * self.p) % 4 == 0
+                        and maxc * (self.p * cfg.img_size + 4) * 4 <= 150 * 1024):
+                    # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
+                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows, dt, _p(tab), len(mods), N, maxc,
+                             self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                    continue
+                ldp_ = self.pred_pix.shape[1] if cfg.pix_mods else 0
+                cat_waves = (kind == "pix_cat" and bool(self.opt["loss_rows"]) and maxc <= 16 and ldp_ % 4 == 0
+                             and all(self.head_cols[om.name] % 4 == 0 for om in mods) and (self.p * self.p * maxc) % 4 == 0
+                             and 16 * self.p * self.p * maxc * 4 <= 150 * 1024)
+                if kind == "pix_cat":
+                    self._cat_waves = cat_waves
+                if cat_waves:      # wave per patch, logits staged through LDS with contiguous vector accesses (loss.cuh)
+                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cat_waves, dt, 0, _p(tab), len(mods), N,
+                             self.p * self.p * maxc, kind=f"loss_{kind}_fwd")
+                    continue
                 self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_multi, dt, 0, kind_id, _p(tab), len(mods), N,
                          kind=f"loss_{kind}_fwd")
         # image-level head chain (LN, pooling, linear heads, their losses) on the side lane next to the pixel heads and
@@ -1108,6 +1126,11 @@ class Engine:
         if self.loss_multi:
             # (the categorical losses on the side lane next to the continuous ones, forward and gradient: 4.99 vs 4.97 ms, not kept)
             for kind, (kind_id, tab, cnt) in self._loss_tabs.items():
+                if kind == "pix_cat" and getattr(self, "_cat_waves", False):
+                    maxc = max(om.chans for om in cfg.out_mods if om.kind == "pix_cat")
+                    self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_pix_cat_waves, dt, 1, _p(tab), cnt, N,
+                             self.p * self.p * maxc, kind=f"loss_{kind}_bwd")
+                    continue
                 self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_multi, dt, 1, kind_id, _p(tab), cnt,
                          N if kind == "img" else N * L, kind=f"loss_{kind}_bwd")
         for om in ([] if self.loss_multi else cfg.out_mods):
