@@ -57,9 +57,16 @@ static inline void submit(hipStream_t st, F&& f) {
   if (g_rec) g_rec->ops.back().launches.emplace_back(std::forward<F>(f));
   else f(st);
 }
+// Launch status: hipGetLastError() is a per-thread STICKY value that any earlier runtime call of the process may have set (PyTorch
+// probes pointers / pinned memory and leaves hipErrorInvalidValue behind: seen as flaky "launch failed" returns of whichever entry
+// point ran next). Every launch therefore clears the stale value first and folds ITS OWN status into a thread-local accumulator that
+// the entry point returns and resets (launch_status()).
+static thread_local int g_launch_err = 0;
+static inline int launch_status() { const int e = g_launch_err; g_launch_err = 0; return e; }
 #define LAUNCH(kern, g, b, lds, st, ...) \
-  submit(st, [=](hipStream_t st__) { hipLaunchKernelGGL(kern, g, b, lds, st__, __VA_ARGS__); })
-#define RET() return (int)hipGetLastError()
+  submit(st, [=](hipStream_t st__) { (void)hipGetLastError(); hipLaunchKernelGGL(kern, g, b, lds, st__, __VA_ARGS__); \
+                                     const hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess && !g_launch_err) g_launch_err = (int)e__; })
+#define RET() return launch_status()
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int grid1d(long long total, int per_block = 256, int cap = 16384) {
@@ -158,7 +165,7 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
 #define GEMM_CASE(P, E)                                                            \
   if (pro == P && epi == E) {                                                      \
     LAUNCH((gemm_kernel<T, P, E>), g, b, 0, st, a);                    \
-    return (int)hipGetLastError();                                                 \
+    return launch_status();                                                 \
   }
   GEMM_CASE(PRO_NONE, EPI_STORE)
   GEMM_CASE(PRO_NONE, EPI_RESID)
@@ -194,7 +201,7 @@ int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream
     launch_reduce(0, args->ws, mblocks, args->N, args->s0, nullptr, 0, 0, 0, 0, S_(s));
     if (epi == EPI_DZ_STATS)
       launch_reduce(0, args->ws + (size_t)mblocks * args->N, mblocks, args->N, args->s1, nullptr, 0, 0, 0, 0, S_(s));
-    err = (int)hipGetLastError();
+    err = launch_status();
   }
   return err;
 }
@@ -205,7 +212,7 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
 #define WG_CASE(P, Q)                                                              \
   if (ppro == P && qpro == Q) {                                                    \
     LAUNCH((wgrad_kernel<T, P, Q>), g, b, 0, st, a);                   \
-    return (int)hipGetLastError();                                                 \
+    return launch_status();                                                 \
   }
   WG_CASE(PRO_NONE, PRO_NONE)
   WG_CASE(PRO_NONE, PRO_GRN)
@@ -234,7 +241,7 @@ int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int spli
   if (err) return err;
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, S_(s));
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, S_(s));
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -492,11 +499,11 @@ static int launch_dw_band(const DwP& a, hipStream_t st) {
   static bool once = false;
   if (!once) {
     if (hipFuncSetAttribute((const void*)dwconv7_band_kernel<S, C, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS) != hipSuccess)
-      return (int)hipGetLastError();
+      return launch_status();
     once = true;
   }
   LAUNCH((dwconv7_band_kernel<S, C, BR>), dim3(a.g.N, cdiv(a.g.grid, BR)), dim3(512), D::LDS, st, a);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
@@ -864,14 +871,14 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
       }
       LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 64, true>), g, dim3(256), l, st, a);
     }
-    return (int)hipGetLastError();
+    return launch_status();
   }
   if (bk32 && (epi == EPI_STORE || epi == EPI_RESID) && BN == 128 && a.M >= 4096 && a.K <= 512) {
     // short K, wide N (decoder pw1 / pw2.dgrad, pixel heads): half-depth K slabs, 41 KB of LDS instead of 74 KB ->
     // 3-4 workgroups per CU (measured 84 -> 67, 72 -> 58, 85 -> 77 us; for K = 2048 the 64-deep slabs stay faster)
     const size_t lds32 = (size_t)(2 * FBM * (32 + FPAD) + 2 * BN * (32 + FPAD)) * sizeof(bf16_t);
     LAUNCH((gemm_nt_bf16_kernel<BN, EPI_STORE, 32>), g, dim3(256), lds32, st, a);
-    return (int)hipGetLastError();
+    return launch_status();
   }
 #define FAST_CASE(E)                                                                                   \
   if (epi == E || (E == EPI_STORE && epi == EPI_RESID)) {                                              \
@@ -882,7 +889,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
       once = true;                                                                                     \
     }                                                                                                  \
     LAUNCH((gemm_nt_bf16_kernel<BN, E>), g, dim3(256), lds, st, a);                        \
-    return (int)hipGetLastError();                                                                     \
+    return launch_status();                                                                     \
   }
   FAST_CASE(EPI_STORE)
   FAST_CASE(EPI_GELU_SUMSQ)
@@ -897,12 +904,12 @@ static int launch_nt3_k(const GemmP& a, const Nt3Scales& sc, hipStream_t st) {
   static bool once = false;
   if (!once) {
     if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return (int)hipGetLastError();
+      return launch_status();
     once = true;
   }
   dim3 g(cdiv(a.M, N3_BM), cdiv(a.N, N3_BN));
   LAUNCH((gemm_nt3_kernel<EPI>), g, dim3(N3_T), lds, st, a, sc);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
@@ -919,11 +926,11 @@ static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
       if (epi == EPI_DZ_STATS)
         LAUNCH(reduce_tile_groups_kernel, dim3(rg), dim3(256), 0, st, (const float*)(a.ws + (size_t)mblocks * 4 * a.N), mblocks, a.N,
                a.rpg, G, a.s1);
-      return (int)hipGetLastError();
+      return launch_status();
     }
     launch_reduce(0, a.ws, mblocks, a.N, a.s0, nullptr, 0, 0, 0, 0, st);
     if (epi == EPI_DZ_STATS) launch_reduce(0, a.ws + (size_t)mblocks * a.N, mblocks, a.N, a.s1, nullptr, 0, 0, 0, 0, st);
-    err = (int)hipGetLastError();
+    err = launch_status();
   }
   return err;
 }
@@ -989,7 +996,7 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
     launch_reduce(1, a.ws, splits, nk + a.Nn, a.dW, nullptr, a.Kk, a.sn, a.sk, nk, st);
     if (a.db) launch_reduce(3, a.ws, splits, nk + a.Nn, nullptr, a.db, nk, 1, 0, 0, st);
   }
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 static int launch_wgrad_fast(WgradP a, hipStream_t st) {
@@ -1010,7 +1017,7 @@ static int launch_wgrad_fast(WgradP a, hipStream_t st) {
   LAUNCH(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const float* beta, int M, int H, int rpg,
@@ -1136,7 +1143,7 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
       launch_reduce(1, a.ws, blocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
     }
   }
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 // chunked variants (rsc.cuh): weights streamed through LDS, any M
@@ -1222,7 +1229,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   } else {
     return (int)hipErrorInvalidValue;
   }
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
@@ -1433,7 +1440,7 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
       if (hipStreamWaitEvent(main, p->join[l], 0) != hipSuccess) return (int)hipGetLastError();
     }
   }
-  return (int)hipGetLastError();
+  return launch_status();
 }
 
 int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total, mpmae_stream_t s) {

@@ -311,6 +311,33 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
     }
   };
   prefetch(0);
+  // band offsets of this lane's elements, once per workgroup (no integer division in the row loop): planar order for the target
+  // statistics (8 consecutive lanes = one image row of the patch: conflict-free), prediction order for the squared error
+  // (only while the tables fit the register file: the 112/16 variant computes them in the loop)
+  constexpr int MAXJ = 4 * MAXP;
+  constexpr bool PRE = MAXP <= 3;
+  int offp[PRE ? MAXJ : 1], offq[PRE ? MAXP : 1][4];
+  auto planar_off = [&](int u) {
+    const int i = lane + 64 * u;
+    const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
+    return i < J ? c * CP + ph * H + pw : -1;
+  };
+  auto pred_off = [&](int u, int (&o)[4]) {
+    const int v = lane + 64 * u;
+    int r = (4 * v) / C, c = 4 * v - r * C;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int ph = r / p, pw = r - ph * p;
+      o[e] = v < npv ? c * CP + ph * H + pw : -1;
+      if (++c == C) { c = 0; ++r; }
+    }
+  };
+  if constexpr (PRE) {
+#pragma unroll
+    for (int u = 0; u < MAXJ; ++u) offp[u] = planar_off(u);
+#pragma unroll
+    for (int u = 0; u < MAXP; ++u) pred_off(u, offq[u]);
+  }
   float as = 0.f, ac = 0.f;
   for (int py = 0; py < G; ++py) {
     __syncthreads();                                            // every wave is done with the previous band
@@ -350,37 +377,37 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       }
       const float* bp = lpc_band + px * p;
       float mean = 0.f, rstd = 1.f;
-      if (q.norm_pix) {                                          // planar walk: 8 consecutive lanes = one image row of the patch
-        float s1 = 0.f;
-        for (int i = lane; i < J; i += 64) {
-          const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
-          s1 += bp[c * CP + ph * H + pw];
-        }
-        mean = wave_sum(s1) / J;
-        float s2 = 0.f;
-        for (int i = lane; i < J; i += 64) {
-          const int c = i / PP, r = i - c * PP, ph = r / p, pw = r - ph * p;
-          const float d = bp[c * CP + ph * H + pw] - mean;
-          s2 += d * d;
+      if (q.norm_pix) {                                          // one LDS pass: the lane's targets stay in registers
+        float s1 = 0.f, s2 = 0.f;
+        if constexpr (PRE) {
+          float tv[MAXJ];
+#pragma unroll
+          for (int u = 0; u < MAXJ; ++u) { tv[u] = offp[u] >= 0 ? bp[offp[u]] : 0.f; s1 += tv[u]; }
+          mean = wave_sum(s1) / J;
+#pragma unroll
+          for (int u = 0; u < MAXJ; ++u) { const float d = offp[u] >= 0 ? tv[u] - mean : 0.f; s2 += d * d; }
+        } else {                                                 // large patches: two passes over the band instead of 48 registers
+          for (int u = 0; u < MAXJ; ++u) { const int o = planar_off(u); s1 += o >= 0 ? bp[o] : 0.f; }
+          mean = wave_sum(s1) / J;
+          for (int u = 0; u < MAXJ; ++u) { const int o = planar_off(u); const float d = o >= 0 ? bp[o] - mean : 0.f; s2 += d * d; }
         }
         rstd = 1.f / sqrtf(wave_sum(s2) / (J - 1) + 1.0e-6f);     // unbiased (torch .var default)
       }
       float se = 0.f, cnt = 0.f;
 #pragma unroll
       for (int u = 0; u < MAXP; ++u) {
-        const int v = lane + 64 * u;
-        if (v < npv) {
-          int r = (4 * v) / C, c = 4 * v - r * C;
+        int o4[4];
+        if constexpr (PRE) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int ph = r / p, pw = r - ph * p;
-            const float t = (bp[c * CP + ph * H + pw] - mean) * rstd;
-            const float d = pv[u][e] - t;
+          for (int e = 0; e < 4; ++e) o4[e] = offq[u][e];
+        } else pred_off(u, o4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (o4[e] >= 0) {
+            const float d = pv[u][e] - (bp[o4[e]] - mean) * rstd;
             const float e2 = d * d;
             if (!isnan(e2)) { se += e2; cnt += 1.f; }
-            if (++c == C) { c = 0; ++r; }
           }
-        }
       }
       se = wave_sum(se); cnt = wave_sum(cnt);
       const float lp = se / cnt;                                 // 0/0 -> NaN -> dropped below
