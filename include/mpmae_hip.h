@@ -245,7 +245,7 @@ int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* args, const uint32_t* scales_a, 
  * recorded programs are the only state it keeps - every other entry point is a pure function of its arguments. Defaults
  * are the measured-best choices on MI355X. */
 enum MpmaeOption {
-  MPMAE_OPT_LNB_BLOCKS = 0,   /* default 1024: workgroup cap of the LayerNorm backward (slab rows) */
+  MPMAE_OPT_LNB_BLOCKS = 0,   /* default 512: workgroup cap of the LayerNorm backward (one fp32 slab row of partial gamma / beta gradients per workgroup) */
   MPMAE_OPT_DW_NT8,   /* default 512: threads per workgroup of the v5 depthwise kernels at S = 8 */
   MPMAE_OPT_DW6_T8,   /* default 320: threads per workgroup, packed depthwise S = 8 */
   MPMAE_OPT_DW6_T4,   /* default 320: ... S = 4 */

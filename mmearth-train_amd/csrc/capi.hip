@@ -94,7 +94,7 @@ static void launch_reduce(int mode, const float* part, int P, int W, float* out,
 // variables read inside the library; defaults are the measured-best choices.
 // ------------------------------------------------------------------------------------------
 static int g_opt[MPMAE_OPT_COUNT_] = {
-    /* MPMAE_OPT_LNB_BLOCKS */ 1024,
+    /* MPMAE_OPT_LNB_BLOCKS */ 512,
     /* MPMAE_OPT_DW_NT8 */ 512,
     /* MPMAE_OPT_DW6_T8 */ 320,
     /* MPMAE_OPT_DW6_T4 */ 320,
@@ -302,13 +302,13 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
     int lncap;
     lncap = g_opt[MPMAE_OPT_LNB_BLOCKS];   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
     int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, lncap);        // one slab row per wave; enough waves to hide the row latency
-    while ((size_t)b2 * 4 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
+    while ((size_t)b2 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
 #define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask, down_S)
 #define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
     if (dt == 0) LNB_T(float); else LNB_T(bf16_t);
 #undef LNB_T
 #undef LNB
-    blocks = b2 * 4;                                                  // slab rows = waves
+    blocks = b2;                                                      // slab rows = workgroups (the 4 waves fold in LDS)
   } else if (dt == 0)
     LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
                        (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);

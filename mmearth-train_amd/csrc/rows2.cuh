@@ -49,8 +49,11 @@ __global__ __launch_bounds__(256) void ln_fwd_v2_kernel(const T* __restrict__ x,
       const int vi = gl + p * G;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        ga[p][e] = (vi < nvec) ? gamma[vi * 8 + e] : 0.f;
-        be[p][e] = (vi < nvec) ? beta[vi * 8 + e] : 0.f;
+        // unconditional, clamped (a load under a per-lane condition is a branch + wait of its own: 16 of them made this
+        // kernel 28 us at C = 512 where a plain copy of the same rows takes 4 us)
+        const float gv = gamma[min(vi, nvec - 1) * 8 + e], bv = beta[min(vi, nvec - 1) * 8 + e];
+        ga[p][e] = (vi < nvec) ? gv : 0.f;
+        be[p][e] = (vi < nvec) ? bv : 0.f;
       }
     }
   }
@@ -63,8 +66,8 @@ __global__ __launch_bounds__(256) void ln_fwd_v2_kernel(const T* __restrict__ x,
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int vi = gl + p * G;
-      if (rok && vi < nvec) ld8<T>(x + (size_t)m * C + vi * 8, v[p]);
-      else {
+      ld8<T>(x + (size_t)min(m, M - 1) * C + min(vi, nvec - 1) * 8, v[p]);          // unconditional, clamped; zeroed below
+      if (!(rok && vi < nvec)) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[p][e] = 0.f;
       }
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
                                                         float* __restrict__ ws, int M, int C,
                                                         const uint8_t* __restrict__ rowmask, int down_S) {
   constexpr int RPW = 64 / G;
-  const int lane = threadIdx.x & 63;
+  __shared__ float ln2_comb[4 * 2 * 1024];       // [wave][dgamma | dbeta][C], C <= 1024 (checked by the launcher)
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int gl = lane % G, rl = lane / G;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -132,8 +136,9 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
     const int vi = gl + p * G;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      ga[p][e] = (vi < nvec) ? gamma[vi * 8 + e] : 0.f;
-      be[p][e] = (vi < nvec && act == 1) ? beta[vi * 8 + e] : 0.f;
+      const float gv = gamma[min(vi, nvec - 1) * 8 + e], bv = beta ? beta[min(vi, nvec - 1) * 8 + e] : 0.f;      // unconditional, clamped
+      ga[p][e] = (vi < nvec) ? gv : 0.f;
+      be[p][e] = (vi < nvec && act == 1) ? bv : 0.f;
       ag[p][e] = 0.f; ab[p][e] = 0.f;
     }
   }
@@ -148,10 +153,16 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
       const int vi = gl + p * G;
 #pragma unroll
       for (int e = 0; e < 8; ++e) { g[p][e] = 0.f; xh[p][e] = 0.f; }
-      if (live && vi < nvec) {
-        float d[8];
-        ld8<T>(xhat + (size_t)m * C + vi * 8, xh[p]);
-        ld8<T>(dy + (down_S ? down_group_off(m, down_S, C) : (size_t)(m / dy_div) * C) + vi * 8, d);
+      float d[8];
+      {
+        const int mc = min(m, M - 1), vc = min(vi, nvec - 1);                        // unconditional, clamped loads
+        ld8<T>(xhat + (size_t)mc * C + vc * 8, xh[p]);
+        ld8<T>(dy + (down_S ? down_group_off(mc, down_S, C) : (size_t)(mc / dy_div) * C) + vc * 8, d);
+      }
+      if (!(live && vi < nvec)) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[p][e] = 0.f;
+      } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float dd = d[e] * dy_scale;
@@ -166,7 +177,8 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
     }
     s1 = group_sum<G>(s1) / C;
     s2 = group_sum<G>(s2) / C;
-    const float rs = live ? rstd[m] : 0.f;
+    const float rsl = rstd[min(m, M - 1)];
+    const float rs = live ? rsl : 0.f;
 #pragma unroll
     for (int p = 0; p < PER; ++p) {
       const int vi = gl + p * G;
@@ -192,12 +204,14 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
       float a = ag[p][e], b = ab[p][e];
 #pragma unroll
       for (int o = G; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-      if (rl == 0 && vi < nvec) {
-        ws[((size_t)wave_global * 2 + 0) * C + vi * 8 + e] = a;
-        ws[((size_t)wave_global * 2 + 1) * C + vi * 8 + e] = b;
-      }
+      if (rl == 0 && vi < nvec) { ln2_comb[(wib * 2 + 0) * C + vi * 8 + e] = a; ln2_comb[(wib * 2 + 1) * C + vi * 8 + e] = b; }
     }
   }
+  // the 4 waves of a workgroup fold their partials in LDS: ONE slab row per workgroup (the per-wave rows were 16 MB of fp32 slab
+  // written and re-read by the second stage for 38 MB of activations at the decoder shape)
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256)
+    ws[(size_t)blockIdx.x * 2 * C + i] = ln2_comb[i] + ln2_comb[2 * C + i] + ln2_comb[4 * C + i] + ln2_comb[6 * C + i];
 }
 
 // column statistics v2: each wave owns a slab of rows and ALL columns in 16-byte vectors

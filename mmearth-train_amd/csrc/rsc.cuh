@@ -25,6 +25,18 @@
 // weight rows in LDS: odd multiple of 16 bytes (a 32 mod 64 byte stride made no difference here)
 constexpr int RSC_PAD = 8;
 
+// Loads in these kernels are UNCONDITIONAL from a clamped address and zeroed afterwards with a mask: `cond ? *ptr : 0` on a per-lane
+// condition is a branch, every branch region gets its own s_waitcnt vmcnt(0), and a prologue of N such loads costs N memory latencies
+// (rsc_wide: activity byte -> wait -> 2 row vectors -> wait -> 3 row vectors -> wait, before the first MFMA).
+__device__ __forceinline__ uint4 and4(const uint4& v, bool keep) {
+  const unsigned m = keep ? 0xffffffffu : 0u;
+  return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+}
+__device__ __forceinline__ uint2 and2(const uint2& v, bool keep) {
+  const unsigned m = keep ? 0xffffffffu : 0u;
+  return make_uint2(v.x & m, v.y & m);
+}
+
 __device__ __forceinline__ uint2 pack_bf16x4(const float (&v)[4]) {
   uint2 u;
   u.x = f2bf2(v[0], v[1]);
@@ -62,8 +74,8 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
-      wr[i] = (v < NC * VPR && (!PAD || k < KC)) ? *reinterpret_cast<const uint4*>(p.W + (size_t)(n_begin + c * NC + n) * p.ldw + k)
-                                                 : make_uint4(0u, 0u, 0u, 0u);
+      const int vc = min(v, NC * VPR - 1), nc = vc / VPR, kc = min((vc - nc * VPR) * 8, KC - 8);
+      wr[i] = and4(*reinterpret_cast<const uint4*>(p.W + (size_t)(n_begin + c * NC + nc) * p.ldw + kc), v < NC * VPR && (!PAD || k < KC));
     }
   };
   auto wstore = [&](int buf) {
@@ -82,12 +94,16 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   for (int rt = 0; rt < RT; ++rt) {
     const int row = rbase + rt * 16 + lr;
     const bool inb = row < p.M;
-    live[rt] = inb && (!p.act || p.act[row]);
+    const int rowc = min(row, p.M - 1);
+    const uint8_t abl = *(p.act ? p.act + rowc : reinterpret_cast<const uint8_t*>(p.A));      // pointer select, not a branch
+    const uint8_t ab = p.act ? abl : (uint8_t)1;
     uint4 raw[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s)
-      raw[s] = (inb && (!PAD || s * 32 + lg * 8 < KC)) ? *reinterpret_cast<const uint4*>(p.A + (size_t)row * KC + s * 32 + lg * 8)
-                                                     : make_uint4(0u, 0u, 0u, 0u);
+      raw[s] = *reinterpret_cast<const uint4*>(p.A + (size_t)rowc * KC + min(s * 32 + lg * 8, KC - 8));
+    live[rt] = inb && ab;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) raw[s] = and4(raw[s], inb && (!PAD || s * 32 + lg * 8 < KC));
     if (MODE == 0) {
       float v[KS][8];
       float s1 = 0.f;
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const int row = rbase + rt * 16 + lr;
-          hraw[rt] = (row < p.M) ? *reinterpret_cast<const uint4*>(p.R + (size_t)row * HN + n8) : make_uint4(0u, 0u, 0u, 0u);
+          hraw[rt] = and4(*reinterpret_cast<const uint4*>(p.R + (size_t)min(row, p.M - 1) * HN + n8), row < p.M);
         }
       }
       bf16x8_t wf[2][KS];
@@ -285,8 +301,8 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
       const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
-      wr[i] = (v < NP * VPR && (!PAD || n < KC)) ? *reinterpret_cast<const uint4*>(p.W + (size_t)n * p.ldw + kc * KCH + k)
-                                                 : make_uint4(0u, 0u, 0u, 0u);
+      const int vc = min(v, NP * VPR - 1), nc = min(vc / VPR, KC - 1), kq = (vc - (vc / VPR) * VPR) * 8;
+      wr[i] = and4(*reinterpret_cast<const uint4*>(p.W + (size_t)nc * p.ldw + kc * KCH + kq), v < NP * VPR && (!PAD || n < KC));
     }
   };
   auto wstore = [&](int buf) {
@@ -297,14 +313,16 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     }
   };
 
-  int rowv[RT];
+  int rowv[RT], rowc[RT];                 // row, and the row clamped into the matrix (load address of out-of-range lanes)
   bool inb[RT], live[RT];
   size_t goff[RT];                       // row's GRN group offset into scale / beta / coef
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     rowv[rt] = rbase + rt * 16 + lr;
     inb[rt] = rowv[rt] < p.M;
-    live[rt] = inb[rt] && (!p.act || p.act[rowv[rt]]);
+    rowc[rt] = min(rowv[rt], p.M - 1);
+    const uint8_t abl = *(p.act ? p.act + rowc[rt] : reinterpret_cast<const uint8_t*>(p.W));      // pointer select, not a branch
+    live[rt] = inb[rt] && (p.act ? abl != 0 : true);
     goff[rt] = (inb[rt] && !STG) ? (size_t)(rowv[rt] / rpg) * HN : 0;
   }
   constexpr int NB = EARLY ? 2 : 1;
@@ -315,9 +333,9 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int s = 0; s < KSC; ++s) {
-        const size_t off = (size_t)rowv[rt] * HN + kc * KCH + s * 32 + lg * 8;
-        if (!RC) araw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0u, 0u, 0u, 0u);
-        if (MODE == 1) hraw[B][rt][s] = inb[rt] ? *reinterpret_cast<const uint4*>(p.A2 + off) : make_uint4(0u, 0u, 0u, 0u);
+        const size_t off = (size_t)rowc[rt] * HN + kc * KCH + s * 32 + lg * 8;
+        if (!RC) araw[B][rt][s] = and4(*reinterpret_cast<const uint4*>(p.A + off), inb[rt]);
+        if (MODE == 1) hraw[B][rt][s] = and4(*reinterpret_cast<const uint4*>(p.A2 + off), inb[rt]);
       }
   };
 
@@ -333,7 +351,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 #pragma unroll
       for (int s2 = 0; s2 < KS2; ++s2) {
         const int k = s2 * 32 + lg * 8;
-        const uint4 v = (inb[rt] && k < KC) ? *reinterpret_cast<const uint4*>(p.D + (size_t)rowv[rt] * KC + k) : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 v = and4(*reinterpret_cast<const uint4*>(p.D + (size_t)rowc[rt] * KC + min(k, KC - 8)), inb[rt] && k < KC);
         df[rt][s2] = __builtin_bit_cast(bf16x8_t, v);
       }
   }
@@ -483,32 +501,53 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   for (int rt = 0; rt < RT; ++rt) {
     const int row = rowv[rt];
     if (MODE == 0) {
+      // residual and bias vectors of every tile first, unconditionally (pointer select for the optional operands): one memory
+      // latency for the epilogue instead of one per 16-column tile
+      uint2 rraw[NT];
+      float4 b4[NT];
+      const bf16_t* rp = p.R ? p.R + (size_t)rowc[rt] * KC : p.W;
+      const float* bp = p.bias ? p.bias : p.v1;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4c = min(j * 16 + lg * 4, KC - 4);
+        rraw[j] = *reinterpret_cast<const uint2*>(rp + n4c);
+        b4[j] = *reinterpret_cast<const float4*>(bp + n4c);
+      }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
         const bool nin = !PAD || n4 < KC;
-        float x[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
-        if (inb[rt] && nin && p.R) unpack4(*reinterpret_cast<const uint2*>(p.R + (size_t)row * KC + n4), x);
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias && nin) b = *reinterpret_cast<const float4*>(p.bias + n4);
-        const float bb[4] = {b.x, b.y, b.z, b.w};
+        float x[4], o[4];
+        unpack4(and2(rraw[j], inb[rt] && nin && p.R != nullptr), x);
+        const bool hb = p.bias != nullptr && nin;
+        const float bb[4] = {hb ? b4[j].x : 0.f, hb ? b4[j].y : 0.f, hb ? b4[j].z : 0.f, hb ? b4[j].w : 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = live[rt] ? acc[rt][j][r] + bb[r] + x[r] : 0.f;
         if (inb[rt] && nin) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
       }
     } else {
       // LayerNorm backward: row sums are lane-local over (j, r) plus the 4 lane groups
+      // every x-hat vector, gamma vector and the row's rstd first, unconditionally (one memory latency for the whole epilogue
+      // instead of one per 16-column tile: written as `cond ? load : 0` inside the tile loop these were NT serial round trips)
       uint2 xraw[NT];
+      float4 gq4[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4c = min(j * 16 + lg * 4, KC - 4);
+        xraw[j] = *reinterpret_cast<const uint2*>(p.xhat + (size_t)rowc[rt] * KC + n4c);
+        gq4[j] = *reinterpret_cast<const float4*>(p.lng + n4c);
+      }
+      const float rsl = p.rstd[rowc[rt]];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
         const bool nin = !PAD || n4 < KC;
-        xraw[j] = (inb[rt] && nin) ? *reinterpret_cast<const uint2*>(p.xhat + (size_t)row * KC + n4) : make_uint2(0u, 0u);
+        xraw[j] = and2(xraw[j], inb[rt] && nin);
         float xh[4];
         unpack4(xraw[j], xh);
-        const float4 g = nin ? *reinterpret_cast<const float4*>(p.lng + n4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float gg[4] = {g.x, g.y, g.z, g.w};
+        const float4 g = gq4[j];
+        const float gg[4] = {nin ? g.x : 0.f, nin ? g.y : 0.f, nin ? g.z : 0.f, nin ? g.w : 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float dxn = live[rt] ? bf2f(f2bf(acc[rt][j][r])) : 0.f;      // bf16 like the unfused path
@@ -523,7 +562,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       s1 /= KC; s2 /= KC;
-      const float rs = inb[rt] ? p.rstd[row] : 0.f;
+      const float rs = inb[rt] ? rsl : 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
