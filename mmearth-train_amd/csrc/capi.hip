@@ -301,7 +301,11 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
     const int rpw = 64 / G;
     int lncap;
     lncap = g_opt[MPMAE_OPT_LNB_BLOCKS];   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
-    int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, lncap);        // one slab row per wave; enough waves to hide the row latency
+    // one fp32 slab row (2C floats) per workgroup, folded from its 4 waves in LDS. Measured (M = 12 544, C = 512): 18 / 21 / 28 / 37 us
+    // at 512 / 1024 / 2048 / 4096 workgroups - the per-wave prologue (gamma / beta vectors) and the fold are the fixed costs, so few
+    // long-running waves win; narrow rows (C < 256: many rows per wave iteration) keep twice the cap
+    const int capc = C >= 256 ? lncap : 2 * lncap;
+    int b2 = grid1d((long long)cdiv(M, rpw) * 64, 256, capc);
     while ((size_t)b2 * 2 * C > ws_floats && b2 > 1) b2 /= 2;
 #define LNB(TT, GG, PP) LAUNCH((ln_bwd_v2_kernel<TT, GG, PP>), dim3(b2), dim3(256), 0, S_(s), (const TT*)dy, dy_div, dy_scale, (const TT*)xhat, rstd, gamma, beta, act, (TT*)dx, accumulate, ws, M, C, rowmask, down_S)
 #define LNB_T(TT) do { if (G == 8) LNB(TT, 8, 1); else if (G == 16) LNB(TT, 16, 1); else if (G == 32) LNB(TT, 32, 1); else if (per == 1) LNB(TT, 64, 1); else LNB(TT, 64, 2); } while (0)
@@ -1293,7 +1297,7 @@ int mpmae_im2col3(int dt, const float* img, const int* vis, const int* inv, void
                   int S, int Cseg, int H, mpmae_stream_t s) {
   const int epv = dt == 0 ? 4 : 8;
   if (!img || !vis || !inv || !out || ldo < 9 * Cseg || (ldo % epv) || S < 1 || S > 16) return (int)hipErrorInvalidValue;
-  const size_t lds = (size_t)(S + 2) * (S + 2) * Cseg * sizeof(float);
+  const size_t lds = (size_t)(S + 2) * (S + 2) * (Cseg | 1) * sizeof(float);      // odd channel pitch in LDS
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
   if (dt == 0) LAUNCH(im2col3_kernel<float>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (float*)out, ldo, keep, grid, S, Cseg, H);
   else LAUNCH(im2col3_kernel<bf16_t>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (bf16_t*)out, ldo, keep, grid, S, Cseg, H);

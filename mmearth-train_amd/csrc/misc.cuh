@@ -150,20 +150,27 @@ template <typename T>
 __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ img, const int* __restrict__ vis,
                                                       const int* __restrict__ inv, T* __restrict__ out, int ldo,
                                                       int keep, int grid, int S, int Cseg, int H) {
-  extern __shared__ float win[];                  // [(S+2)*(S+2)][Cseg]
+  extern __shared__ float win[];                  // [(S+2)*(S+2)][CP], CP = Cseg | 1 (odd pitch: the 8 taps x channels a lane reads
+  __shared__ int nb_ok[9];                        //  per output vector spread over the banks; pitch 12 was 75 % bank conflicts)
+  const int CP = Cseg | 1;
   const int nk = blockIdx.x, n = nk / keep;
   const int patch = vis[nk];
   const int py = patch / grid, px = patch - py * grid;
   const int W2 = S + 2, L = grid * grid;
+  // visibility of the 3 x 3 neighbour patches first (9 lookups), then every window element UNCONDITIONALLY from a clamped address:
+  // `if (inside) if (inv[..] >= 0) v = img[..]` was two dependent round trips per element and loop iteration
+  if (threadIdx.x < 9) {
+    const int qy = py + (int)threadIdx.x / 3 - 1, qx = px + (int)threadIdx.x % 3 - 1;
+    const bool in = qy >= 0 && qx >= 0 && qy < grid && qx < grid;
+    nb_ok[threadIdx.x] = in ? (inv[n * L + min(max(qy, 0), grid - 1) * grid + min(max(qx, 0), grid - 1)] >= 0) : 0;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < W2 * W2 * Cseg; i += blockDim.x) {
     const int wx = i % W2, r = i / W2, wy = r % W2, cin = r / W2;       // x fastest: contiguous image reads
     const int gy = py * S + wy - 1, gx = px * S + wx - 1;
-    float v = 0.f;
-    if (gy >= 0 && gx >= 0 && gy < H && gx < H) {
-      const int pp = (gy / S) * grid + gx / S;
-      if (inv[n * L + pp] >= 0) v = img[((size_t)(n * Cseg + cin) * H + gy) * H + gx];
-    }
-    win[(wy * W2 + wx) * Cseg + cin] = v;
+    const int by = wy == 0 ? 0 : (wy == W2 - 1 ? 2 : 1), bx = wx == 0 ? 0 : (wx == W2 - 1 ? 2 : 1);
+    const float v = img[((size_t)(n * Cseg + cin) * H + min(max(gy, 0), H - 1)) * H + min(max(gx, 0), H - 1)];
+    win[(wy * W2 + wx) * CP + cin] = nb_ok[by * 3 + bx] ? v : 0.f;
   }
   __syncthreads();
   constexpr int EPV = 16 / sizeof(T);
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
       if (k < K) {
         const int tap = k / Cseg, cin = k - tap * Cseg;
         const int kh = tap % 3, kw = tap / 3;
-        x = win[((iy + kh) * W2 + ix + kw) * Cseg + cin];
+        x = win[((iy + kh) * W2 + ix + kw) * CP + cin];
       }
       o[e] = x;
     }
