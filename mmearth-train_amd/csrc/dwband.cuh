@@ -122,8 +122,11 @@ __global__ __launch_bounds__(512) void dwconv7_band_kernel(const DwP p) {
     uint8_t live[S];
 #pragma unroll
     for (int o = 0; o < S; ++o) {
-      addraw[o] = add ? *reinterpret_cast<const uint32_t*>(add + (r0 + o * S) * C + 2 * cp) : 0u;
-      live[o] = p.act ? p.act[r0 + o * S] : 1;
+      // optional operands through a pointer select (unconditional loads; a branch here parks a wait in front of the tap loop)
+      const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (r0 + o * S) * C + 2 * cp : reinterpret_cast<const T*>(p.w));
+      const uint8_t lv = *(p.act ? p.act + r0 + o * S : reinterpret_cast<const uint8_t*>(p.w));
+      addraw[o] = add ? ar : 0u;
+      live[o] = p.act ? lv : (uint8_t)1;
       acc[o] = b2;
     }
 #pragma unroll 1
