@@ -315,14 +315,15 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
 
   int rowv[RT], rowc[RT];                 // row, and the row clamped into the matrix (load address of out-of-range lanes)
   bool inb[RT], live[RT];
+  uint8_t abl[RT];
   size_t goff[RT];                       // row's GRN group offset into scale / beta / coef
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     rowv[rt] = rbase + rt * 16 + lr;
     inb[rt] = rowv[rt] < p.M;
     rowc[rt] = min(rowv[rt], p.M - 1);
-    const uint8_t abl = *(p.act ? p.act + rowc[rt] : reinterpret_cast<const uint8_t*>(p.W));      // pointer select, not a branch
-    live[rt] = inb[rt] && (p.act ? abl != 0 : true);
+    abl[rt] = *(p.act ? p.act + rowc[rt] : reinterpret_cast<const uint8_t*>(p.W));      // pointer select, not a branch; turned into
+    live[rt] = false;                                                                 // `live` only after the operand loads are out
     goff[rt] = (inb[rt] && !STG) ? (size_t)(rowv[rt] / rpg) * HN : 0;
   }
   constexpr int NB = EARLY ? 2 : 1;
@@ -446,43 +447,73 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
       }
     } else if (MODE == 0) {                         // grn_fwd_finalize_kernel (rows.cuh), same summation order
+      // every vector element this thread owns is requested up front (NJ = ceil(H / 256) is a compile-time count, addresses clamped):
+      // as `for (j = tid; j < H; j += 256)` loops with the loads inside, the finalisation was five serial round trips - each behind
+      // an s_waitcnt vmcnt(0) that also drained the operand loads already in flight - before the first MFMA of every workgroup
+      constexpr int NJ = (HN + 255) / 256;
+      float fs[NJ], fg[NJ], fb[NJ];
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int jc = min(tid + 256 * u, HN - 1);
+        fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fb[u] = p.v1[jc];
+      }
       float s = 0.f;
-      for (int j = tid; j < HN; j += 256) { const float gx = sqrtf(p.fin_sum[j]); vec[j] = gx; s += gx; }
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) { fs[u] = sqrtf(fs[u]); s += (tid + 256 * u < HN) ? fs[u] : 0.f; }
       s = wave_sum(s);
       if (lane == 0) fsh[wave] = s;
       __syncthreads();
       const float ainv = 1.f / ((fsh[0] + fsh[1] + fsh[2] + fsh[3]) / HN + p.fin_eps);
       const bool pub = blockIdx.x == 0;
       if (pub && tid == 0) p.fin_ainv[0] = ainv;
-      for (int j = tid; j < HN; j += 256) {
-        const float gx = vec[j], sc = 1.f + p.fin_gamma[j] * (gx * ainv);
-        vec[j] = sc;
-        vec[HN + j] = p.v1[j];
-        if (pub) { p.fin_gx[j] = gx; p.fin_out[j] = sc; }
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + 256 * u;
+        if (j < HN) {
+          const float gx = fs[u], sc = 1.f + fg[u] * (gx * ainv);
+          vec[j] = sc;
+          vec[HN + j] = fb[u];
+          if (pub) { p.fin_gx[j] = gx; p.fin_out[j] = sc; }
+        }
       }
     } else {                                        // grn_bwd_finalize_kernel
+      constexpr int NJ = (HN + 255) / 256;
+      float fs[NJ], fg[NJ], fx[NJ], f0[NJ], fv[NJ];
+      const float* s0p = p.fin_sum0 ? p.fin_sum0 : p.fin_sum;
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int jc = min(tid + 256 * u, HN - 1);
+        fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fx[u] = p.fin_gx[jc]; f0[u] = s0p[jc]; fv[u] = p.v0[jc];
+      }
       const float ainv = p.fin_ainv[0];
       float s = 0.f;
-      for (int j = tid; j < HN; j += 256) s += p.fin_gamma[j] * p.fin_sum[j] * p.fin_gx[j];
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) s += (tid + 256 * u < HN) ? fg[u] * fs[u] * fx[u] : 0.f;
       s = wave_sum(s);
       if (lane == 0) fsh[wave] = s;
       __syncthreads();
       const float T2 = (fsh[0] + fsh[1] + fsh[2] + fsh[3]) * ainv * ainv / HN;
       const bool pub = blockIdx.x == 0;
-      for (int j = tid; j < HN; j += 256) {
-        const float gx = p.fin_gx[j], s1 = p.fin_sum[j];
-        const float dGx = p.fin_gamma[j] * s1 * ainv - T2;
-        const float cf = (gx > 0.f) ? dGx / gx : 0.f;
-        vec[j] = p.v0[j];
-        vec[HN + j] = cf;
-        if (pub) {
-          if (p.fin_out) p.fin_out[j] = cf;
-          atomicAdd(p.fin_dgamma + j, gx * ainv * s1);
-          atomicAdd(p.fin_dbeta + j, p.fin_sum0[j]);
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + 256 * u;
+        if (j < HN) {
+          const float gx = fx[u], s1 = fs[u];
+          const float dGx = fg[u] * s1 * ainv - T2;
+          const float cf = (gx > 0.f) ? dGx / gx : 0.f;
+          vec[j] = fv[u];
+          vec[HN + j] = cf;
+          if (pub) {
+            if (p.fin_out) p.fin_out[j] = cf;
+            atomicAdd(p.fin_dgamma + j, gx * ainv * s1);
+            atomicAdd(p.fin_dbeta + j, f0[u]);
+          }
         }
       }
     }
   }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) live[rt] = inb[rt] && (p.act ? abl[rt] != 0 : true);
   wstore(0);
   if (RC) wstore2(0);
   __syncthreads();
