@@ -35,16 +35,25 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   constexpr int U = 4, WMAX = (49 * CW + 255) / 256;
   const int items = p.g.keep * S * S * D::VPL;
   const T* x = reinterpret_cast<const T*>(p.x);
-  auto row_ld = [&](int it, int& dst) -> uint4 {          // by value: arrays captured by reference ended up in scratch
-    const bool ok = it < items;
-    const int itc = ok ? it : 0;
+  // A row vector's LDS destination needs the patch index (a `vis` lookup), its source address does not: the lookup and the data
+  // load are both issued by row_ld (the lookup through a pointer select, no branch) and the destination is worked out by row_dst
+  // AFTER all of a thread's loads are out. Computed inside row_ld, every vector cost two dependent round trips (lookup -> wait ->
+  // destination -> data load), eight in a row at the top of every workgroup of the stage-2 kernel.
+  auto row_ld = [&](int it, int& patch_raw) -> uint4 {    // by value: arrays captured by reference ended up in scratch
+    const int itc = it < items ? it : 0;
     const int v = itc % D::VPL, pt = itc / D::VPL;
     const int slot = pt / (S * S), q = pt - slot * (S * S);
-    const int iy = q / S, ix = q - iy * S;
-    const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
-    const int py = patch / p.g.grid, px = patch - py * p.g.grid;
-    dst = ok ? (((py * S + iy + 3) * MS + px * S + ix + 3) * CW + v * D::EPV) : -1;
+    patch_raw = *(p.g.vis ? p.g.vis + n * p.g.keep + slot : reinterpret_cast<const int*>(p.w));
     return *reinterpret_cast<const uint4*>(x + ((size_t)(n * p.g.keep + slot) * (S * S) + q) * C + c0 + v * D::EPV);
+  };
+  auto row_dst = [&](int it, int patch_raw) -> int {
+    if (it >= items) return -1;
+    const int v = it % D::VPL, pt = it / D::VPL;
+    const int slot = pt / (S * S), q = pt - slot * (S * S);
+    const int iy = q / S, ix = q - iy * S;
+    const int patch = p.g.vis ? patch_raw : slot;
+    const int py = patch / p.g.grid, px = patch - py * p.g.grid;
+    return ((py * S + iy + 3) * MS + px * S + ix + 3) * CW + v * D::EPV;
   };
   auto row_st = [&](const uint4& v, int dst) { if (dst >= 0) *reinterpret_cast<uint4*>(map + dst) = v; };
   auto tap = [&](int i) {
@@ -54,9 +63,9 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
     return p.w[kh * p.s_kh + kw * p.s_kw + (c0 + cc) * p.s_c];
   };
   static_assert(U == 4, "four rows in flight per thread");
-  int d0, d1, d2, d3;
-  const uint4 v0 = row_ld(tid, d0), v1 = row_ld(tid + blockDim.x, d1), v2 = row_ld(tid + 2 * blockDim.x, d2),
-              v3 = row_ld(tid + 3 * blockDim.x, d3);
+  int q0, q1, q2, q3;
+  const uint4 v0 = row_ld(tid, q0), v1 = row_ld(tid + blockDim.x, q1), v2 = row_ld(tid + 2 * blockDim.x, q2),
+              v3 = row_ld(tid + 3 * blockDim.x, q3);
   float wv[WMAX];
 #pragma unroll
   for (int u = 0; u < WMAX; ++u) {
@@ -76,8 +85,9 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
     if (i < 49 * CW) wl[i] = wv[u];
   }
   for (int i = tid + WMAX * blockDim.x; i < 49 * CW; i += blockDim.x) wl[i] = tap(i);      // blocks under 256 threads
-  row_st(v0, d0); row_st(v1, d1); row_st(v2, d2); row_st(v3, d3);
-  for (int it = tid + blockDim.x * U; it < items; it += blockDim.x) { int d; const uint4 v = row_ld(it, d); row_st(v, d); }
+  row_st(v0, row_dst(tid, q0)); row_st(v1, row_dst(tid + blockDim.x, q1)); row_st(v2, row_dst(tid + 2 * blockDim.x, q2));
+  row_st(v3, row_dst(tid + 3 * blockDim.x, q3));
+  for (int it = tid + blockDim.x * U; it < items; it += blockDim.x) { int q; const uint4 v = row_ld(it, q); row_st(v, row_dst(it, q)); }
   __syncthreads();
 
   const int cp = lane % CP, ox = (lane / CP) % S, sub = lane / (CP * S);      // CP * S == 32
@@ -239,23 +249,30 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
     wv[u] = p.w[kh * p.s_kh + kw * p.s_kw + (cc0 + cc) * p.s_c];
   }
   const T* x = reinterpret_cast<const T*>(p.x);
-  auto row_ld = [&](int it, int& dst) -> uint4 {          // G*G*2 <= 128 items: at most 2 per lane
-    const bool ok = it < p.g.keep * 2;
-    const int v = it & 1, slot = ok ? it >> 1 : 0;
-    const int patch = p.g.vis ? p.g.vis[n * p.g.keep + slot] : slot;
-    const int py = patch / G, px = patch - py * G;
-    dst = ok ? ((py + 3) * MS + px + 3) * CW + v * 8 : -1;
-    return *reinterpret_cast<const uint4*>(x + (size_t)(n * p.g.keep + slot) * C + cc0 + v * 8);
+  // lookups (vis, inv) and row vectors are all REQUESTED first, through pointer selects; the LDS destinations / row numbers that
+  // depend on the lookups are worked out afterwards (see dwconv7_v6_kernel)
+  auto row_ld = [&](int it, int& patch_raw) -> uint4 {    // G*G*2 <= 128 items: at most 2 per lane
+    const int slot = it < p.g.keep * 2 ? it >> 1 : 0;
+    patch_raw = *(p.g.vis ? p.g.vis + n * p.g.keep + slot : reinterpret_cast<const int*>(p.w));
+    return *reinterpret_cast<const uint4*>(x + (size_t)(n * p.g.keep + slot) * C + cc0 + (it & 1) * 8);
   };
-  int d0, d1;
-  const uint4 v0 = row_ld(lane, d0), v1 = row_ld(lane + 64, d1);
+  auto row_dst = [&](int it, int patch_raw) -> int {
+    if (it >= p.g.keep * 2) return -1;
+    const int patch = p.g.vis ? patch_raw : it >> 1;
+    const int py = patch / G, px = patch - py * G;
+    return ((py + 3) * MS + px + 3) * CW + (it & 1) * 8;
+  };
+  int q0, q1;
+  const uint4 v0 = row_ld(lane, q0), v1 = row_ld(lane + 64, q1);
   const int cp = lane & 7, oxr = lane >> 3, ox = oxr < G ? oxr : 0;
   const int c = cc0 + 2 * cp;
   int rows[G];
 #pragma unroll
+  for (int o = 0; o < G; ++o) rows[o] = *(p.g.inv ? p.g.inv + n * G * G + o * G + ox : reinterpret_cast<const int*>(p.w));
+  const int d0 = row_dst(lane, q0), d1 = row_dst(lane + 64, q1);
+#pragma unroll
   for (int o = 0; o < G; ++o) {
-    const int patch = o * G + ox;
-    const int slot = p.g.inv ? p.g.inv[n * G * G + patch] : patch;
+    const int slot = p.g.inv ? rows[o] : o * G + ox;
     rows[o] = slot >= 0 ? n * p.g.keep + slot : -1;
   }
   {
