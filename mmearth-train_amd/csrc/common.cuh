@@ -229,3 +229,14 @@ __device__ __forceinline__ int geom_row_of(const Geom& g, int n, int gy, int gx)
   if (slot < 0) return -1;
   return (n * g.keep + slot) * g.S * g.S + (gy - py * g.S) * g.S + (gx - px * g.S);
 }
+
+// An all-ones / zero mask (in a VGPR) the optimizer cannot see through. `x = ptr ? load(ptr + i) : 0` (and `load(...) & (ptr ? ~0 : 0)`,
+// which instcombine folds back into the select) compile to a branch around the load with an `s_waitcnt vmcnt(0)` at its join: N optional
+// operands in a row become N serial round trips. With an opaque mask the load stays unconditional (from `ptr ? ptr + i : some_valid_address`)
+// and only the AND depends on it.
+__device__ __forceinline__ unsigned opaque_mask(bool on) {
+  unsigned m = on ? 0xffffffffu : 0u;
+  asm volatile("" : "+v"(m));
+  return m;
+}
+

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(512) void dwconv7_band_kernel(const DwP p) {
   // ---- convolution: item = (central visible patch, patch column ox, channel pair cp); consecutive lanes = consecutive cp
   T* out = reinterpret_cast<T*>(p.out);
   const T* add = reinterpret_cast<const T*>(p.add);
+  const unsigned add_m = opaque_mask(add != nullptr), act_m = opaque_mask(p.act != nullptr) & 0xffu;
   const int ncen = cnt[2], first_cen = cnt[3];                              // central patches are a contiguous run of the list
   const int items = ncen * S * CP;
   for (int it = tid; it < items; it += 512) {
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(512) void dwconv7_band_kernel(const DwP p) {
       // optional operands through a pointer select (unconditional loads; a branch here parks a wait in front of the tap loop)
       const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (r0 + o * S) * C + 2 * cp : reinterpret_cast<const T*>(p.w));
       const uint8_t lv = *(p.act ? p.act + r0 + o * S : reinterpret_cast<const uint8_t*>(p.w));
-      addraw[o] = add ? ar : 0u;
-      live[o] = p.act ? lv : (uint8_t)1;
+      addraw[o] = ar & add_m;                                   // opaque masks (see opaque_mask): a ternary on `add` is turned back
+      live[o] = (uint8_t)((lv & act_m) | (~act_m & 1u));        // into a branch around the load by the optimizer
       acc[o] = b2;
     }
 #pragma unroll 1

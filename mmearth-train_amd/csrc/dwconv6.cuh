@@ -94,6 +94,7 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   const int c = c0 + 2 * cp;
   T* out = reinterpret_cast<T*>(p.out);
   const T* add = reinterpret_cast<const T*>(p.add);
+  const unsigned add_m = opaque_mask(add != nullptr), act_m = opaque_mask(p.act != nullptr) & 0xffu;
   f32x2_t b2 = {0.f, 0.f};
   if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
 
@@ -111,8 +112,8 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
       // optional operands through a pointer select (unconditional loads; a branch here parks a wait in front of the tap loop)
       const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (r0 + o * S) * C + c : reinterpret_cast<const T*>(p.w));
       const uint8_t lv = *(p.act ? p.act + r0 + o * S : reinterpret_cast<const uint8_t*>(p.w));
-      addraw[o] = add ? ar : 0u;
-      live[o] = p.act ? lv : (uint8_t)1;
+      addraw[o] = ar & add_m;                                   // opaque masks (see opaque_mask): a ternary on `add` is turned back
+      live[o] = (uint8_t)((lv & act_m) | (~act_m & 1u));        // into a branch around the load by the optimizer
       acc[o] = b2;
     }
 #pragma unroll 1
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
   }
   T* out = reinterpret_cast<T*>(p.out);
   const T* add = reinterpret_cast<const T*>(p.add);
+  const unsigned add_m = opaque_mask(add != nullptr);
   f32x2_t b2 = {0.f, 0.f};
   if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
   uint32_t addraw[G];
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
 #pragma unroll
   for (int o = 0; o < G; ++o) {
     const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (size_t)max(rows[o], 0) * C + c : reinterpret_cast<const T*>(p.w));
-    addraw[o] = (add && rows[o] >= 0) ? ar : 0u;                 // unconditional load through a pointer select
+    addraw[o] = ar & add_m & (rows[o] >= 0 ? 0xffffffffu : 0u);   // unconditional load (pointer select + opaque mask)
     acc[o] = b2;
   }
   __syncthreads();
