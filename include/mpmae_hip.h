@@ -392,6 +392,12 @@ int mpmae_program_begin_op(MpmaeProgram* p, int lane, const int* waits, int nwai
 int mpmae_program_end(MpmaeProgram* p);
 int mpmae_program_num_ops(const MpmaeProgram* p);
 int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_stream);
+/* Hand an op's `signal` event to a stream outside the program (the gradient exchange waits for "bucket ready" points of a backward that
+ * is replayed as ONE run() call): export_signal keeps the event recorded although no op of the program waits for it (call after
+ * mpmae_program_end); stream_wait makes `stream` wait for the event as recorded by the most recent run() (no-op if that run did not
+ * reach the op). */
+int mpmae_program_export_signal(MpmaeProgram* p, int signal);
+int mpmae_program_stream_wait(MpmaeProgram* p, int signal, mpmae_stream_t stream);
 /* recordable fills / host->device copies (gradient and statistics clears, the AdamW hyper-parameter record) */
 int mpmae_memset_async(void* ptr, int value, size_t bytes, mpmae_stream_t stream);
 int mpmae_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, mpmae_stream_t stream);

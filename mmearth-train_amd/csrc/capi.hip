@@ -1407,6 +1407,21 @@ int mpmae_program_end(MpmaeProgram* p) {
 
 int mpmae_program_num_ops(const MpmaeProgram* p) { return p ? (int)p->ops.size() : -1; }
 
+// Export an op's `signal` event to a stream outside the program (the gradient exchange): export_signal() keeps the event recorded even
+// though no op of the program waits for it (call after mpmae_program_end), stream_wait() makes `stream` wait for the event as recorded
+// by the MOST RECENT run() call (a no-op when that call did not reach the op).
+int mpmae_program_export_signal(MpmaeProgram* p, int signal) {
+  if (!p || signal <= 0 || signal >= (int)p->waited.size() || p->sig_op[signal] < 0) return (int)hipErrorInvalidValue;
+  p->waited[signal] = 1;
+  return 0;
+}
+
+int mpmae_program_stream_wait(MpmaeProgram* p, int signal, mpmae_stream_t stream) {
+  if (!p || signal <= 0 || signal >= (int)p->events.size()) return (int)hipErrorInvalidValue;
+  if (p->epoch[signal] != p->run) return 0;
+  return hipStreamWaitEvent(S_(stream), p->events[signal], 0) == hipSuccess ? 0 : (int)hipGetLastError();
+}
+
 int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_) {
   if (!p || g_rec || first < 0 || count < 0 || first + count > (int)p->ops.size()) return (int)hipErrorInvalidValue;
   hipStream_t main = S_(main_);

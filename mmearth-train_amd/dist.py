@@ -12,8 +12,11 @@ points of the backward program (parameters are laid out in state-dict order, hea
     bucket 1  [proj ... pred_dict)      9.2 MB   proj, mask token, shared decoder block: ready after proj.wgrad
     bucket 2  [stages.2, stages.3]     11.7 MB   ready after the stage-3 and stage-2 blocks
     bucket 3  [0 ... stages.2)          1.9 MB   initial conv, stem, downsample layers, stages 0-1 (last)
-Each bucket is all-reduced (SUM) on a communication stream as soon as its segment of the backward program
-has been enqueued; averaging (1/world) is folded into the AdamW kernel's grad_scale. `allreduce_dtype=
+Each bucket is all-reduced (SUM) on a communication stream as soon as it is final. With the native launch program (default) the
+forward and the WHOLE backward are one replay call and the communication stream waits for the program's per-bucket "ready" events
+(the last main-lane op of the bucket's segment and the last weight-gradient-lane op so far: mpmae_program_stream_wait), so the main
+lane never stops for the weight-gradient lane at a bucket boundary; `overlap="segments"` replays one call per bucket instead (each
+joins the side lane first). Averaging (1/world) is folded into the AdamW kernel's grad_scale. `allreduce_dtype=
 torch.bfloat16` sends the buckets as bf16 (half the xGMI bytes; the sum then carries bf16 rounding). With HIP
 graphs the forward, every backward segment and the optimizer are separate captured graphs.
 """
@@ -109,6 +112,16 @@ def allreduce_buckets_sync(gflat, buckets):
         dist.all_reduce(gflat[lo:hi], op=dist.ReduceOp.SUM)
 
 
+def _check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what}: hipError {err}")
+
+
+def _c_stream(stream):
+    import ctypes
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
 class _EventWork:
     """`.wait()` of a chain that finished on the communication stream: the current stream waits for its event."""
 
@@ -129,7 +142,7 @@ class StepRunner:
     overlap as well as real streams); "eager" is the Python loop over the C-ABI calls."""
 
     def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None, update_freq=1,
-                 allreduce_dtype=None):
+                 allreduce_dtype=None, overlap="events"):
         self.eng = engine
         self.world = world_size
         self.lr = lr
@@ -163,6 +176,15 @@ class StepRunner:
                 engine.step_pieces(self.segments if world_size > 1 else None, weight_decay=weight_decay,
                                    loss_scale=1.0 / self.update_freq))
             self.graph_mode = "program"
+            # overlap "events" (default): the whole backward is ONE replay call and the communication stream waits for the
+            # per-bucket "ready" events of the program; "segments": one replay call per bucket, each joining the side lane first
+            self.bucket_signals = []
+            if world_size > 1 and overlap == "events" and self.comm_stream is not None:
+                for keys in engine._bucket_keys:
+                    sig = [engine._program_ids[k] for k in keys]
+                    for i_ in sig:
+                        _check(engine.lib.mpmae_program_export_signal(self.prog, i_), "program_export_signal")
+                    self.bucket_signals.append(sig)
         elif mode == "hipgraph":
             self._capture()
 
@@ -229,7 +251,9 @@ class StepRunner:
         finally:
             eng.single_stream = False
 
-    def _launch_allreduce(self, b, works):
+    def _launch_allreduce(self, b, works, ready=False):
+        """ready=True: the communication stream already waits for the bucket (program events); otherwise it waits for the
+        current stream's position."""
         lo, hi = self.buckets[b]
         if self.comm_stream is None:         # host tensors (gloo logic tests): the collective is synchronous
             if self.wire is not None:
@@ -239,9 +263,10 @@ class StepRunner:
             else:
                 dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM)
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        self.comm_stream.wait_event(ev)
+        if not ready:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
         with torch.cuda.stream(self.comm_stream):
             if self.wire is not None:        # cast -> all-reduce -> cast back, all on the communication stream
                 self.wire[b].copy_(self.eng.gflat[lo:hi])
@@ -319,10 +344,24 @@ class StepRunner:
                 eng.note_optimizer_launch()
             return
         works = []
-        eng.run_program(self.prog, self._span(FWD, ZERO if first else FWD))
-        for i in range(nseg):
-            eng.run_program(self.prog, self._span(SEG0 + i, SEG0 + i))
-            self._launch_allreduce(i, works)
+        if self.bucket_signals:
+            # ONE replay call for forward + the whole backward (no side-lane join between buckets: the main lane never waits for
+            # the weight-gradient lane at a bucket boundary); the communication stream waits for each bucket's "ready" events
+            if first:
+                eng.run_program(self.prog, self._span(FWD, SEG0 + nseg - 1))
+            else:
+                eng.run_program(self.prog, self._span(FWD, FWD))
+                eng.run_program(self.prog, self._span(SEG0, SEG0 + nseg - 1))
+            comm = _c_stream(self.comm_stream)
+            for i in range(nseg):
+                for sig in self.bucket_signals[i]:
+                    _check(eng.lib.mpmae_program_stream_wait(self.prog, sig, comm), "program_stream_wait")
+                self._launch_allreduce(i, works, ready=True)
+        else:
+            eng.run_program(self.prog, self._span(FWD, ZERO if first else FWD))
+            for i in range(nseg):
+                eng.run_program(self.prog, self._span(SEG0 + i, SEG0 + i))
+                self._launch_allreduce(i, works)
         self.loss_buf.copy_(eng.total)
         works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:

@@ -1427,6 +1427,24 @@ class Engine:
                                                  _p(self.hp), _p(self.total)), dict(lane=0, wait=tuple(joins), signal=None)),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
+        # "bucket ready" points for a data-parallel runner that replays the whole backward as ONE call: per segment the keys of its last
+        # main-lane op and of the last side-lane op seen so far (in-order lanes: they imply everything before them)
+        self._bucket_keys = []
+        last_side_key = None
+        for sg in segs:
+            keys = []
+            main_ops = [op for op in sg if op[3]["lane"] == 0]
+            side_ops = [op for op in sg if op[3]["lane"] != 0]
+            for op in ([main_ops[-1]] if main_ops else []) + ([side_ops[-1]] if side_ops else []):
+                if op[3]["signal"] is None:
+                    self._evseq += 1
+                    op[3]["signal"] = f"b{self._evseq}"
+                keys.append(op[3]["signal"])
+            if side_ops:
+                last_side_key = side_ops[-1][3]["signal"]
+            elif last_side_key is not None:
+                keys.append(last_side_key)
+            self._bucket_keys.append(keys)
         return [fwd, zero, first] + [list(sg) for sg in segs[1:]] + [opt]
 
     def record_program(self, pieces):
@@ -1450,6 +1468,7 @@ class Engine:
         _lib.check(err, "program_end")
         assert lib.mpmae_program_num_ops(prog) == n
         self._programs = getattr(self, "_programs", []) + [prog]
+        self._program_ids = ids                       # event key -> signal id of the most recently recorded program
         return prog, spans
 
     def run_program(self, prog, span):

@@ -376,10 +376,10 @@ def test_two_rank_step_driver_on_one_gpu(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_probe.py"), str(tmp_path)], capture_output=True,
                        text=True, timeout=600, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
-    for mode in ("program", "eager"):
-        m = re.search(mode + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
+    for mode in ("program", "program+segments", "eager"):      # bucket-event overlap (default), per-bucket replay calls, Python loop
+        m = re.search(re.escape(mode) + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
         assert m and float(m.group(1)) < 1e-5, r.stdout
-        assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
+        assert re.search(re.escape(mode) + r" ranks equal: True", r.stdout), r.stdout
 
 
 # ----------------------------------------------------------------------------- MX-fp8 pointwise path (BASELINE configs[4])

@@ -30,7 +30,9 @@ def worker(rank, world, mode, out):
     torch.cuda.set_device(0)
     from mmearth_train_amd import dist as mdist
     eng = build(rank)
-    run = mdist.StepRunner(eng, world_size=world, lr=1e-3, mode=mode, update_freq=UF)
+    drv, _, ov = mode.partition("+")              # "program" (bucket events), "program+segments" (one replay call per bucket), "eager"
+    run = mdist.StepRunner(eng, world_size=world, lr=1e-3, mode=drv, update_freq=UF, overlap=ov or "events")
+    assert drv != "program" or bool(run.bucket_signals) == (ov != "segments")
     for _ in range(UF):
         run.step()
     torch.cuda.synchronize()
@@ -45,7 +47,7 @@ def worker(rank, world, mode, out):
 
 if __name__ == "__main__":
     out = sys.argv[1] if len(sys.argv) > 1 else "/tmp"
-    for mode in ("program", "eager"):
+    for mode in ("program", "program+segments", "eager"):
         mp.spawn(worker, args=(2, mode, out), nprocs=2, join=True)
     # reference: one process, both ranks' data, gradients averaged by hand
     engs = [build(0), build(1)]
@@ -63,7 +65,7 @@ if __name__ == "__main__":
             e.gflat.copy_(g); e.optimizer_step(lr=1e-3)
     torch.cuda.synchronize()
     ref = engs[0].pflat.cpu()
-    for mode in ("program", "eager"):
+    for mode in ("program", "program+segments", "eager"):
         p0, p1 = torch.load(f"{out}/p0_{mode}.pt"), torch.load(f"{out}/p1_{mode}.pt")
         g0 = torch.load(f"{out}/g0_{mode}.pt")
         print(mode, "step-1 averaged gradient vs reference: max rel %.2e" % ((g0 - gref).abs().max() / gref.abs().max()).item())
