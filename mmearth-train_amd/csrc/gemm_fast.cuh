@@ -143,6 +143,44 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
     // epilogue: lane = row m0 + wm*64 + i*16 + lr, columns n0 + wn*(BN/2) + jp*32 + lg*8 + (t*4 + r)
     bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
     const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
+    if constexpr (NJ == 2) {
+      // 64-wide tiles (stage 3, downsample, stem: activity bytes AND residuals): every optional operand of the tile's rows is
+      // requested first - clamped addresses, pointer selects, opaque masks - and consumed afterwards; in the store loop below
+      // (`live = !act || act[row]; if (R) ld8(R...)`) they are two dependent round trips per 16-row group. (At 128-wide tiles the
+      // extra 32 + 16 registers cost more occupancy than the round trips: head GEMM 69 -> 80 us.)
+      const unsigned act_m = opaque_mask(p.act != nullptr) & 0xffu, r_m = opaque_mask(Rg != nullptr), b_m = opaque_mask(p.bias != nullptr);
+      const int colc = min(n0 + wn * (BN / 2) + lg * 8, p.N - 8);
+      const float* bp = p.bias ? p.bias + colc : reinterpret_cast<const float*>(p.B);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      uint8_t lv[4];
+      uint4 rraw[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rowc = min(m0 + wm * 64 + i * 16 + lr, p.M - 1);
+        lv[i] = *(p.act ? p.act + rowc : reinterpret_cast<const uint8_t*>(p.B));
+        rraw[i] = *reinterpret_cast<const uint4*>(Rg ? Rg + (size_t)rowc * p.ldr + colc : reinterpret_cast<const bf16_t*>(p.B));
+      }
+      const int col = n0 + wn * (BN / 2) + lg * 8;
+      if (col < p.N) {
+        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + wm * 64 + i * 16 + lr;
+          if (row >= p.M) continue;
+          const bool live = ((lv[i] & act_m) | (~act_m & 1u)) != 0;
+          const uint4 rm = make_uint4(rraw[i].x & r_m, rraw[i].y & r_m, rraw[i].z & r_m, rraw[i].w & r_m);
+          float v[8], rr[8];
+          rr[0] = __uint_as_float(rm.x << 16); rr[1] = __uint_as_float(rm.x & 0xffff0000u);
+          rr[2] = __uint_as_float(rm.y << 16); rr[3] = __uint_as_float(rm.y & 0xffff0000u);
+          rr[4] = __uint_as_float(rm.z << 16); rr[5] = __uint_as_float(rm.z & 0xffff0000u);
+          rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][e >> 2][e & 3] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
+          st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int jp = 0; jp < NJ / 2; ++jp) {
       const int col = n0 + wn * (BN / 2) + jp * 32 + lg * 8;
