@@ -273,23 +273,24 @@ __global__ __launch_bounds__(256) void colstats_v3_kernel(const T* __restrict__ 
   for (int i = 0; i < VPL; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a0[i][e] = 0.f; a1[i][e] = 0.f; }
+  // unconditional loads from clamped column vectors (the second operand through a pointer select), lanes past the last vector
+  // masked afterwards: `if (v < nvec) { load ... }` in the row loop was a branch region with its own wait per row
+  const T* dzp = mode == 1 ? dz : h;
 #pragma unroll 4
   for (int m = mb + wave; m < me; m += 4) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
-      const int v = vbase + lane + 64 * i;
-      if (v < nvec) {
-        float hv[8];
-        ld8<T>(h + (size_t)m * H + v * 8, hv);
-        if (mode == 0) {
+      const int v = vbase + lane + 64 * i, vc = min(v, nvec - 1);
+      const float keep = v < nvec ? 1.f : 0.f;
+      float hv[8], d[8];
+      ld8<T>(h + (size_t)m * H + vc * 8, hv);
+      ld8<T>(dzp + (size_t)m * H + vc * 8, d);
+      if (mode == 0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { const float g = gelu_t<T>(hv[e]); a0[i][e] += g * g; }
-        } else {
-          float d[8];
-          ld8<T>(dz + (size_t)m * H + v * 8, d);
+        for (int e = 0; e < 8; ++e) { const float g = gelu_t<T>(hv[e]); a0[i][e] += keep * g * g; }
+      } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { a0[i][e] += d[e]; a1[i][e] += d[e] * gelu_t<T>(hv[e]); }
-        }
+        for (int e = 0; e < 8; ++e) { a0[i][e] += keep * d[e]; a1[i][e] += keep * d[e] * gelu_t<T>(hv[e]); }
       }
     }
   }
