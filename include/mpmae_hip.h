@@ -350,6 +350,9 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
  * needs H % 4 == 0, (p*p) % 4 == 0 and maxC * (p*H + 4) * 4 <= 150 KB of LDS, else hipErrorInvalidValue (use mpmae_loss_multi). */
 int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
                              mpmae_stream_t stream);
+/* Gradient twin (same band walk, no statistics): d pred of every record, zeros at patches that were not counted. */
+int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
+                                 mpmae_stream_t stream);
 /* Categorical pixel losses, wave-per-patch form (forward bwd = 0 / gradient bwd = 1): same records, outputs and partial layout as
  * mpmae_loss_multi(kind 1). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and
  * coff % 4 == 0 (vector accesses); 16 * max_pk elements of LDS. */

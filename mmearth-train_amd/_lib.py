@@ -158,6 +158,7 @@ SYMBOLS = {
     "mpmae_loss_img": [c_int, c_int, P(ImgArgs), c_void_p],
     "mpmae_loss_multi": [c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mpmae_loss_pix_cont_rows_bwd": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],

@@ -777,21 +777,31 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
   RET();
 }
 
-int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
   if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)maxC * (p * H + 4) * 4;
   const int nvec = maxC * p * (H / 4), npv = maxC * p * p / 4;
   const int mv = cdiv(nvec, 512), mp = cdiv(npv, 64);
   if (lds > 150 * 1024 || mv > 12 || mp > 12) return (int)hipErrorInvalidValue;
   const auto* tab = (const MpmaePixContArgs*)dev_args;
-#define LPR(TT, MV, MP) do { \
+#define LPR(TT, MV, MP, BW) do { \
     static size_t cur = 48 * 1024; \
-    if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cont_rows_kernel<TT, MV, MP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
-    LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP>), dim3(N, count), dim3(512), lds, S_(s), tab); } while (0)
-  if (mv <= 3 && mp <= 3) { if (dt == 0) LPR(float, 3, 3); else LPR(bf16_t, 3, 3); }
-  else { if (dt == 0) LPR(float, 12, 12); else LPR(bf16_t, 12, 12); }
+    if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cont_rows_kernel<TT, MV, MP, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+    LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP, BW>), dim3(N, count), dim3(512), lds, S_(s), tab); } while (0)
+#define LPR2(TT, MV, MP) do { if (bwd) LPR(TT, MV, MP, true); else LPR(TT, MV, MP, false); } while (0)
+  if (mv <= 3 && mp <= 3) { if (dt == 0) LPR2(float, 3, 3); else LPR2(bf16_t, 3, 3); }
+  else { if (dt == 0) LPR2(float, 12, 12); else LPR2(bf16_t, 12, 12); }
+#undef LPR2
 #undef LPR
   RET();
+}
+
+int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  return loss_pix_cont_rows_impl(dt, 0, dev_args, count, N, maxC, p, H, s);
+}
+
+int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  return loss_pix_cont_rows_impl(dt, 1, dev_args, count, N, maxC, p, H, s);
 }
 
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {

@@ -292,7 +292,7 @@ __global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_multi_kernel(co
 // grid = (N, modalities); block = 512; dynamic LDS = max_C * (p*H + 4) * 4 bytes. MAXV / MAXP: float4 of the band per thread /
 // 4-element prediction vectors per lane and patch (3 / 3 at 56/8 with C <= 12, 11 / 12 at 112/16).
 // ---------------------------------------------------------------------------------
-template <typename T, int MAXV, int MAXP>
+template <typename T, int MAXV, int MAXP, bool BWD = false>
 __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP* __restrict__ tab) {
   const PixContP q = tab[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float lpc_band[];
@@ -356,6 +356,52 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
     for (int px = wave; px < G; px += 8) {
       const int b = n * q.L + py * G + px;
       const float mk = q.mask[b];
+      if constexpr (BWD) {
+        // gradient (same band walk, no statistics): d pred = coef * mask * 2 / count * (pred - normalised target) at counted patches,
+        // zero elsewhere; the patch's five scalars are requested together, the slice is read and written as contiguous vectors
+        const float pl = q.patch_l[b], pc = q.patch_cnt[b], pm = q.patch_mean[b], pr = q.patch_rstd[b], cf = q.coef[0];
+        const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
+        T* dp = reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff;
+        const bool counted = mk != 0.f && pl != 0.f && !isnan(pl);
+        const float k = cf * mk * 2.f / pc;
+        const float* bp = lpc_band + px * p;
+        float pv4[MAXP][4];
+        if (counted) {                                           // wave-uniform: one region, all of the slice's vectors in flight
+#pragma unroll
+          for (int u = 0; u < MAXP; ++u) {
+            const int v = min(lane + 64 * u, npv - 1);
+            if constexpr (std::is_same<T, float>::value) {
+              const float4 r = *reinterpret_cast<const float4*>(pred + 4 * v);
+              pv4[u][0] = r.x; pv4[u][1] = r.y; pv4[u][2] = r.z; pv4[u][3] = r.w;
+            } else {
+              const uint2 r = *reinterpret_cast<const uint2*>(pred + 4 * v);
+              pv4[u][0] = __uint_as_float(r.x << 16); pv4[u][1] = __uint_as_float(r.x & 0xffff0000u);
+              pv4[u][2] = __uint_as_float(r.y << 16); pv4[u][3] = __uint_as_float(r.y & 0xffff0000u);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+          const int v = lane + 64 * u;
+          if (v >= npv) continue;
+          float o[4] = {0.f, 0.f, 0.f, 0.f};
+          if (counted) {
+            int o4[4];
+            if constexpr (PRE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = offq[u][e];
+            } else pred_off(u, o4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = pv4[u][e] - (bp[o4[e]] - pm) * pr;
+              o[e] = isnan(d * d) ? 0.f : k * d;
+            }
+          }
+          if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(dp + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+          else *reinterpret_cast<uint2*>(dp + 4 * v) = make_uint2(f2bf2(o[0], o[1]), f2bf2(o[2], o[3]));
+        }
+        continue;
+      }
       if (mk == 0.f) {
         if (lane == 0) { q.patch_l[b] = 0.f; q.patch_cnt[b] = 0.f; q.patch_mean[b] = 0.f; q.patch_rstd[b] = 1.f; }
         continue;
@@ -420,6 +466,7 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       if (counted) { as += qv; ac += 1.f; }
     }
   }
+  if constexpr (BWD) return;
   if (lane == 0) { part[wave][0] = as; part[wave][1] = ac; }
   __syncthreads();
   if (tid == 0) {

@@ -45,6 +45,7 @@ ENGINE_OPTIONS = dict(
     stem_fused=1,           # fused stem tail (patch 8)
     loss_multi=1,           # one launch per loss kind
     loss_rows=1,            # continuous pixel losses: row-band forward kernel
+    loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
@@ -1043,6 +1044,7 @@ class Engine:
                     # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
                     self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows, dt, _p(tab), len(mods), N, maxc,
                              self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                    self._cont_rows = maxc
                     continue
                 ldp_ = self.pred_pix.shape[1] if cfg.pix_mods else 0
                 cat_waves = (kind == "pix_cat" and bool(self.opt["loss_rows"]) and maxc <= 16 and ldp_ % 4 == 0
@@ -1126,6 +1128,10 @@ class Engine:
         if self.loss_multi:
             # (the categorical losses on the side lane next to the continuous ones, forward and gradient: 4.99 vs 4.97 ms, not kept)
             for kind, (kind_id, tab, cnt) in self._loss_tabs.items():
+                if kind == "pix_cont" and getattr(self, "_cont_rows", 0) and bool(self.opt["loss_rows_bwd"]):
+                    self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_pix_cont_rows_bwd, dt, _p(tab), cnt, N, self._cont_rows,
+                             self.p, cfg.img_size, kind=f"loss_{kind}_bwd")
+                    continue
                 if kind == "pix_cat" and getattr(self, "_cat_waves", False):
                     maxc = max(om.chans for om in cfg.out_mods if om.kind == "pix_cat")
                     self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_pix_cat_waves, dt, 1, _p(tab), cnt, N,
