@@ -48,6 +48,7 @@ ENGINE_OPTIONS = dict(
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
+    wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
@@ -755,8 +756,13 @@ class Engine:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "STORE", A=dout, B=w2t["t"], C=dz, M=M, N=H, K=Cc, lda=Cc,
                        ldb=w2t["ld"], ldc=H)
         self._guard(lst, dz)
-        self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
-                    dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
+        # pw2's weight gradient only reads dout and z: issued right here it needs an event of its own between the two fused kernels of
+        # the main lane; with `wgrad_late` it is issued behind the second one and shares that kernel's event with pw1 / depthwise
+        late_w2 = self.lanes and bool(self.opt["wgrad_late"]) and rs and rs_n == "fused"
+        late_all = self.lanes and int(self.opt["wgrad_late"]) >= 2 and not rs and rs_n is None      # unfused blocks: all three behind ln.bwd
+        w2_args = dict(P=dout, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H, dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
+        if not late_w2 and not late_all:
+            self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], **w2_args)
         if not blk["sparse"] and not self.grouped_epi:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
@@ -790,13 +796,19 @@ class Engine:
             self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
                        ldb=w1t["ld"], ldc=Cc)
         self._guard(lst, dd)
-        self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
-                    dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
+        if late_w2:
+            self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], **w2_args)
+        w1_args = dict(P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
+        if not late_all:
+            self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         if rs_n is None:
             self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
             self._guard(lst, dd)
+        if late_all:
+            self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout], **w2_args)
+            self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         self._dw_bwd(lst, blk, dd, dout, dx)
 
     def _dw_bwd(self, lst, blk, dd, dout, dx):
