@@ -165,6 +165,40 @@ typedef struct MpmaeRsArgs {
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 
+/* ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------------
+ * ONE launch runs every Block of a sparse stage (convnextv2_sparse.py:47-56 x depth, with MinkowskiLayerNorm and the
+ * batch-global MinkowskiGRN of sparse_norm_layers.py:24-33,61-77): depthwise 7x7 -> LayerNorm -> pwconv1 -> GELU -> GRN ->
+ * pwconv2 -> + residual, block after block, one workgroup per sample with the sample's rows resident in LDS and ONE grid
+ * barrier per block for the GRN statistics (device-scope float atomics into G2 + a monotonic arrival counter).
+ * bf16 activations only. Supported shapes: (C = 160, S = 2, keep <= 20) and (C = 320, S = 1, keep <= 32), N <= number of
+ * compute units of the device (every workgroup must be resident), nblk <= MPMAE_PS_MAXBLK; anything else returns
+ * hipErrorInvalidValue and the caller uses mpmae_dwconv7_fwd / mpmae_rs. `sync` = 4 zero-initialised device words
+ * {arrivals, departures, error, -}: the kernel leaves arrivals / departures at zero again; error != 0 after a launch means a
+ * workgroup never became resident within the spin bound (e.g. another persistent kernel shares the GPU) and the results
+ * are invalid. The forward writes, per block, exactly what the backward and the weight gradients read: x-hat, rstd, xn
+ * (LayerNorm output), h (pwconv1 output), z (GRN output), out, and Gx / Ainv / scale of the GRN. */
+#define MPMAE_PS_MAXBLK 9
+typedef struct MpmaePsBlock {
+  const float* dw_w; const float* dw_b;        /* ME depthwise kernel (49, C), index (kw*7 + kh)*C + c; bias (C) */
+  const float* ln_g; const float* ln_b;
+  const void* W1; const float* b1;             /* staged bf16 [4C][ldw1] (mpmae_prep_weights), bias (4C) */
+  const float* grn_g; const float* grn_b;
+  const void* W2; const float* b2;             /* staged bf16 [C][ldw2], bias (C) */
+  int ldw1, ldw2;
+  void* dhat; float* rstd; void* xn; void* h; void* z; void* out;   /* saved activations [M, C] / [M] / [M, 4C] */
+  float* G2; float* Gx; float* Ainv; float* scale;                  /* GRN: G2 = [ng][4C] partial sums of gelu(h)^2 (zeroed by the caller,
+                                                                       workgroup n accumulates into copy n % ng); results (4C each) */
+} MpmaePsBlock;
+typedef struct MpmaePsArgs {
+  const void* x_in;                            /* stage input rows [M, C] bf16 */
+  MpmaeGeom g; const uint8_t* act;
+  int C, nblk; float eps;
+  int ng;                                      /* accumulator copies per statistics vector (1 .. 16): measured best 4 at 256 workgroups */
+  unsigned* sync;
+  MpmaePsBlock blk[MPMAE_PS_MAXBLK];
+} MpmaePsArgs;
+int mpmae_ps_fwd(const MpmaePsArgs* args, mpmae_stream_t stream);
+
 /* im2col of the masked fp32 NCHW image for the sparse 3x3 stem convolution (MinkowskiConvolution
  * 3x3 of convnextv2_sparse.py:113-117): out[(n*keep+slot)*S*S + iy*S + ix][k], k = (kw*3+kh)*Cseg + cin
  * (taps outside the image / in masked patches are zero), row stride ldo >= 9*Cseg (padding columns

@@ -105,6 +105,23 @@ class RsArgs(C.Structure):
                 ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p)]
 
 
+PS_MAXBLK = 9          # MPMAE_PS_MAXBLK
+
+
+class PsBlock(C.Structure):
+    _fields_ = [("dw_w", c_void_p), ("dw_b", c_void_p), ("ln_g", c_void_p), ("ln_b", c_void_p),
+                ("W1", c_void_p), ("b1", c_void_p), ("grn_g", c_void_p), ("grn_b", c_void_p),
+                ("W2", c_void_p), ("b2", c_void_p), ("ldw1", c_int), ("ldw2", c_int),
+                ("dhat", c_void_p), ("rstd", c_void_p), ("xn", c_void_p), ("h", c_void_p), ("z", c_void_p), ("out", c_void_p),
+                ("G2", c_void_p), ("Gx", c_void_p), ("Ainv", c_void_p), ("scale", c_void_p)]
+
+
+class PsArgs(C.Structure):
+    _fields_ = [("x_in", c_void_p), ("g", Geom), ("act", c_void_p),
+                ("C", c_int), ("nblk", c_int), ("eps", c_float), ("ng", c_int),
+                ("sync", c_void_p), ("blk", PsBlock * PS_MAXBLK)]
+
+
 class StemTailArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("xhat1", c_void_p), ("rstd1", c_void_p), ("xhat2", c_void_p), ("rstd2", c_void_p),
                 ("out", c_void_p), ("g1", c_void_p), ("b1", c_void_p), ("w", c_void_p), ("wb", c_void_p),
@@ -140,6 +157,7 @@ SYMBOLS = {
     "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                        c_void_p],
     "mpmae_rs": [c_int, P(RsArgs), c_void_p],
+    "mpmae_ps_fwd": [P(PsArgs), c_void_p],
     "mpmae_quant_mx": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mpmae_gemm_mx": [c_int, P(GemmArgs), c_void_p, c_int, c_void_p, c_int, c_void_p],
     "mpmae_set_option": [c_int, c_int],

@@ -16,6 +16,7 @@
 #include "stemtail.cuh"
 #include "gemm_nt3.cuh"
 #include "dwband.cuh"
+#include "ps.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -1273,6 +1274,57 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (a->C == 40 && a->H == 160) return launch_rs<40, 160>(which, *a, S_(s));
   if (a->C == 80 && a->H == 320) return launch_rs<80, 320>(which, *a, S_(s));
   if (a->C == 96 && a->H == 384) return launch_rs<96, 384>(which, *a, S_(s));
+  return (int)hipErrorInvalidValue;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// persistent per-sample stage kernels (ps.cuh)
+// ------------------------------------------------------------------------------------------
+static int ps_num_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    (void)hipGetLastError();
+    cus = v;
+  }
+  return cus;
+}
+
+static int ps_check(const MpmaePsArgs& a, int S, int keep_max) {
+  if (!a.x_in || !a.g.vis || !a.g.inv || !a.sync || a.nblk < 1 || a.nblk > MPMAE_PS_MAXBLK || a.ng < 1 || a.ng > 16) return (int)hipErrorInvalidValue;
+  if (a.g.S != S || a.g.keep < 1 || a.g.keep > keep_max || a.g.N < 1 || a.g.N > ps_num_cus()) return (int)hipErrorInvalidValue;
+  if ((size_t)a.g.keep * S * S * a.C * 4 >= 65535u) return (int)hipErrorInvalidValue;       // 16-bit LDS offsets of the neighbour table
+  return 0;
+}
+
+template <int C, int S>
+static int launch_ps_fwd(const MpmaePsArgs& a, hipStream_t st) {
+  using K = ps::Cfg<C, S>;
+  if (const int e = ps_check(a, S, S == 2 ? K::RP / 4 : 32)) return e;
+  for (int b = 0; b < a.nblk; ++b) {
+    const MpmaePsBlock& B = a.blk[b];
+    if (!B.dw_w || !B.dw_b || !B.ln_g || !B.ln_b || !B.W1 || !B.b1 || !B.grn_g || !B.grn_b || !B.W2 || !B.b2 || !B.dhat || !B.rstd ||
+        !B.xn || !B.h || !B.z || !B.out || !B.G2 || !B.Gx || !B.Ainv || !B.scale || (B.ldw1 & 7) || (B.ldw2 & 7) || B.ldw1 < C || B.ldw2 < 4 * C)
+      return (int)hipErrorInvalidValue;
+    if (((uintptr_t)B.W1 | (uintptr_t)B.W2 | (uintptr_t)B.dhat | (uintptr_t)B.xn | (uintptr_t)B.h | (uintptr_t)B.z | (uintptr_t)B.out |
+         (uintptr_t)B.dw_w | (uintptr_t)B.dw_b | (uintptr_t)B.ln_g | (uintptr_t)B.ln_b | (uintptr_t)B.b1 | (uintptr_t)B.b2) & 15)
+      return (int)hipErrorInvalidValue;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)ps::ps_fwd_kernel<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS) != hipSuccess) return (int)hipGetLastError();
+    attr = true;
+  }
+  LAUNCH((ps::ps_fwd_kernel<C, S>), dim3(a.g.N), dim3(ps::NTHR), K::LDS, st, a);
+  return launch_status();
+}
+
+int mpmae_ps_fwd(const MpmaePsArgs* a, mpmae_stream_t s) {
+  if (!a) return (int)hipErrorInvalidValue;
+  if (a->C == 160 && a->g.S == 2) return launch_ps_fwd<160, 2>(*a, S_(s));
+  if (a->C == 320 && a->g.S == 1) return launch_ps_fwd<320, 1>(*a, S_(s));
   return (int)hipErrorInvalidValue;
 }
 

@@ -1,0 +1,563 @@
+// Persistent per-sample stage kernels ("ps"): ONE launch runs every ConvNeXtV2 block of a sparse stage, forward or backward.
+//
+// Replaces, per block, the launch chain  dw7x7 -> [LN + pw1 + GELU^2 sums] -> reduce -> [GRN + pw2 + residual]  (and its backward
+// twin) of the row-streaming kernels (rsc.cuh, dwconv6.cuh) at the compute-shaped stages, where those launches are latency chains
+// (profiles/r02: 17 + 33 + 33 us per block for ~4 us of roofline work). Reference semantics: models/convnextv2_sparse.py:47-56,
+// models/sparse_norm_layers.py:24-33 (batch-global GRN) and :61-77.
+//
+// Decomposition: one 512-thread workgroup per SAMPLE (grid = N <= number of CUs, one workgroup per CU by LDS footprint). A sample's
+// rows of the stage (keep * S^2 <= 80) live in LDS for the whole stage:
+//   XA  [RP][C+8]   bf16   depthwise output d -> LayerNorm output xn (A operand of pw1)
+//   HA  [RP][4C+16] bf16   h -> z = GRN(gelu(h)) (A operand of pw2); aliased by XF [R][C] fp32, the block input x, while no
+//                          hidden tensor is live (written by the pw2 epilogue, read by the next block's depthwise gather)
+// Weights never touch LDS: a wave owns a slice of the output columns, so every weight element is needed by exactly one wave and
+// streams global (L2) -> registers directly in MFMA fragment layout through a ring of k-steps. The MFMA is issued transposed
+// (D[n][m] = W A^T) as in rsc.cuh: a lane ends with 4 consecutive output columns of one row, bias / GELU / residual are lane-local.
+// The batch-global GRN statistics cross workgroups through device-scope float atomics into the block's G2 vector and ONE grid
+// barrier per block: a monotonic arrival counter polled with relaxed agent-scope loads. Both sides of every exchange are atomics /
+// sc1 loads (MI355X_MICROARCH.md "valid forms": {agent atomics both sides}), so no release / acquire fence - whose L2 write-back
+// would have to flush the ~270 KB of saved activations each workgroup streams out per block - is needed.
+// The depthwise 7x7 is a patch-granular gather: per visible patch a table of the (2 NB + 1)^2 neighbouring patch slots; absent
+// (masked) neighbours are skipped wave-uniformly, present ones are S^2 contiguous rows at immediate offsets.
+#pragma once
+#include <cstddef>
+#include "rsc.cuh"
+
+typedef MpmaePsArgs PsP;
+
+namespace ps {
+
+constexpr int NTHR = 512;
+constexpr unsigned ABSENT = 0xFFFFu;
+
+// -DPS_STAMPS: workgroup 0 writes shader-cycle stamps of block 1's phases to sync[8 + i] (tools/ps_check.py --stamps)
+#ifdef PS_STAMPS
+#define PS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && b == 1) a.sync[8 + (i)] = (unsigned)clock64(); } while (0)
+#else
+#define PS_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ float atomic_ld(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// all workgroups of the launch; `target` = arrivals expected so far (monotonic counter, reset by the last workgroup to leave)
+__device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 21)) {          // a workgroup never became resident (another persistent kernel on the GPU): fail, do not hang
+        __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void grid_exit(unsigned* sync, unsigned nwg) {
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nwg - 1) {
+      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int C, int S> struct Cfg {
+  static constexpr int H = 4 * C, SS = S * S;
+  static constexpr int MT = (S == 2) ? 5 : 2, RP = 16 * MT;            // row tiles: keep * S^2 <= RP
+  static constexpr int NB = (S == 2) ? 2 : 3, NBW = 2 * NB + 1, NBN = NBW * NBW;   // neighbour patches of the 7x7 window
+  static constexpr int MASKW = (NBN * 2 + 3) / 4;                       // dword of the presence mask inside a table row
+  static constexpr int TABB = ((MASKW + (NBN > 32 ? 2 : 1)) * 4 + 15) / 16 * 16;   // bytes per table row: uint16 XF byte offsets + mask
+  static constexpr int ZOFF = 16 * ((S == 2) ? 5 : 2) * C * 4;          // zero patch behind the XF rows (absent neighbours read it)
+  static constexpr int LDX = C + 8, LDH = H + 16;
+  static constexpr int XA_B = RP * LDX * 2, HA_B = RP * LDH * 2;
+  static constexpr int OFF_XA = 0, OFF_HA = XA_B, OFF_VEC = OFF_HA + HA_B, OFF_CS = OFF_VEC + 2 * H * 4,
+                       OFF_TAB = OFF_CS + H * 4, OFF_LIVE = OFF_TAB + 32 * TABB, OFF_RED = OFF_LIVE + RP, LDS = OFF_RED + 64;
+  static_assert(ZOFF + SS * C * 4 <= HA_B && ZOFF + SS * C * 4 < 65536, "XF alias + zero patch");
+  static_assert(LDS <= 160 * 1024, "LDS");
+  static constexpr int CP = C / 2, NPG = NTHR / CP;                    // depthwise: channel pairs x patch groups
+  static constexpr int NCC = H / 8, NRG = NTHR / NCC;                  // z pass: 8-column chunks x row groups
+};
+
+// D[n][m] += sum_k W[n][k] A[m][k] for NTL 16-column tiles (rows of W) x MT 16-row tiles of A (LDS), k = KS steps of 32.
+// wl: this lane's weight pointer (&W[(n_first + lr) * ldw + lg * 8]); tile j is wl + j * tstride. W streams global -> registers through a
+// ring of D k-steps; gemm_prefetch() issues the first D steps (call it a phase EARLY: weights do not depend on anything the kernel
+// computes, so their L2 latency hides behind the preceding LayerNorm / barrier), gemm_run() consumes and refills the ring.
+template <int NTL, int KS, int D>
+__device__ __forceinline__ void gemm_prefetch(const bf16_t* __restrict__ wl, const int tstride, uint4 (&wq)[D][NTL]) {
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < KS) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) wq[s][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + s * 32);
+    }
+}
+template <int NTL, int MT, int KS, int D, int LDA>
+__device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ wl, const int tstride, const bf16_t* al, uint4 (&wq)[D][NTL],
+                                         f32x4_t (&acc)[NTL][MT]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    bf16x8_t af[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(al + m * 16 * LDA + ks * 32));
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wq[ks % D][j]);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[m], acc[j][m], 0, 0, 0);
+    }
+    if (ks + D < KS) {
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) wq[ks % D][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + (ks + D) * 32);
+    }
+  }
+}
+
+template <int N> __device__ __forceinline__ unsigned tab_dword(const uint4 (&t)[N], int i) {      // i: compile-time after unrolling
+  const uint4& q = t[i >> 2];
+  return (i & 3) == 0 ? q.x : (i & 3) == 1 ? q.y : (i & 3) == 2 ? q.z : q.w;
+}
+template <int N> __device__ __forceinline__ unsigned tab_entry(const uint4 (&t)[N], int i) {
+  const unsigned d = tab_dword(t, i >> 1);
+  return (i & 1) ? (d >> 16) : (d & 0xFFFFu);
+}
+
+// neighbour (nb, row q of that patch) feeds output o of the patch with tap (ky, kx): compile-time geometry of the 7x7 window
+template <int S> __device__ __forceinline__ constexpr bool dw_used(int nb, int q) {
+  constexpr int NB = (S == 2) ? 2 : 3, NBW = 2 * NB + 1;
+  const int wy = S * (nb / NBW - NB) + q / S, wx = S * (nb % NBW - NB) + q % S;
+  for (int o = 0; o < S * S; ++o) {
+    const int ky = wy - o / S + 3, kx = wx - o % S + 3;
+    if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) return true;
+  }
+  return false;
+}
+
+// One depthwise 7x7 of patch slot k over the sample's LDS-resident fp32 rows XF (channel pair cp), accumulated into accout[o].
+// The table row of the patch holds, per neighbour patch, the XF byte offset of its S^2 rows (absent neighbours point at a zero patch)
+// and a presence mask. The LDS reads are UNCONDITIONAL and run one GROUP of neighbours (one row of the 5x5 patch window at S = 2,
+// two rows of the 7x7 window at S = 1) ahead of the multiply-adds; only the multiply-adds of an absent neighbour are skipped. With
+// the reads inside that branch every present neighbour cost a full LDS round trip (19 k of the first version's 100 k cycles per
+// block), one NEIGHBOUR ahead still 20 k: most neighbours are masked, so there is nothing to hide a round trip behind.
+// FLIP = 1: data gradient (taps mirrored).
+template <int C, int S, int FLIP>
+__device__ __forceinline__ void dw_gather(const unsigned char* smem, f32x2_t (&accout)[4], int k /*patch slot*/, int cp,
+                                          const f32x2_t (&w)[49]) {
+  using K = Cfg<C, S>;
+  constexpr int SS = K::SS, NB = K::NB, NBW = K::NBW, NBN = K::NBN;
+  constexpr int GR = (S == 2) ? 1 : 2, GN = GR * NBW, NG = (NBW + GR - 1) / GR;      // window rows / neighbours per group, groups
+  uint4 tabv[K::TABB / 16];
+#pragma unroll
+  for (int i = 0; i < K::TABB / 16; ++i) tabv[i] = *reinterpret_cast<const uint4*>(smem + K::OFF_TAB + k * K::TABB + i * 16);
+  const unsigned mlo = tab_dword(tabv, K::MASKW), mhi = (NBN > 32) ? tab_dword(tabv, K::MASKW + 1) : 0u;
+  const unsigned char* xf = smem + K::OFF_HA + cp * 8;
+  f32x2_t v[2][GN * SS];
+#pragma unroll
+  for (int i = 0; i < GN; ++i)
+#pragma unroll
+    for (int q = 0; q < SS; ++q)
+      if (dw_used<S>(i, q)) v[0][i * SS + q] = *reinterpret_cast<const f32x2_t*>(xf + tab_entry(tabv, i) + q * C * 4);
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (g + 1 < NG) {
+#pragma unroll
+      for (int i = 0; i < GN; ++i) {
+        const int nb = (g + 1) * GN + i;
+        if (nb < NBN) {
+          const unsigned off = tab_entry(tabv, nb);
+#pragma unroll
+          for (int q = 0; q < SS; ++q)
+            if (dw_used<S>(nb, q)) v[(g + 1) & 1][i * SS + q] = *reinterpret_cast<const f32x2_t*>(xf + off + q * C * 4);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GN; ++i) {
+      const int nb = g * GN + i;
+      if (nb < NBN) {
+        const bool present = ((nb < 32 ? mlo >> nb : mhi >> (nb - 32)) & 1u) != 0;
+        if (present) {
+          const int dpy = nb / NBW - NB, dpx = nb % NBW - NB;
+#pragma unroll
+          for (int q = 0; q < SS; ++q) {
+            const int wy = S * dpy + q / S, wx = S * dpx + q % S;          // input position relative to the patch origin
+#pragma unroll
+            for (int o = 0; o < SS; ++o) {
+              const int ky = wy - o / S + 3, kx = wx - o % S + 3;
+              if (ky >= 0 && ky < 7 && kx >= 0 && kx < 7) {
+                const int t = FLIP ? (6 - ky) * 7 + (6 - kx) : ky * 7 + kx;
+                accout[o] = __builtin_elementwise_fma(w[t], v[g & 1][i * SS + q], accout[o]);      // v_pk_fma_f32 (scalar fmacs made hipcc spill half of w)
+              }
+            }
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // keep the reads ONE group ahead: hoisted all at once they need 200 registers
+  }
+}
+
+// neighbour table of the sample's visible patches: per patch slot k a row of TABB bytes = NBN uint16 XF byte offsets (absent -> ZOFF,
+// the zero patch) and the presence mask at dword MASKW
+template <int C, int S>
+__device__ __forceinline__ void build_tab(const PsP& a, unsigned char* smem, int n) {
+  using K = Cfg<C, S>;
+  unsigned short* tab = reinterpret_cast<unsigned short*>(smem + K::OFF_TAB);
+  unsigned* tabw = reinterpret_cast<unsigned*>(smem + K::OFF_TAB);
+  const int keep = a.g.keep, grid = a.g.grid, L = grid * grid;
+  for (int i = threadIdx.x; i < keep * (K::TABB / 4); i += NTHR) {
+    const int k = i / (K::TABB / 4), wd = i - k * (K::TABB / 4);
+    if (wd >= K::MASKW) tabw[i] = 0u;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < keep * K::NBN; i += NTHR) {
+    const int k = i / K::NBN, nb = i - k * K::NBN;
+    const int patch = a.g.vis[n * keep + k];
+    const int qy = patch / grid + nb / K::NBW - K::NB, qx = patch % grid + nb % K::NBW - K::NB;
+    int slot = -1;
+    if (qy >= 0 && qx >= 0 && qy < grid && qx < grid) slot = a.g.inv[n * L + qy * grid + qx];
+    tab[k * (K::TABB / 2) + nb] = slot >= 0 ? (unsigned short)(slot * K::SS * C * 4) : (unsigned short)K::ZOFF;
+    if (slot >= 0) atomicOr(&tabw[k * (K::TABB / 4) + K::MASKW + (nb >> 5)], 1u << (nb & 31));
+  }
+}
+
+// =====================================================================================
+// forward: blocks 0 .. nblk-1 of one stage
+template <int C, int S>
+__global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
+  using K = Cfg<C, S>;
+  using T = bf16_t;
+  constexpr int H = K::H, SS = K::SS, MT = K::MT, RP = K::RP, LDX = K::LDX, LDH = K::LDH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* XA = reinterpret_cast<bf16_t*>(smem + K::OFF_XA);
+  bf16_t* HA = reinterpret_cast<bf16_t*>(smem + K::OFF_HA);
+  float* XF = reinterpret_cast<float*>(smem + K::OFF_HA);
+  float* vec = reinterpret_cast<float*>(smem + K::OFF_VEC);
+  float* csum = reinterpret_cast<float*>(smem + K::OFF_CS);
+  unsigned char* live = smem + K::OFF_LIVE;
+  float* red = reinterpret_cast<float*>(smem + K::OFF_RED);
+
+  const int tid0 = threadIdx.x;
+  const int n = blockIdx.x, nwg = gridDim.x;
+  const int keep = a.g.keep, R = keep * SS;
+  const size_t rowbase = (size_t)n * R;
+
+  // ---- stage prologue: neighbour table, activity, input rows
+  {
+  const int tid = tid0;
+  for (int i = tid; i < K::XA_B / 16; i += NTHR) reinterpret_cast<uint4*>(XA)[i] = make_uint4(0u, 0u, 0u, 0u);
+  build_tab<C, S>(a, smem, n);
+  for (int i = tid; i < RP; i += NTHR) live[i] = (i < R) ? (a.act ? a.act[rowbase + i] : (unsigned char)1) : (unsigned char)0;
+  {
+    const T* xin = reinterpret_cast<const T*>(a.x_in) + rowbase * C;
+    for (int i = tid; i < R * (C / 8); i += NTHR) {
+      float v[8];
+      ld8<T>(xin + (size_t)i * 8, v);
+      *reinterpret_cast<float4*>(XF + i * 8) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(XF + i * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    for (int i = tid; i < SS * C / 4; i += NTHR) *reinterpret_cast<float4*>(smem + K::OFF_HA + K::ZOFF + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  }
+  __syncthreads();
+
+  // the per-block records are read from the kernel-argument segment itself (constant address space, scalar loads with a dynamic
+  // offset): indexing the by-value copy `a.blk[b]` with a runtime b makes hipcc spill the whole argument struct to scratch
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const char* kchar_p;
+  typedef __attribute__((address_space(4))) const MpmaePsBlock* kblk_p;
+  const kblk_p blks = (kblk_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MpmaePsArgs, blk));
+#else
+  const MpmaePsBlock* blks = a.blk;
+#endif
+  const void* prev_out = a.x_in;
+  for (int b = 0; b < a.nblk; ++b) {
+    const MpmaePsBlock B = blks[b];
+    const T* xres = reinterpret_cast<const T*>(prev_out);
+    prev_out = B.out;
+    // thread coordinates behind an opaque copy: otherwise every address of the (fully unrolled) block body is loop-invariant, gets
+    // hoisted out of the block loop and lives - spilled - across the whole kernel (72 scratch stores in the prologue, 200 reloads)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lg = lane >> 4;
+
+    PS_STAMP(0);
+    // ---- P1: depthwise 7x7 (XF -> XA), thread = (channel pair, patch group)
+    {
+      const int cp = tid % K::CP, pg = tid / K::CP;
+      if (pg < K::NPG) {
+        f32x2_t w[49];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cp);   // t = ky*7 + kx -> (kw*7 + kh)*C
+        const f32x2_t bias = *reinterpret_cast<const f32x2_t*>(B.dw_b + 2 * cp);
+#pragma unroll 1
+        for (int k = pg; k < keep; k += K::NPG) {
+          f32x2_t acc[4];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = bias;
+          dw_gather<C, S, 0>(smem, acc, k, cp, w);
+#pragma unroll
+          for (int o = 0; o < SS; ++o) {
+            const int row = k * SS + o;
+            const bool lv = live[row] != 0;
+            *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = lv ? f2bf2(acc[o].x, acc[o].y) : 0u;
+          }
+        }
+      }
+    }
+    // LayerNorm vectors and pw1's first weight slabs: requested before the barrier in front of the LayerNorm phase
+    constexpr int NCH = C / 8, NI = (NCH + 15) / 16;
+    float ga[NI][8], be[NI][8];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int q = min(lr + 16 * i, NCH - 1);
+      ld8<float>(B.ln_g + q * 8, ga[i]);
+      ld8<float>(B.ln_b + q * 8, be[i]);
+    }
+    constexpr int NT1 = C / 32, KS1 = C / 32;            // 16-column tiles per wave, k-steps
+    constexpr int NTL1 = (NT1 % 5 == 0) ? 5 : NT1;       // tiles processed together
+    constexpr int D1 = (KS1 < 4) ? KS1 : 4;
+    const int n0 = wave * (H / 8);
+    const T* W1 = reinterpret_cast<const T*>(B.W1);
+    uint4 wq1[D1][NTL1];
+    gemm_prefetch<NTL1, KS1, D1>(W1 + (size_t)(n0 + lr) * B.ldw1 + lg * 8, 16 * B.ldw1, wq1);
+    __syncthreads();
+
+    PS_STAMP(1);
+    // ---- P3: LayerNorm in place on XA (16 lanes per row), x-hat / rstd / xn saved for the backward
+    {
+      T* dhat = reinterpret_cast<T*>(B.dhat) + rowbase * C;
+      T* xng = reinterpret_cast<T*>(B.xn) + rowbase * C;
+      constexpr int NPASS = (RP + 31) / 32;
+#pragma unroll
+      for (int ps_ = 0; ps_ < NPASS; ++ps_) {
+        const int row = ps_ * 32 + wave * 4 + lg;
+        const bool inb = row < R;
+        const int rowc = min(row, RP - 1);
+        float v[NI][8];
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int q = lr + 16 * i;
+          const uint4 raw = and4(*reinterpret_cast<const uint4*>(XA + rowc * LDX + min(q, NCH - 1) * 8), q < NCH);
+          unpack8(raw, v[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s1 += v[i][e];
+        }
+        s1 = sum16(s1);
+        const float mean = s1 / C;
+        float s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = (lr + 16 * i < NCH) ? v[i][e] - mean : 0.f;
+            s2 += d * d;
+          }
+        s2 = sum16(s2);
+        const float rstd = rsqrtf(s2 / C + 1e-6f);
+        const bool lv = inb && live[rowc] != 0;
+        if (inb && lr == 0) B.rstd[rowbase + row] = lv ? rstd : 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int q = lr + 16 * i;
+          float xh[8], xn[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            xh[e] = lv ? bf2f(f2bf((v[i][e] - mean) * rstd)) : 0.f;
+            xn[e] = lv ? xh[e] * ga[i][e] + be[i][e] : 0.f;
+          }
+          if (inb && q < NCH) {
+            st8<T>(dhat + (size_t)row * C + q * 8, xh);
+            const bf16x8_t pk = pack_bf16x8(xn);
+            *reinterpret_cast<uint4*>(xng + (size_t)row * C + q * 8) = __builtin_bit_cast(uint4, pk);
+            *reinterpret_cast<uint4*>(XA + row * LDX + q * 8) = __builtin_bit_cast(uint4, pk);
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    PS_STAMP(2);
+    // ---- P4: pw1 + bias -> h (global, bf16); g = gelu(h) -> HA (bf16) with its squared column sums
+    {
+      T* hg = reinterpret_cast<T*>(B.h) + rowbase * H;
+#pragma unroll 1
+      for (int jg = 0; jg < NT1 / NTL1; ++jg) {
+        const int nb0 = n0 + jg * NTL1 * 16;
+        const T* wl = W1 + (size_t)(nb0 + lr) * B.ldw1 + lg * 8;
+        if (jg > 0) gemm_prefetch<NTL1, KS1, D1>(wl, 16 * B.ldw1, wq1);
+        float4 b4[NTL1];
+#pragma unroll
+        for (int j = 0; j < NTL1; ++j) b4[j] = *reinterpret_cast<const float4*>(B.b1 + nb0 + j * 16 + lg * 4);
+        f32x4_t acc[NTL1][MT];
+#pragma unroll
+        for (int j = 0; j < NTL1; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        gemm_run<NTL1, MT, KS1, D1, LDX>(wl, 16 * B.ldw1, XA + lr * LDX + lg * 8, wq1, acc);
+        bool lv[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) lv[m] = live[m * 16 + lr] != 0;
+#pragma unroll
+        for (int j = 0; j < NTL1; ++j) {
+          const int nc = nb0 + j * 16 + lg * 4;
+          const float bb[4] = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
+          float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const int row = m * 16 + lr;
+            float o[4], gl[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = lv[m] ? acc[j][m][r] + bb[r] : 0.f;
+            const uint2 hp = pack_bf16x4(o);
+            if (row < R) *reinterpret_cast<uint2*>(hg + (size_t)row * H + nc) = hp;
+            unpack4(hp, o);                               // the backward (and the row-streaming path) see the stored bf16 value
+            gelu_n<T, 4>(o, gl);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cs[r] += gl[r] * gl[r];
+            *reinterpret_cast<uint2*>(HA + row * LDH + nc) = pack_bf16x4(gl);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float s = sum16(cs[r]);
+            if (lr == 0) csum[nc + r] = s;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    PS_STAMP(3);
+    // ---- P5 .. P8 per wave tile count (waves w, w + 8, ... own the 16-column tiles of pw2)
+    constexpr int NT2 = C / 16, NTW = (NT2 + 7) / 8, KS2 = H / 32;
+    auto tail = [&](auto ntl_) {
+      constexpr int NTL = decltype(ntl_)::value;
+      constexpr int D2 = (S == 2) ? 8 : 6;
+      const T* W2 = reinterpret_cast<const T*>(B.W2);
+      const T* wl2 = W2 + (size_t)(wave * 16 + lr) * B.ldw2 + lg * 8;
+      uint4 wq2[D2][NTL];
+      // ---- P5: batch-global GRN statistics: atomics into G2, one grid barrier, finalisation by every workgroup
+      constexpr int NJ = (H + NTHR - 1) / NTHR;
+      float gg[NJ], gb[NJ];
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + NTHR * u, jc = min(j, H - 1);
+        gg[u] = B.grn_g[jc]; gb[u] = B.grn_b[jc];
+        if (j < H) (void)unsafeAtomicAdd(B.G2 + (size_t)(n % a.ng) * H + j, csum[j]);      // ng accumulator copies: fewer colliding adds per line
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds are performed (acknowledged) before this workgroup arrives
+      gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw2, wq2);      // pw2's first weight slabs travel while the barrier is waited for
+      grid_barrier(a.sync, (unsigned)(b + 1) * nwg);
+      PS_STAMP(4);
+      float gx[NJ], s = 0.f;
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + NTHR * u;
+        float t = 0.f;
+        for (int q = 0; q < a.ng; ++q) t += atomic_ld(B.G2 + (size_t)q * H + min(j, H - 1));
+        gx[u] = sqrtf(t);
+        s += (j < H) ? gx[u] : 0.f;
+      }
+      s = wave_sum(s);
+      if (lane == 0) red[wave] = s;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) tot += red[w8];
+      const float ainv = 1.f / (tot / H + a.eps);
+      if (n == 0 && tid == 0) B.Ainv[0] = ainv;
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + NTHR * u;
+        if (j < H) {
+          const float sc = 1.f + gg[u] * (gx[u] * ainv);
+          vec[j] = sc;
+          vec[H + j] = gb[u];
+          if (n == 0) { B.Gx[j] = gx[u]; B.scale[j] = sc; }
+        }
+      }
+      __syncthreads();
+
+      PS_STAMP(5);
+      // ---- P7: z = g * scale + beta in place on HA, saved for the backward (operand of pw2's weight gradient)
+      {
+        const int cc = tid % K::NCC, rg = tid / K::NCC;
+        if (rg < K::NRG) {
+          float sc[8], bt[8];
+          ld8<float>(vec + cc * 8, sc);
+          ld8<float>(vec + H + cc * 8, bt);
+          T* zg = reinterpret_cast<T*>(B.z) + rowbase * H + cc * 8;
+          for (int m = rg; m < R; m += K::NRG) {
+            float g[8], z[8];
+            unpack8(*reinterpret_cast<const uint4*>(HA + m * LDH + cc * 8), g);
+            const bool lvm = live[m] != 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = lvm ? g[e] * sc[e] + bt[e] : 0.f;
+            const uint4 zp = __builtin_bit_cast(uint4, pack_bf16x8(z));
+            *reinterpret_cast<uint4*>(zg + (size_t)m * H) = zp;
+            *reinterpret_cast<uint4*>(HA + m * LDH + cc * 8) = zp;
+          }
+        }
+      }
+      // residual rows and bias: requested before the product, consumed after it
+      T* outg = reinterpret_cast<T*>(B.out) + rowbase * C;
+      const T* xr = xres + rowbase * C;
+      uint2 xraw[NTL][MT];
+      float4 b4[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        b4[j] = *reinterpret_cast<const float4*>(B.b2 + (wave + 8 * j) * 16 + lg * 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          xraw[j][m] = *reinterpret_cast<const uint2*>(xr + (size_t)min(m * 16 + lr, R - 1) * C + (wave + 8 * j) * 16 + lg * 4);
+      }
+      __syncthreads();
+
+      PS_STAMP(6);
+      // ---- P8: pw2 + bias + residual -> out (global, bf16) and XF (fp32 copy of the bf16 value: next block's depthwise input)
+      f32x4_t acc[NTL][MT];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      gemm_run<NTL, MT, KS2, D2, LDH>(wl2, 8 * 16 * B.ldw2, HA + lr * LDH + lg * 8, wq2, acc);
+      __syncthreads();                               // every wave is done reading z: HA's bytes become XF
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        const int nc = (wave + 8 * j) * 16 + lg * 4;
+        const float bb[4] = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int row = m * 16 + lr;
+          const bool lvm = live[row] != 0;
+          float x[4], o[4];
+          unpack4(xraw[j][m], x);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = lvm ? acc[j][m][r] + bb[r] + x[r] : 0.f;
+          if (row < R) {
+            const uint2 pk = pack_bf16x4(o);
+            *reinterpret_cast<uint2*>(outg + (size_t)row * C + nc) = pk;
+            float of[4];
+            unpack4(pk, of);
+            *reinterpret_cast<float4*>(XF + row * C + nc) = make_float4(of[0], of[1], of[2], of[3]);
+          }
+        }
+      }
+      for (int i = tid; i < SS * C / 4; i += NTHR) *reinterpret_cast<float4*>(smem + K::OFF_HA + K::ZOFF + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (wave + 8 * (NTW - 1) < NT2) tail(std::integral_constant<int, NTW>{});
+    else tail(std::integral_constant<int, (NTW > 1 ? NTW - 1 : 1)>{});
+    __syncthreads();
+    PS_STAMP(7);
+  }
+  grid_exit(a.sync, nwg);
+}
+
+}  // namespace ps

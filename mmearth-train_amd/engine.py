@@ -49,6 +49,7 @@ ENGINE_OPTIONS = dict(
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
+    ps=1,                   # persistent per-sample stage kernels (ps.cuh) at (C, S) = (160, 2) / (320, 1): one launch per stage
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
@@ -275,13 +276,20 @@ class Engine:
         self.dpooled = self._t(N, D)
         T = len(cfg.out_mods)
         self.n_stats = sum(self._stat_sizes)
-        self.stats = torch.zeros(self.n_stats, dtype=f32, device=dev)
+        # persistent stage kernels: PS_NG accumulator copies of each statistics vector (same arena: zeroed once per step)
+        self.PS_NG = 4
+        ps_blocks = [blk for blk in self.blocks if self._ps_ok(blk["stage"])]
+        self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks), dtype=f32, device=dev)
         off = 0
         for blk in self.blocks + [self.dec]:
             G, H = blk["G"], blk["H"]
             for nm in ("G2", "S0", "S1"):
                 blk[nm] = self.stats[off:off + G * H]
                 off += G * H
+        for blk in ps_blocks:
+            for nm in ("G2", "S0", "S1"):
+                blk["ps_" + nm] = self.stats[off:off + self.PS_NG * blk["H"]]
+                off += self.PS_NG * blk["H"]
         self.loss_acc = torch.zeros(T, N, 2, dtype=f32, device=dev)      # per-sample {sum, count} partials
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
@@ -651,6 +659,55 @@ class Engine:
     def _block_bwd(self, lst, blk, dout, dx):
         return (self._block_bwd_mat if blk["mode"] == "mat" else self._block_bwd_fused)(lst, blk, dout, dx)
 
+    # ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------
+    def _ps_ok(self, stage):
+        """One launch for the whole stage: bf16, (C, S) = (160, 2) or (320, 1), every sample's workgroup resident (N <= CUs)."""
+        if not self.opt["ps"] or self.dt != BF16 or self.disable_rs or (self.block_mode_override or "mat") != "mat":
+            return False
+        Cc, S, depth = self.cfg.dims[stage], self.S[stage], self.cfg.depths[stage]
+        if (Cc, S) not in ((160, 2), (320, 1)) or depth > _lib.PS_MAXBLK:
+            return False
+        if self.keep * S * S > (80 if S == 2 else 32) or self.keep * S * S * Cc * 4 >= 65535:
+            return False
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+        return self.N <= cus
+
+    def _stage_fwd_ps(self, lst, stage, blks, x):
+        P = self.params
+        a = _lib.PsArgs()
+        a.x_in, a.g, a.act = x.data_ptr(), self._geom(stage), (self.act[stage].data_ptr() if self.act[stage] is not None else 0)
+        a.C, a.nblk, a.eps, a.ng = blks[0]["C"], len(blks), 1e-6, self.PS_NG
+        if not hasattr(self, "ps_sync"):
+            self.ps_sync = torch.zeros(8, 64, dtype=torch.int32, device=self.device)     # one {arrivals, departures, error, -, debug...} row per launch
+            self._ps_launches = 0
+        a.sync = self.ps_sync[self._ps_launches].data_ptr()
+        self._ps_launches += 1
+        nbytes = flops = 0
+        for i, blk in enumerate(blks):
+            nm, tag = self._block_names(blk), blk["prefix"]
+            M, Cc, H = blk["M"], blk["C"], blk["H"]
+            blk["mode"], blk["x"] = "mat", x
+            if "xn" not in blk:
+                blk["xn"] = self._t(M, Cc)
+                blk["z"] = self._t(M, H)
+            blk["rs"], blk["rs_n"] = self._rs_plan(blk)
+            blk["grn_fold"] = (blk["rs_n"] == "fused" and blk["G"] == 1 and self.grn_fold and Cc >= int(self.opt["grn_fold_minc"]))
+            b = a.blk[i]
+            b.dw_w, b.dw_b = P[tag + ".dwconv.kernel"].data_ptr(), P[tag + ".dwconv.bias"].data_ptr()
+            b.ln_g, b.ln_b = P[nm["ln_w"]].data_ptr(), P[nm["ln_b"]].data_ptr()
+            w1, w2 = self.w[tag + ".W1"], self.w[tag + ".W2"]
+            b.W1, b.ldw1, b.b1 = w1["t"].data_ptr(), w1["ld"], P[nm["b1"]].data_ptr()
+            b.W2, b.ldw2, b.b2 = w2["t"].data_ptr(), w2["ld"], P[nm["b2"]].data_ptr()
+            b.grn_g, b.grn_b = P[nm["gg"]].data_ptr(), P[nm["gb"]].data_ptr()
+            b.dhat, b.rstd, b.xn, b.h, b.z, b.out = (blk[k].data_ptr() for k in ("dhat", "rstd", "xn", "h", "z", "out"))
+            b.G2, b.Gx, b.Ainv, b.scale = (blk[k].data_ptr() for k in ("ps_G2", "Gx", "Ainv", "scale"))
+            nbytes += (4 * M * Cc + 2 * M * H) * 2 + 2 * Cc * H * 2       # x-hat, xn, out written + one read of x; h, z written; weights once
+            flops += 4 * M * Cc * H + 2 * 49 * M * Cc
+            x = blk["out"]
+        self._keepalive.append(a)
+        self._op(lst, f"encoder.stages.{stage}:ps.fwd[{len(blks)}]", self.lib.mpmae_ps_fwd, C.byref(a), kind="ps_fwd", nbytes=nbytes, flops=flops)
+        return x
+
     def _block_fwd_mat(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
         nm = self._block_names(blk)
@@ -950,6 +1007,10 @@ class Engine:
                                ldc=dims[i], p0=P[pre + ".0.ln.weight"], p1=P[pre + ".0.ln.bias"], S=self.S[i],
                                Cseg=dims[i - 1], act=self.act[i], act_src=self.act[i - 1])
                 x = dn["out"]
+            if self._ps_ok(i):
+                x = self._stage_fwd_ps(f, i, self.blocks[bi:bi + cfg.depths[i]], x)
+                bi += cfg.depths[i]
+                continue
             for j in range(cfg.depths[i]):
                 x = self._block_fwd(f, self.blocks[bi], x)
                 bi += 1

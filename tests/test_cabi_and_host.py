@@ -37,7 +37,8 @@ def test_struct_layouts_match_header(tmp_path):
     names = dict(MpmaeGeom=_lib.Geom, MpmaeGemmArgs=_lib.GemmArgs, MpmaeWgradArgs=_lib.WgradArgs,
                  MpmaeDwArgs=_lib.DwArgs, MpmaeDwWgArgs=_lib.DwWgArgs, MpmaePrepDesc=_lib.PrepDesc,
                  MpmaePixContArgs=_lib.PixContArgs, MpmaePixCatArgs=_lib.PixCatArgs, MpmaeImgArgs=_lib.ImgArgs,
-                 MpmaeRsArgs=_lib.RsArgs, MpmaeStemTailArgs=_lib.StemTailArgs)
+                 MpmaeRsArgs=_lib.RsArgs, MpmaeStemTailArgs=_lib.StemTailArgs,
+                 MpmaePsBlock=_lib.PsBlock, MpmaePsArgs=_lib.PsArgs)
     src = tmp_path / "sz.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
     src.write_text(f'#include <stdio.h>\n#include "mpmae_hip.h"\nint main(void) {{\n{body}\n  return 0;\n}}\n')
@@ -57,7 +58,7 @@ def test_engine_program_builds_on_cpu(lib):
     cfg = make_cfg()
     eng = Engine(cfg, 2, dtype="bf16", device="cpu")
     assert eng.n_params == 7580674                    # SURVEY §8a row 13 (all_mod atto)
-    assert len(eng.fwd_ops) > 50 and len(eng.bwd_ops) > 50
+    assert len(eng.fwd_ops) > 30 and len(eng.bwd_ops) > 50      # (stages 2 / 3 of the forward are ONE persistent launch each)
     sd = make_state_dict(cfg, seed=1)
     eng.load_state_dict(sd)
     full = eng.state_dict()

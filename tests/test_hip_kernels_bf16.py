@@ -50,7 +50,7 @@ def eng():
     from mmearth_train_amd.synth import make_inputs, make_state_dict
     cfg = make_cfg()
     N = 6
-    e = Engine(cfg, N, dtype="bf16", device=DEV)
+    e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=0))      # per-block kernels (the persistent stage kernels have their own test below)
     e.load_state_dict(make_state_dict(cfg, seed=21))
     inputs, noise = make_inputs(cfg, N, seed=22)
     z = torch.rand(N, 1, 56, 56, generator=torch.Generator().manual_seed(23)) < 0.06
@@ -401,3 +401,53 @@ def test_depthwise_stem_2x2_stride2_bf16(Cc, S, NK):
     _assert_bf16_close(din, rdin, "stem dw din")
     rdw = torch.einsum("nyxc,nyhxwc->whc", g, xv * act_in.view(NK, S, 2, S, 2, 1)).reshape(4, Cc)
     assert _rel(dw, rdw) < 3e-4 and _rel(db, dout.float().sum(0)) < 3e-4
+
+
+def _ps_pair(N, seed):
+    """Two bf16 engines on the same weights / inputs / mask: persistent stage kernels (csrc/ps.cuh) vs the per-block kernels."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.engine import Engine
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg()
+    sd = make_state_dict(cfg, seed=seed)
+    inputs, noise = make_inputs(cfg, N, seed=seed + 1)
+    z = torch.rand(N, 1, 56, 56, generator=torch.Generator().manual_seed(seed + 2)) < 0.05      # inactive sites inside visible patches
+    inputs["sentinel2"] = inputs["sentinel2"] * (~z)
+    engs = []
+    for ps in (0, 1):
+        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=ps))
+        e.load_state_dict(sd)
+        e.set_inputs(inputs, noise)
+        engs.append(e)
+    return engs
+
+
+@pytest.mark.parametrize("N", [3, 40])
+def test_persistent_stage_kernels_match_the_per_block_kernels(N):
+    """mpmae_ps_fwd (one launch per stage, grid barrier per block) against mpmae_dwconv7_fwd + mpmae_rs + GEMMs on the same bf16
+    operands: every tensor the backward reads (x-hat, rstd, xn, h, z, out, GRN vectors), the losses and all gradients.
+    Stated bound: bf16 tensors within 2 bf16 ulps of each other relative to the tensor's max (both paths round the same fp32
+    values at slightly different points, and the differences of one block feed the next), statistics 1e-2."""
+    e0, e1 = _ps_pair(N, 31)
+    assert any(op[0].endswith("ps.fwd[6]") for op in e1.fwd_ops) and not any("ps.fwd" in op[0] for op in e0.fwd_ops)
+    for e in (e0, e1):
+        e.forward()
+        e.backward()
+    torch.cuda.synchronize()
+    assert int(e1.ps_sync[:, 2].sum()) == 0, "a persistent kernel timed out at its grid barrier"
+    assert int(e1.ps_sync[:, :2].abs().sum()) == 0, "arrival / departure counters must be left at zero"
+    assert torch.equal(e0.mask, e1.mask)
+    for b0, b1 in zip(e0.blocks, e1.blocks):
+        if b0["stage"] not in (2, 3):
+            continue
+        for k in ("dhat", "xn", "h", "z", "out"):
+            a, b = b1[k].float(), b0[k].float()
+            assert (a - b).abs().max() <= 2 * 2.0 ** -7 * b.abs().max(), (b0["prefix"], k)
+            assert ((b == 0) == (a == 0)).float().mean() > 0.999, (b0["prefix"], k, "zero rows (inactive sites)")
+        for k in ("rstd", "Gx", "scale"):
+            a, b = b1[k].float(), b0[k].float()
+            assert (a - b).abs().max() <= 1e-2 * b.abs().max(), (b0["prefix"], k)
+    assert torch.allclose(e1.losses, e0.losses, rtol=5e-3)
+    assert abs(e1.total.item() - e0.total.item()) <= 1e-3 * abs(e0.total.item())
+    cos = torch.nn.functional.cosine_similarity(e0.gflat.double(), e1.gflat.double(), dim=0).item()
+    assert cos > 0.9999, cos
