@@ -198,6 +198,33 @@ typedef struct MpmaePsArgs {
   MpmaePsBlock blk[MPMAE_PS_MAXBLK];
 } MpmaePsArgs;
 int mpmae_ps_fwd(const MpmaePsArgs* args, mpmae_stream_t stream);
+/* Backward twin (autograd of the same blocks), blocks in REVERSE order of the stage: blk[0] is the stage's LAST block. Per
+ * block: dz = dout W2 and the batch-global sums (sum dz, sum dz gelu(h)) -> GRN backward -> dh (stored: operand of pwconv1's
+ * weight gradient) -> dxn = dh W1 -> LayerNorm backward -> dd (stored: operand of the depthwise weight gradient) -> depthwise
+ * data gradient + residual -> dx (stored: the next block's dout, operand of ITS pwconv2 weight gradient). d_grn_g / d_grn_b /
+ * d_ln_g / d_ln_b are ACCUMULATED (GRN ones by workgroup 0 behind the grid barrier, LayerNorm ones by a second-stage launch over
+ * the per-workgroup slab rows in ln_slab). The weight / bias gradients of pwconv1, pwconv2 and
+ * the depthwise convolution stay with mpmae_wgrad / mpmae_dwconv7_wgrad on the operands saved here and by the forward.
+ * Same shape limits, `sync` protocol and `ng` as mpmae_ps_fwd; S0 / S1 are [ng][4C] zero-initialised accumulators. */
+typedef struct MpmaePsBwdBlock {
+  const float* dw_w; const float* ln_g; const float* grn_g;
+  const void* W2T; const void* W1T;            /* staged bf16 [4C][ldw2t] (= W2^T), [C][ldw1t] (= W1^T) */
+  int ldw2t, ldw1t;
+  const void* h; const void* dhat; const float* rstd;            /* saved by the forward */
+  const float* Gx; const float* Ainv; const float* scale;
+  float* S0; float* S1; float* coef;                             /* statistics accumulators; coef [4C] optional output */
+  float* d_grn_g; float* d_grn_b; float* d_ln_g; float* d_ln_b;  /* parameter gradients, accumulated */
+  void* dh; void* dd; void* dx;                                  /* [M, 4C], [M, C], [M, C] */
+} MpmaePsBwdBlock;
+typedef struct MpmaePsBwdArgs {
+  const void* dout_in;                         /* gradient wrt the stage output [M, C] bf16 */
+  MpmaeGeom g; const uint8_t* act;
+  int C, nblk, ng;
+  unsigned* sync;
+  float* ln_slab;                              /* scratch [nblk][N][2C] floats: per-workgroup LayerNorm parameter-gradient partials */
+  MpmaePsBwdBlock blk[MPMAE_PS_MAXBLK];
+} MpmaePsBwdArgs;
+int mpmae_ps_bwd(const MpmaePsBwdArgs* args, mpmae_stream_t stream);
 
 /* im2col of the masked fp32 NCHW image for the sparse 3x3 stem convolution (MinkowskiConvolution
  * 3x3 of convnextv2_sparse.py:113-117): out[(n*keep+slot)*S*S + iy*S + ix][k], k = (kw*3+kh)*Cseg + cin

@@ -1321,6 +1321,39 @@ static int launch_ps_fwd(const MpmaePsArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+template <int C, int S>
+static int launch_ps_bwd(const MpmaePsBwdArgs& a, hipStream_t st) {
+  using K = ps::Cfg<C, S>;
+  if (!a.dout_in || !a.g.vis || !a.g.inv || !a.sync || a.nblk < 1 || a.nblk > MPMAE_PS_MAXBLK || a.ng < 1 || a.ng > 16) return (int)hipErrorInvalidValue;
+  if (a.g.S != S || a.g.keep < 1 || a.g.keep > (S == 2 ? K::RP / 4 : 32) || a.g.N < 1 || a.g.N > ps_num_cus()) return (int)hipErrorInvalidValue;
+  if ((size_t)a.g.keep * S * S * C * 4 >= 65535u || ((uintptr_t)a.dout_in & 15)) return (int)hipErrorInvalidValue;
+  for (int b = 0; b < a.nblk; ++b) {
+    const MpmaePsBwdBlock& B = a.blk[b];
+    if (!B.dw_w || !B.ln_g || !B.grn_g || !B.W2T || !B.W1T || !B.h || !B.dhat || !B.rstd || !B.Gx || !B.Ainv || !B.scale || !B.S0 || !B.S1 ||
+        !B.d_grn_g || !B.d_grn_b || !B.d_ln_g || !B.d_ln_b || !B.dh || !B.dd || !B.dx || !a.ln_slab || (B.ldw2t & 7) || (B.ldw1t & 7) || B.ldw2t < C || B.ldw1t < 4 * C)
+      return (int)hipErrorInvalidValue;
+    if (((uintptr_t)B.W2T | (uintptr_t)B.W1T | (uintptr_t)B.h | (uintptr_t)B.dhat | (uintptr_t)B.dh | (uintptr_t)B.dd | (uintptr_t)B.dx |
+         (uintptr_t)B.dw_w | (uintptr_t)B.ln_g) & 15)
+      return (int)hipErrorInvalidValue;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)ps::ps_bwd_kernel<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS) != hipSuccess) return (int)hipGetLastError();
+    attr = true;
+  }
+  LAUNCH((ps::ps_bwd_kernel<C, S>), dim3(a.g.N), dim3(ps::NTHR), K::LDS, st, a);
+  const int nwg = a.g.N;
+  LAUNCH(ps::ps_ln_reduce_kernel, dim3((2 * C + 63) / 64, a.nblk), dim3(256), 0, st, a, nwg);
+  return launch_status();
+}
+
+int mpmae_ps_bwd(const MpmaePsBwdArgs* a, mpmae_stream_t s) {
+  if (!a) return (int)hipErrorInvalidValue;
+  if (a->C == 160 && a->g.S == 2) return launch_ps_bwd<160, 2>(*a, S_(s));
+  if (a->C == 320 && a->g.S == 1) return launch_ps_bwd<320, 1>(*a, S_(s));
+  return (int)hipErrorInvalidValue;
+}
+
 int mpmae_ps_fwd(const MpmaePsArgs* a, mpmae_stream_t s) {
   if (!a) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->g.S == 2) return launch_ps_fwd<160, 2>(*a, S_(s));

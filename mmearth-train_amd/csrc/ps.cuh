@@ -70,6 +70,7 @@ __device__ __forceinline__ void grid_exit(unsigned* sync, unsigned nwg) {
 
 template <int C, int S> struct Cfg {
   static constexpr int H = 4 * C, SS = S * S;
+  static constexpr int NRG_ = NTHR / (H / 8);
   static constexpr int MT = (S == 2) ? 5 : 2, RP = 16 * MT;            // row tiles: keep * S^2 <= RP
   static constexpr int NB = (S == 2) ? 2 : 3, NBW = 2 * NB + 1, NBN = NBW * NBW;   // neighbour patches of the 7x7 window
   static constexpr int MASKW = (NBN * 2 + 3) / 4;                       // dword of the presence mask inside a table row
@@ -78,7 +79,9 @@ template <int C, int S> struct Cfg {
   static constexpr int LDX = C + 8, LDH = H + 16;
   static constexpr int XA_B = RP * LDX * 2, HA_B = RP * LDH * 2;
   static constexpr int OFF_XA = 0, OFF_HA = XA_B, OFF_VEC = OFF_HA + HA_B, OFF_CS = OFF_VEC + 2 * H * 4,
-                       OFF_TAB = OFF_CS + H * 4, OFF_LIVE = OFF_TAB + 32 * TABB, OFF_RED = OFF_LIVE + RP, LDS = OFF_RED + 64;
+                       OFF_TAB = OFF_CS + 2 * H * 4, OFF_LIVE = OFF_TAB + 32 * TABB, OFF_RED = OFF_LIVE + RP, OFF_ROW = OFF_RED + 64,
+                       LDS = OFF_ROW + RP * 8;                           // OFF_ROW: LayerNorm-backward row sums [RP][2]
+  static constexpr int NCHK = (RP + NRG_ - 1) / NRG_;                  // rows per thread of the element-wise passes
   static_assert(ZOFF + SS * C * 4 <= HA_B && ZOFF + SS * C * 4 < 65536, "XF alias + zero patch");
   static_assert(LDS <= 160 * 1024, "LDS");
   static constexpr int CP = C / 2, NPG = NTHR / CP;                    // depthwise: channel pairs x patch groups
@@ -89,23 +92,28 @@ template <int C, int S> struct Cfg {
 // wl: this lane's weight pointer (&W[(n_first + lr) * ldw + lg * 8]); tile j is wl + j * tstride. W streams global -> registers through a
 // ring of D k-steps; gemm_prefetch() issues the first D steps (call it a phase EARLY: weights do not depend on anything the kernel
 // computes, so their L2 latency hides behind the preceding LayerNorm / barrier), gemm_run() consumes and refills the ring.
+// `rot` (workgroup-uniform, 0 .. KS-1) rotates the order in which the k-steps are visited: every workgroup of the launch streams the
+// SAME weight matrix at the same moment, and in lock step they would all hit the same L2 channel at once.
+template <int KS> __device__ __forceinline__ int kstep(int ks, int rot) { const int t = ks + rot; return (t >= KS ? t - KS : t) * 32; }
 template <int NTL, int KS, int D>
-__device__ __forceinline__ void gemm_prefetch(const bf16_t* __restrict__ wl, const int tstride, uint4 (&wq)[D][NTL]) {
+__device__ __forceinline__ void gemm_prefetch(const bf16_t* __restrict__ wl, const int tstride, uint4 (&wq)[D][NTL], const int rot = 0) {
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < KS) {
+      const int ko = kstep<KS>(s, rot);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) wq[s][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + s * 32);
+      for (int j = 0; j < NTL; ++j) wq[s][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + ko);
     }
 }
 template <int NTL, int MT, int KS, int D, int LDA>
 __device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ wl, const int tstride, const bf16_t* al, uint4 (&wq)[D][NTL],
-                                         f32x4_t (&acc)[NTL][MT]) {
+                                         f32x4_t (&acc)[NTL][MT], const int rot = 0) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     bf16x8_t af[MT];
+    const int ka = kstep<KS>(ks, rot);
 #pragma unroll
-    for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(al + m * 16 * LDA + ks * 32));
+    for (int m = 0; m < MT; ++m) af[m] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(al + m * 16 * LDA + ka));
 #pragma unroll
     for (int j = 0; j < NTL; ++j) {
       const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wq[ks % D][j]);
@@ -113,8 +121,9 @@ __device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ wl, const in
       for (int m = 0; m < MT; ++m) acc[j][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[m], acc[j][m], 0, 0, 0);
     }
     if (ks + D < KS) {
+      const int ko = kstep<KS>(ks + D, rot);
 #pragma unroll
-      for (int j = 0; j < NTL; ++j) wq[ks % D][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + (ks + D) * 32);
+      for (int j = 0; j < NTL; ++j) wq[ks % D][j] = *reinterpret_cast<const uint4*>(wl + (size_t)j * tstride + ko);
     }
   }
 }
@@ -206,11 +215,11 @@ __device__ __forceinline__ void dw_gather(const unsigned char* smem, f32x2_t (&a
 // neighbour table of the sample's visible patches: per patch slot k a row of TABB bytes = NBN uint16 XF byte offsets (absent -> ZOFF,
 // the zero patch) and the presence mask at dword MASKW
 template <int C, int S>
-__device__ __forceinline__ void build_tab(const PsP& a, unsigned char* smem, int n) {
+__device__ __forceinline__ void build_tab(const MpmaeGeom& g_, unsigned char* smem, int n) {
   using K = Cfg<C, S>;
   unsigned short* tab = reinterpret_cast<unsigned short*>(smem + K::OFF_TAB);
   unsigned* tabw = reinterpret_cast<unsigned*>(smem + K::OFF_TAB);
-  const int keep = a.g.keep, grid = a.g.grid, L = grid * grid;
+  const int keep = g_.keep, grid = g_.grid, L = grid * grid;
   for (int i = threadIdx.x; i < keep * (K::TABB / 4); i += NTHR) {
     const int k = i / (K::TABB / 4), wd = i - k * (K::TABB / 4);
     if (wd >= K::MASKW) tabw[i] = 0u;
@@ -218,10 +227,10 @@ __device__ __forceinline__ void build_tab(const PsP& a, unsigned char* smem, int
   __syncthreads();
   for (int i = threadIdx.x; i < keep * K::NBN; i += NTHR) {
     const int k = i / K::NBN, nb = i - k * K::NBN;
-    const int patch = a.g.vis[n * keep + k];
+    const int patch = g_.vis[n * keep + k];
     const int qy = patch / grid + nb / K::NBW - K::NB, qx = patch % grid + nb % K::NBW - K::NB;
     int slot = -1;
-    if (qy >= 0 && qx >= 0 && qy < grid && qx < grid) slot = a.g.inv[n * L + qy * grid + qx];
+    if (qy >= 0 && qx >= 0 && qy < grid && qx < grid) slot = g_.inv[n * L + qy * grid + qx];
     tab[k * (K::TABB / 2) + nb] = slot >= 0 ? (unsigned short)(slot * K::SS * C * 4) : (unsigned short)K::ZOFF;
     if (slot >= 0) atomicOr(&tabw[k * (K::TABB / 4) + K::MASKW + (nb >> 5)], 1u << (nb & 31));
   }
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
   {
   const int tid = tid0;
   for (int i = tid; i < K::XA_B / 16; i += NTHR) reinterpret_cast<uint4*>(XA)[i] = make_uint4(0u, 0u, 0u, 0u);
-  build_tab<C, S>(a, smem, n);
+  build_tab<C, S>(a.g, smem, n);
   for (int i = tid; i < RP; i += NTHR) live[i] = (i < R) ? (a.act ? a.act[rowbase + i] : (unsigned char)1) : (unsigned char)0;
   {
     const T* xin = reinterpret_cast<const T*>(a.x_in) + rowbase * C;
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     const int n0 = wave * (H / 8);
     const T* W1 = reinterpret_cast<const T*>(B.W1);
     uint4 wq1[D1][NTL1];
-    gemm_prefetch<NTL1, KS1, D1>(W1 + (size_t)(n0 + lr) * B.ldw1 + lg * 8, 16 * B.ldw1, wq1);
+    gemm_prefetch<NTL1, KS1, D1>(W1 + (size_t)(n0 + lr) * B.ldw1 + lg * 8, 16 * B.ldw1, wq1, n % KS1);
     __syncthreads();
 
     PS_STAMP(1);
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
       for (int jg = 0; jg < NT1 / NTL1; ++jg) {
         const int nb0 = n0 + jg * NTL1 * 16;
         const T* wl = W1 + (size_t)(nb0 + lr) * B.ldw1 + lg * 8;
-        if (jg > 0) gemm_prefetch<NTL1, KS1, D1>(wl, 16 * B.ldw1, wq1);
+        if (jg > 0) gemm_prefetch<NTL1, KS1, D1>(wl, 16 * B.ldw1, wq1, n % KS1);
         float4 b4[NTL1];
 #pragma unroll
         for (int j = 0; j < NTL1; ++j) b4[j] = *reinterpret_cast<const float4*>(B.b1 + nb0 + j * 16 + lg * 4);
@@ -401,7 +410,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
         for (int j = 0; j < NTL1; ++j)
 #pragma unroll
           for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        gemm_run<NTL1, MT, KS1, D1, LDX>(wl, 16 * B.ldw1, XA + lr * LDX + lg * 8, wq1, acc);
+        gemm_run<NTL1, MT, KS1, D1, LDX>(wl, 16 * B.ldw1, XA + lr * LDX + lg * 8, wq1, acc, n % KS1);
         bool lv[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) lv[m] = live[m * 16 + lr] != 0;
@@ -453,7 +462,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
         if (j < H) (void)unsafeAtomicAdd(B.G2 + (size_t)(n % a.ng) * H + j, csum[j]);      // ng accumulator copies: fewer colliding adds per line
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds are performed (acknowledged) before this workgroup arrives
-      gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw2, wq2);      // pw2's first weight slabs travel while the barrier is waited for
+      gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw2, wq2, n % KS2);      // pw2's first weight slabs travel while the barrier is waited for
       grid_barrier(a.sync, (unsigned)(b + 1) * nwg);
       PS_STAMP(4);
       float gx[NJ], s = 0.f;
@@ -527,7 +536,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
       for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      gemm_run<NTL, MT, KS2, D2, LDH>(wl2, 8 * 16 * B.ldw2, HA + lr * LDH + lg * 8, wq2, acc);
+      gemm_run<NTL, MT, KS2, D2, LDH>(wl2, 8 * 16 * B.ldw2, HA + lr * LDH + lg * 8, wq2, acc, n % KS2);
       __syncthreads();                               // every wave is done reading z: HA's bytes become XF
 #pragma unroll
       for (int j = 0; j < NTL; ++j) {
@@ -558,6 +567,362 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     PS_STAMP(7);
   }
   grid_exit(a.sync, nwg);
+}
+
+// =====================================================================================
+// backward: the blocks of one stage in REVERSE order (a.blk[0] = last block of the stage). Per block
+//   dz = dout W2 (-> HA)            | column sums S0 = sum dz, S1 = sum dz gelu(h) -> atomics, grid barrier, GRN backward finalisation
+//   dh = (dz scale + coef gelu(h)) gelu'(h) (-> HA, global)   | dxn = dh W1, LayerNorm backward -> dd (global, fp32 rows XF)
+//   dx = depthwise^T(dd) + dout (-> XA = next block's dout, global)
+// h is read ONCE per block, 16 bytes per lane in the layout of the element-wise passes, and kept in registers from the end of the
+// previous block (its HBM latency hides behind that block's depthwise phase) across the barrier.
+template <int C, int S>
+__global__ __launch_bounds__(512) void ps_bwd_kernel(const MpmaePsBwdArgs a) {
+  using K = Cfg<C, S>;
+  using T = bf16_t;
+  constexpr int H = K::H, SS = K::SS, MT = K::MT, RP = K::RP, LDX = K::LDX, LDH = K::LDH, NCHK = K::NCHK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  bf16_t* XA = reinterpret_cast<bf16_t*>(smem + K::OFF_XA);
+  bf16_t* HA = reinterpret_cast<bf16_t*>(smem + K::OFF_HA);
+  float* XF = reinterpret_cast<float*>(smem + K::OFF_HA);
+  float* vec = reinterpret_cast<float*>(smem + K::OFF_VEC);
+  float* csum = reinterpret_cast<float*>(smem + K::OFF_CS);
+  unsigned char* live = smem + K::OFF_LIVE;
+  float* red = reinterpret_cast<float*>(smem + K::OFF_RED);
+  float* rowsum = reinterpret_cast<float*>(smem + K::OFF_ROW);
+
+  const int tid0 = threadIdx.x;
+  const int n = blockIdx.x, nwg = gridDim.x;
+  const int keep = a.g.keep, R = keep * SS;
+  const size_t rowbase = (size_t)n * R;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const char* kchar_p;
+  typedef __attribute__((address_space(4))) const MpmaePsBwdBlock* kblk_p;
+  const kblk_p blks = (kblk_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MpmaePsBwdArgs, blk));
+#else
+  const MpmaePsBwdBlock* blks = a.blk;
+#endif
+
+  uint4 hreg[NCHK];                       // this thread's h rows of the CURRENT block (column chunk cc, rows rg + i NRG)
+  auto load_h = [&](const void* hp, int tid) {
+    const int cc = tid % K::NCC, rg = tid / K::NCC;
+    const T* hg = reinterpret_cast<const T*>(hp) + rowbase * H + cc * 8;
+#pragma unroll
+    for (int i = 0; i < NCHK; ++i) {
+      const int m = min(rg + i * K::NRG, R - 1);
+      hreg[i] = *reinterpret_cast<const uint4*>(hg + (size_t)m * H);
+    }
+  };
+  // ---- stage prologue
+  {
+    const int tid = tid0;
+    for (int i = tid; i < K::XA_B / 16; i += NTHR) reinterpret_cast<uint4*>(XA)[i] = make_uint4(0u, 0u, 0u, 0u);
+    build_tab<C, S>(a.g, smem, n);
+    for (int i = tid; i < RP; i += NTHR) live[i] = (i < R) ? (a.act ? a.act[rowbase + i] : (unsigned char)1) : (unsigned char)0;
+    __syncthreads();
+    const T* din = reinterpret_cast<const T*>(a.dout_in) + rowbase * C;
+    for (int i = tid; i < R * (C / 8); i += NTHR) {
+      const int row = i / (C / 8), q = i - row * (C / 8);
+      *reinterpret_cast<uint4*>(XA + row * LDX + q * 8) = *reinterpret_cast<const uint4*>(din + (size_t)row * C + q * 8);
+    }
+    if (tid < (NTHR / K::NCC) * K::NCC) load_h(blks[0].h, tid);
+  }
+  __syncthreads();
+
+  for (int b = 0; b < a.nblk; ++b) {
+    const MpmaePsBwdBlock B = blks[b];
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lg = lane >> 4;
+    const int cc = tid % K::NCC, rg = tid / K::NCC;
+    const bool ew = rg < K::NRG;                           // thread takes part in the element-wise passes
+
+    PS_STAMP(0);
+    // ---- B1: dz = dout W2 (weights: staged W2^T [H][C]), bf16 -> HA
+    {
+      constexpr int NT1 = C / 32, KS1 = C / 32, NTL1 = (NT1 % 5 == 0) ? 5 : NT1, D1 = (KS1 < 3) ? KS1 : 3;
+      const int n0 = wave * (H / 8);
+      const T* W2T = reinterpret_cast<const T*>(B.W2T);
+#pragma unroll 1
+      for (int jg = 0; jg < NT1 / NTL1; ++jg) {
+        const int nb0 = n0 + jg * NTL1 * 16;
+        const T* wl = W2T + (size_t)(nb0 + lr) * B.ldw2t + lg * 8;
+        uint4 wq1[D1][NTL1];
+        gemm_prefetch<NTL1, KS1, D1>(wl, 16 * B.ldw2t, wq1, n % KS1);
+        f32x4_t acc[NTL1][MT];
+#pragma unroll
+        for (int j = 0; j < NTL1; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        gemm_run<NTL1, MT, KS1, D1, LDX>(wl, 16 * B.ldw2t, XA + lr * LDX + lg * 8, wq1, acc, n % KS1);
+#pragma unroll
+        for (int j = 0; j < NTL1; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float o[4] = {acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]};
+            *reinterpret_cast<uint2*>(HA + (m * 16 + lr) * LDH + nb0 + j * 16 + lg * 4) = pack_bf16x4(o);
+          }
+      }
+    }
+    for (int i = tid; i < 2 * H; i += NTHR) csum[i] = 0.f;
+    for (int i = tid; i < RP * 2; i += NTHR) rowsum[i] = 0.f;
+    // this block's h (HBM): requested BEHIND the product's weight loads - vmcnt retires in order, so issued in front of them (at the end
+    // of the previous block) every weight load of the product waited for the HBM round trip of h
+    if (b > 0 && ew) load_h(B.h, tid);
+    __syncthreads();
+
+    PS_STAMP(1);
+    // ---- B2: column sums of dz and dz gelu(h) over this sample's rows (thread: 8 columns x its rows), then the exchange
+    constexpr int NT2 = C / 16, NTW = (NT2 + 7) / 8, KS2 = H / 32;
+    auto tail = [&](auto ntl_) {
+      constexpr int NTL = decltype(ntl_)::value;
+      constexpr int D2 = (S == 2) ? 8 : 6;
+      const T* W1T = reinterpret_cast<const T*>(B.W1T);
+      const T* wl2 = W1T + (size_t)(wave * 16 + lr) * B.ldw1t + lg * 8;
+      uint4 wq2[D2][NTL];
+      if (ew) {
+        float s0[8], s1[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {
+          const int m = rg + i * K::NRG;
+          float dz[8], hv[8], g[8];
+          unpack8(*reinterpret_cast<const uint4*>(HA + min(m, RP - 1) * LDH + cc * 8), dz);
+          unpack8(hreg[i], hv);
+          gelu_n<T, 8>(hv, g);
+          const bool in = m < R;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s0[e] += in ? dz[e] : 0.f; s1[e] += in ? dz[e] * g[e] : 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {            // element-major layout: the lanes of one ds_add hit consecutive banks (column-major was 16-way conflicted)
+          atomicAdd(&csum[e * K::NCC + cc], s0[e]);
+          atomicAdd(&csum[H + e * K::NCC + cc], s1[e]);
+        }
+      }
+      __syncthreads();
+      constexpr int NJ = (2 * H + NTHR - 1) / NTHR;
+#pragma unroll
+      for (int u = 0; u < NJ; ++u) {
+        const int j = tid + NTHR * u;            // [0, H): S0, [H, 2H): S1
+        if (j < 2 * H) {
+          const int jj = j < H ? j : j - H;
+          (void)unsafeAtomicAdd((j < H ? B.S0 : B.S1) + (size_t)(n % a.ng) * H + jj, csum[(j < H ? 0 : H) + (jj & 7) * K::NCC + (jj >> 3)]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw1t, wq2, n % KS2);
+      constexpr int NH = (H + NTHR - 1) / NTHR;
+      float gg[NH], gxv[NH], scv[NH];
+#pragma unroll
+      for (int u = 0; u < NH; ++u) {
+        const int jc = min(tid + NTHR * u, H - 1);
+        gg[u] = B.grn_g[jc]; gxv[u] = B.Gx[jc]; scv[u] = B.scale[jc];
+      }
+      const float ainv = B.Ainv[0];
+      grid_barrier(a.sync, (unsigned)(b + 1) * nwg);
+      PS_STAMP(2);
+      // ---- B3: GRN backward finalisation (grn_bwd_finalize_kernel, rows.cuh) by every workgroup; workgroup 0 owns dgamma / dbeta
+      float s0v[NH], s1v[NH], ts = 0.f;
+#pragma unroll
+      for (int u = 0; u < NH; ++u) {
+        const int j = tid + NTHR * u, jc = min(j, H - 1);
+        float t0 = 0.f, t1 = 0.f;
+        for (int q = 0; q < a.ng; ++q) { t0 += atomic_ld(B.S0 + (size_t)q * H + jc); t1 += atomic_ld(B.S1 + (size_t)q * H + jc); }
+        s0v[u] = t0; s1v[u] = t1;
+        ts += (j < H) ? gg[u] * t1 * gxv[u] : 0.f;
+      }
+      ts = wave_sum(ts);
+      if (lane == 0) red[wave] = ts;
+      __syncthreads();
+      float tot = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) tot += red[w8];
+      const float T2 = tot * ainv * ainv / H;
+#pragma unroll
+      for (int u = 0; u < NH; ++u) {
+        const int j = tid + NTHR * u;
+        if (j < H) {
+          const float dGx = gg[u] * s1v[u] * ainv - T2;
+          const float cf = (gxv[u] > 0.f) ? dGx / gxv[u] : 0.f;
+          vec[j] = scv[u];
+          vec[H + j] = cf;
+          if (n == 0) {
+            if (B.coef) B.coef[j] = cf;
+            B.d_grn_g[j] += gxv[u] * ainv * s1v[u];
+            B.d_grn_b[j] += s0v[u];
+          }
+        }
+      }
+      __syncthreads();
+
+      PS_STAMP(3);
+      // ---- B4: dh = (dz scale + coef gelu(h)) gelu'(h) in place on HA, saved for pw1's weight gradient
+      if (ew) {
+        float sc[8], cf[8];
+        ld8<float>(vec + cc * 8, sc);
+        ld8<float>(vec + H + cc * 8, cf);
+        T* dhg = reinterpret_cast<T*>(B.dh) + rowbase * H + cc * 8;
+#pragma unroll
+        for (int i = 0; i < NCHK; ++i) {
+          const int m = rg + i * K::NRG;
+          float dz[8], hv[8], g[8], dg[8], o[8];
+          unpack8(*reinterpret_cast<const uint4*>(HA + min(m, RP - 1) * LDH + cc * 8), dz);
+          unpack8(hreg[i], hv);
+          gelu_both_n<T, 8>(hv, g, dg);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (dz[e] * sc[e] + cf[e] * g[e]) * dg[e];
+          if (m < R) {
+            const uint4 pk = __builtin_bit_cast(uint4, pack_bf16x8(o));
+            *reinterpret_cast<uint4*>(dhg + (size_t)m * H) = pk;
+            *reinterpret_cast<uint4*>(HA + m * LDH + cc * 8) = pk;
+          }
+        }
+      }
+      // LayerNorm-backward operands: requested before the product
+      const T* xh = reinterpret_cast<const T*>(B.dhat) + rowbase * C;
+      uint2 xraw[NTL][MT];
+      float4 g4[NTL];
+      float rs[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) rs[m] = B.rstd[rowbase + min(m * 16 + lr, R - 1)];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        g4[j] = *reinterpret_cast<const float4*>(B.ln_g + (wave + 8 * j) * 16 + lg * 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          xraw[j][m] = *reinterpret_cast<const uint2*>(xh + (size_t)min(m * 16 + lr, R - 1) * C + (wave + 8 * j) * 16 + lg * 4);
+      }
+      __syncthreads();
+
+      PS_STAMP(4);
+      // ---- B5: dxn = dh W1 (weights: staged W1^T [C][H]), LayerNorm backward
+      f32x4_t acc[NTL][MT];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      gemm_run<NTL, MT, KS2, D2, LDH>(wl2, 8 * 16 * B.ldw1t, HA + lr * LDH + lg * 8, wq2, acc, n % KS2);
+      float rs1[MT], rs2[MT];
+      float* lnp = a.ln_slab + ((size_t)b * nwg + n) * 2 * C;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { rs1[m] = 0.f; rs2[m] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        const int nc = (wave + 8 * j) * 16 + lg * 4;
+        const float gq4[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w};
+        float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int row = m * 16 + lr;
+          const bool lvm = live[row] != 0;
+          float xhv[4];
+          unpack4(and2(xraw[j][m], row < R), xhv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dxn = lvm ? bf2f(f2bf(acc[j][m][r])) : 0.f;      // bf16 like the unfused path
+            ca[r] += dxn * xhv[r];
+            cb[r] += dxn;
+            const float gq = dxn * gq4[r];
+            acc[j][m][r] = gq;
+            rs1[m] += gq;
+            rs2[m] += gq * xhv[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sa = sum16(ca[r]), sb = sum16(cb[r]);
+          if (lr == 0) { lnp[nc + r] = sa; lnp[C + nc + r] = sb; }      // this workgroup's slab row; ps_ln_reduce_kernel folds the rows
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MT; ++m) { atomicAdd(&rowsum[(m * 16 + lr) * 2], rs1[m]); atomicAdd(&rowsum[(m * 16 + lr) * 2 + 1], rs2[m]); }
+      __syncthreads();                               // row sums complete; every wave is done reading dh: HA's bytes become XF
+      T* ddg = reinterpret_cast<T*>(B.dd) + rowbase * C;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int row = m * 16 + lr;
+        const bool lvm = live[row] != 0;
+        const float s1 = rowsum[row * 2] / C, s2 = rowsum[row * 2 + 1] / C;
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          const int nc = (wave + 8 * j) * 16 + lg * 4;
+          float xhv[4], o[4];
+          unpack4(and2(xraw[j][m], row < R), xhv);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = lvm ? rs[m] * (acc[j][m][r] - s1 - xhv[r] * s2) : 0.f;
+          if (row < R) {
+            const uint2 pk = pack_bf16x4(o);
+            *reinterpret_cast<uint2*>(ddg + (size_t)row * C + nc) = pk;
+            float of[4];
+            unpack4(pk, of);
+            *reinterpret_cast<float4*>(XF + row * C + nc) = make_float4(of[0], of[1], of[2], of[3]);
+          }
+        }
+      }
+      for (int i = tid; i < SS * C / 4; i += NTHR) *reinterpret_cast<float4*>(smem + K::OFF_HA + K::ZOFF + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (wave + 8 * (NTW - 1) < NT2) tail(std::integral_constant<int, NTW>{});
+    else tail(std::integral_constant<int, (NTW > 1 ? NTW - 1 : 1)>{});
+    __syncthreads();
+
+    PS_STAMP(5);
+    // ---- B6: dx = depthwise^T(dd) + dout (XA in place: the next block's dout), thread = (channel pair, patch group)
+    {
+      const int cp = tid % K::CP, pg = tid / K::CP;
+      if (pg < K::NPG) {
+        f32x2_t w[49];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cp);
+        T* dxg = reinterpret_cast<T*>(B.dx) + rowbase * C;
+#pragma unroll 1
+        for (int k = pg; k < keep; k += K::NPG) {
+          f32x2_t acc[4];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) acc[o] = (f32x2_t){0.f, 0.f};
+          dw_gather<C, S, 1>(smem, acc, k, cp, w);
+#pragma unroll
+          for (int o = 0; o < SS; ++o) {
+            const int row = k * SS + o;
+            const bool lv = live[row] != 0;
+            const unsigned dr = *reinterpret_cast<const unsigned*>(XA + row * LDX + 2 * cp);
+            const float d0 = __uint_as_float(dr << 16), d1 = __uint_as_float(dr & 0xffff0000u);
+            const unsigned pk = lv ? f2bf2(acc[o].x + d0, acc[o].y + d1) : 0u;
+            *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = pk;
+            *reinterpret_cast<unsigned*>(dxg + (size_t)row * C + 2 * cp) = pk;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    PS_STAMP(6);
+  }
+  grid_exit(a.sync, nwg);
+}
+
+// second stage of the LayerNorm parameter gradients of ps_bwd_kernel: slab [nblk][nwg][2C] -> d_ln_g / d_ln_b of every block
+__global__ __launch_bounds__(256) void ps_ln_reduce_kernel(const MpmaePsBwdArgs a, int nwg) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const char* kchar_p;
+  typedef __attribute__((address_space(4))) const MpmaePsBwdBlock* kblk_p;
+  const kblk_p blks = (kblk_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MpmaePsBwdArgs, blk));
+#else
+  const MpmaePsBwdBlock* blks = a.blk;
+#endif
+  __shared__ float part[4][64];
+  const int b = blockIdx.y, C2 = 2 * a.C;
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s = 0.f;
+  if (col < C2)
+    for (int w = q; w < nwg; w += 4) s += a.ln_slab[((size_t)b * nwg + w) * C2 + col];
+  part[q][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (q == 0 && col < C2) {
+    const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    float* dst = col < a.C ? blks[b].d_ln_g + col : blks[b].d_ln_b + (col - a.C);
+    *dst += t;
+  }
 }
 
 }  // namespace ps

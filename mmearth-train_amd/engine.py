@@ -50,6 +50,7 @@ ENGINE_OPTIONS = dict(
     prep_side=1,            # weight staging of the forward on the side lane
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     ps=1,                   # persistent per-sample stage kernels (ps.cuh) at (C, S) = (160, 2) / (320, 1): one launch per stage
+    ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
@@ -708,6 +709,55 @@ class Engine:
         self._op(lst, f"encoder.stages.{stage}:ps.fwd[{len(blks)}]", self.lib.mpmae_ps_fwd, C.byref(a), kind="ps_fwd", nbytes=nbytes, flops=flops)
         return x
 
+    def _stage_bwd_ps(self, lst, stage, blks, dout, ring, ri):
+        """Backward of a whole stage as ONE persistent launch (blocks in reverse order) + the stage's weight gradients on the side lane.
+        dout: gradient wrt the stage output; every block's dx goes to the next slot of the dx ring. Returns (dx of the stage, ring index)."""
+        P, Gd = self.params, self.grads
+        a = _lib.PsBwdArgs()
+        a.dout_in, a.g, a.act = dout.data_ptr(), self._geom(stage), (self.act[stage].data_ptr() if self.act[stage] is not None else 0)
+        a.C, a.nblk, a.ng = blks[0]["C"], len(blks), self.PS_NG
+        a.sync = self.ps_sync[self._ps_launches].data_ptr()
+        self._ps_launches += 1
+        slab = torch.zeros(len(blks) * self.N * 2 * blks[0]["C"], dtype=torch.float32, device=self.device)
+        self._keepalive.append(slab)
+        a.ln_slab = slab.data_ptr()
+        plan, cur = [], dout
+        nbytes = flops = 0
+        for i, blk in enumerate(reversed(blks)):
+            nm, tag = self._block_names(blk), blk["prefix"]
+            M, Cc, H = blk["M"], blk["C"], blk["H"]
+            t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1
+            dh = self.scr_dz2[t % len(self.scr_dz2)][:M * H]
+            dd = self.scr_dd2[t % len(self.scr_dd2)][:M * Cc]
+            dx = ring[ri][:M * Cc]
+            ri = (ri + 1) % len(ring)
+            w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
+            b = a.blk[i]
+            b.dw_w, b.ln_g, b.grn_g = P[tag + ".dwconv.kernel"].data_ptr(), P[nm["ln_w"]].data_ptr(), P[nm["gg"]].data_ptr()
+            b.W2T, b.ldw2t, b.W1T, b.ldw1t = w2t["t"].data_ptr(), w2t["ld"], w1t["t"].data_ptr(), w1t["ld"]
+            b.h, b.dhat, b.rstd = blk["h"].data_ptr(), blk["dhat"].data_ptr(), blk["rstd"].data_ptr()
+            b.Gx, b.Ainv, b.scale = blk["Gx"].data_ptr(), blk["Ainv"].data_ptr(), blk["scale"].data_ptr()
+            b.S0, b.S1, b.coef = blk["ps_S0"].data_ptr(), blk["ps_S1"].data_ptr(), blk["coef"].data_ptr()
+            b.d_grn_g, b.d_grn_b = Gd[nm["gg"]].data_ptr(), Gd[nm["gb"]].data_ptr()
+            b.d_ln_g, b.d_ln_b = Gd[nm["ln_w"]].data_ptr(), Gd[nm["ln_b"]].data_ptr()
+            b.dh, b.dd, b.dx = dh.data_ptr(), dd.data_ptr(), dx.data_ptr()
+            plan.append((blk, cur, dh, dd, dx))
+            nbytes += (M * H * 2 + 4 * M * Cc) * 2 + 2 * Cc * H * 2      # h read, dh written; x-hat read, dd / dx written (+ dout once); weights
+            flops += 4 * M * Cc * H + 2 * 49 * M * Cc
+            cur = dx
+        self._keepalive.append(a)
+        self._op(lst, f"encoder.stages.{stage}:ps.bwd[{len(blks)}]", self.lib.mpmae_ps_bwd, C.byref(a), kind="ps_bwd", nbytes=nbytes, flops=flops)
+        self._guard(lst, *[p_[2] for p_ in plan], *[p_[3] for p_ in plan], *[p_[4] for p_ in plan])
+        for blk, dout_b, dh, dd, dx in plan:          # the stage's weight gradients: side lane, behind the launch
+            nm, tag = self._block_names(blk), blk["prefix"]
+            M, Cc, H = blk["M"], blk["C"], blk["H"]
+            self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout_b], P=dout_b, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
+                             dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
+            self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dh], P=dh, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
+                             dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
+            self._dw_wgrad(lst, blk, dd)
+        return cur, ri
+
     def _block_fwd_mat(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
         nm = self._block_names(blk)
@@ -870,6 +920,11 @@ class Engine:
 
     def _dw_bwd(self, lst, blk, dd, dout, dx):
         """depthwise conv backward: weight/bias gradient, then data gradient (+ residual dout)."""
+        self._dw_wgrad(lst, blk, dd)
+        self._dwconv(lst, blk["prefix"] + ":dw.dgrad", blk, dd, dx, dout, 1, False)
+        self._guard(lst, dx)
+
+    def _dw_wgrad(self, lst, blk, dd):
         lib, dt = self.lib, self.dt
         M, Cc = blk["M"], blk["C"]
         act = self.act[blk["stage"]] if blk["sparse"] else None
@@ -895,8 +950,6 @@ class Engine:
         else:
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
                      nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
-        self._dwconv(lst, tag + ":dw.dgrad", blk, dd, dx, dout, 1, False)
-        self._guard(lst, dx)
 
     def _block_fwd_fused(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
@@ -1277,7 +1330,13 @@ class Engine:
         other = ring[ri]
         bi = len(self.blocks) - 1
         for i in range(3, -1, -1):
-            for j in range(cfg.depths[i] - 1, -1, -1):
+            if self._ps_ok(i) and bool(self.opt["ps_bwd"]):
+                d = cfg.depths[i]
+                cur, ri = self._stage_bwd_ps(b, i, self.blocks[bi - d + 1:bi + 1], cur, ring, ri)
+                other = ring[ri]
+                bi -= d
+            else:
+              for j in range(cfg.depths[i] - 1, -1, -1):
                 blk = self.blocks[bi]
                 nxt = other[:blk["M"] * blk["C"]]
                 self._block_bwd(b, blk, cur, nxt)

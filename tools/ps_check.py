@@ -62,7 +62,10 @@ def main():
             st = e1.ps_sync[r, 8:16].tolist()
             if any(st):
                 d = [(st[i + 1] - st[i]) & 0xffffffff for i in range(7)]
-                print(f"launch {r} block-1 phase cycles (workgroup 0): dw {d[0]} | LN {d[1]} | pw1 {d[2]} | stats+barrier {d[3]} | finalize {d[4]} | z {d[5]} | pw2 {d[6]}  total {sum(d)}")
+                if r < 2:
+                    print(f"launch {r} (fwd) block-1 phase cycles (workgroup 0): dw {d[0]} | LN {d[1]} | pw1 {d[2]} | stats+barrier {d[3]} | finalize {d[4]} | z {d[5]} | pw2 {d[6]}  total {sum(d)}")
+                else:
+                    print(f"launch {r} (bwd) block-1 phase cycles (workgroup 0): dz gemm {d[0]} | sums+barrier {d[1]} | finalize {d[2]} | dh {d[3]} | dxn gemm + LN bwd {d[4]} | dw dgrad {d[5]}  total {sum(d[:6])}")
     worst = 0.0
     for b0, b1 in zip(e0.blocks, e1.blocks):
         if b0["stage"] not in (2, 3):
@@ -74,6 +77,14 @@ def main():
     print("losses ps=0:", [round(v, 5) for v in e0.losses.tolist()])
     print("losses ps=1:", [round(v, 5) for v in e1.losses.tolist()])
     print("total", e0.total.item(), e1.total.item(), "rel", abs(e0.total.item() - e1.total.item()) / abs(e0.total.item()))
+    bad = []
+    for k in e0.grads:
+        g0, g1 = e0.grads[k].double().flatten(), e1.grads[k].double().flatten()
+        c = torch.nn.functional.cosine_similarity(g0, g1, dim=0).item()
+        r = (g1.norm() / (g0.norm() + 1e-30)).item()
+        if c < 0.999 or abs(r - 1) > 2e-2:
+            bad.append((k, round(c, 5), round(r, 4)))
+    print("gradient tensors with cosine < 0.999 or norm ratio off by > 2 %:", bad if bad else "none")
     gcos = torch.nn.functional.cosine_similarity(e0.gflat.double(), e1.gflat.double(), dim=0).item()
     print("flat gradient cosine ps=1 vs ps=0:", gcos, " worst block-tensor rel err:", worst)
     # timings: the stage ops of the forward
