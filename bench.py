@@ -193,9 +193,36 @@ def cpu_baseline(cfg, batches, steps, warm=3):
                        f"oracle/mpmae_ref.py (fwd+bwd+AdamW); value = batch {best['batch']}")
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _spawn_ranks(a):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
+    rendezvous on 127.0.0.1, like the reference's `torch.distributed.launch --nproc_per_node=N main_pretrain.py`,
+    /root/reference/TRAINING.md:18-42) and pass their exit code on. Fails loudly when the node has fewer GPUs."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:

@@ -99,7 +99,7 @@ def split_bwd_segments(bwd_ops):
     """Cut the backward launch list where each bucket becomes final. Returns 4 lists of ops."""
     names = [op[0] for op in bwd_ops]
     i0 = next(i for i, n in enumerate(names) if n.startswith("decoder_dict."))
-    i1 = next(i for i, n in enumerate(names) if n.startswith("encoder.stages.3."))
+    i1 = next(i for i, n in enumerate(names) if n.startswith(("encoder.stages.3.", "encoder.stages.3:")))
     i2 = next(i for i, n in enumerate(names) if n.startswith("encoder.downsample_layers.1"))
     assert 0 < i0 < i1 < i2 < len(names)
     assert not any(n.startswith(("head", "dloss")) for n in names[i0:]), "head gradients must be final before the decoder segment"
@@ -142,9 +142,12 @@ class StepRunner:
     overlap as well as real streams); "eager" is the Python loop over the C-ABI calls."""
 
     def __init__(self, engine, world_size=1, use_graph=True, lr=1e-4, weight_decay=0.05, mode=None, update_freq=1,
-                 allreduce_dtype=None, overlap="events"):
+                 allreduce_dtype=None, overlap="events", force_exchange=False):
         self.eng = engine
         self.world = world_size
+        # the bucketed gradient exchange runs when there is someone to exchange with - or on request at world size 1 (a process
+        # group of one rank: the RCCL path, its streams and the program's "bucket ready" events, exercised on a single GPU)
+        self.exchange = world_size > 1 or (bool(force_exchange) and dist.is_initialized())
         self.lr = lr
         self.wd = weight_decay
         self.t = 0                       # optimizer updates done (AdamW bias-correction step)
@@ -157,10 +160,10 @@ class StepRunner:
         if self.update_freq > 1 and (mode == "hipgraph" or (mode is None and use_graph)):
             raise ValueError("update_freq > 1 needs mode 'program' or 'eager'")
         self.graph_mode = "eager"
-        self.buckets = plan_buckets(engine.offsets, engine.n_params) if world_size > 1 else []
-        self.segments = split_bwd_segments(engine.bwd_ops) if world_size > 1 else [engine.bwd_ops]
+        self.buckets = plan_buckets(engine.offsets, engine.n_params) if self.exchange else []
+        self.segments = split_bwd_segments(engine.bwd_ops) if self.exchange else [engine.bwd_ops]
         self.comm_stream = (torch.cuda.Stream(device=engine.device)
-                            if world_size > 1 and engine.device.type == "cuda" else None)
+                            if self.exchange and engine.device.type == "cuda" else None)
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
         # optional low-precision exchange: one staging buffer per bucket in the wire dtype
         self.wire = ([torch.empty(hi - lo, dtype=allreduce_dtype, device=engine.device) for lo, hi in self.buckets]
@@ -173,13 +176,13 @@ class StepRunner:
             mode = "hipgraph" if use_graph else "eager"
         if mode == "program":
             self.prog, self.spans = engine.record_program(
-                engine.step_pieces(self.segments if world_size > 1 else None, weight_decay=weight_decay,
+                engine.step_pieces(self.segments if self.exchange else None, weight_decay=weight_decay,
                                    loss_scale=1.0 / self.update_freq))
             self.graph_mode = "program"
             # overlap "events" (default): the whole backward is ONE replay call and the communication stream waits for the
             # per-bucket "ready" events of the program; "segments": one replay call per bucket, each joining the side lane first
             self.bucket_signals = []
-            if world_size > 1 and overlap == "events" and self.comm_stream is not None:
+            if self.exchange and overlap == "events" and self.comm_stream is not None:
                 for keys in engine._bucket_keys:
                     sig = [engine._program_ids[k] for k in keys]
                     for i_ in sig:
@@ -230,7 +233,7 @@ class StepRunner:
                     fn()
                 graphs.append(g)
 
-            if self.world == 1:
+            if not self.exchange:
                 def whole():
                     self._fwd(); self._bwd_head(); self._bwd_seg(0); self._opt(note=False)
                 cap(whole)
@@ -295,7 +298,7 @@ class StepRunner:
 
     def _step_launches(self, first, last):
         eng = self.eng
-        if self.graphs and self.world == 1:
+        if self.graphs and not self.exchange:
             self.graphs[0].replay()
             eng.note_optimizer_launch()
             return
@@ -308,11 +311,11 @@ class StepRunner:
                 if i == 0:
                     self._fwd(); self._bwd_head(zero=first)
                 self._bwd_seg(i)
-            if last and self.world > 1:
+            if last and self.exchange:
                 self._launch_allreduce(i, works)
         if not last:
             return
-        if self.world > 1:
+        if self.exchange:
             # scalar loss all-reduce for logging (engine_pretrain.py:104), no host sync
             self.loss_buf.copy_(eng.total)
             works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
@@ -333,7 +336,7 @@ class StepRunner:
         eng = self.eng
         nseg = len(self.segments)
         FWD, ZERO, SEG0, OPT = 0, 1, 2, 2 + nseg
-        if self.world == 1 or not last:
+        if not self.exchange or not last:
             hi = OPT if last else OPT - 1
             if first:
                 eng.run_program(self.prog, self._span(FWD, hi))            # the whole micro-step in one call
@@ -390,6 +393,6 @@ class StepRunner:
         return int(self.eng.hp[5].item())
 
     def mean_loss(self) -> float:
-        if self.world == 1:
+        if not self.exchange:
             return float(self.eng.total.item())
         return float(self.loss_buf.item()) / self.world

@@ -217,6 +217,27 @@ def test_two_rank_step_driver_with_update_freq_2(tmp_path):
         assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
 
 
+def test_rccl_exchange_runs_at_world_size_one():
+    """The "nccl" backend (RCCL) on a one-rank process group drives the bucketed gradient exchange of StepRunner (program events ->
+    communication stream -> async all-reduce) in both drivers; gradients, parameters and the logged loss equal the no-exchange step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_world1_probe.py")], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    for mode in ("program", "eager"):
+        m = re.search(mode + r": RCCL world-1 exchange vs no exchange after 2 steps: gradients max rel ([0-9.e+-]+)", r.stdout)
+        assert m and float(m.group(1)) < 1e-5, r.stdout
+
+
+def test_bench_gpus_flag_starts_ranks_or_fails_loudly():
+    """`python bench.py --gpus N` outside a launcher spawns N ranks itself; on a node with fewer GPUs it must refuse (exit code 2 and
+    a message), not run one rank and print n_gpus: 1."""
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert r.returncode == 2 and f"--gpus {n + 1} requested but this node exposes {n} GPU" in r.stderr, (r.returncode, r.stderr[-500:])
+    assert "n_gpus" not in r.stdout
+
+
 def test_on_device_crop_matches_indexing_and_feeds_forward():
     """Input stage: 64x64 tiles from disk, aligned random 56x56 window per sample shared by all pixel-wise modalities
     (kornia RandomCrop, fcmae.py:419-434) cut by mpmae_crop into the engine's buffers - fp32 bands and int64 class maps - then the
