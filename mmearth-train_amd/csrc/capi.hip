@@ -504,7 +504,7 @@ static int launch_dw_band(const DwP& a, hipStream_t st) {
   static bool once = false;
   if (!once) {
     if (hipFuncSetAttribute((const void*)dwconv7_band_kernel<S, C, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS) != hipSuccess)
-      return launch_status();
+      return (int)hipGetLastError();      // (launch_status() only reports LAUNCH errors: it would return success without a launch)
     once = true;
   }
   LAUNCH((dwconv7_band_kernel<S, C, BR>), dim3(a.g.N, cdiv(a.g.grid, BR)), dim3(512), D::LDS, st, a);
@@ -919,7 +919,7 @@ static int launch_nt3_k(const GemmP& a, const Nt3Scales& sc, hipStream_t st) {
   static bool once = false;
   if (!once) {
     if (hipFuncSetAttribute((const void*)gemm_nt3_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return launch_status();
+      return (int)hipGetLastError();
     once = true;
   }
   dim3 g(cdiv(a.M, N3_BM), cdiv(a.N, N3_BN));

@@ -177,7 +177,10 @@ class StepRunner:
         if mode == "program":
             self.prog, self.spans = engine.record_program(
                 engine.step_pieces(self.segments if self.exchange else None, weight_decay=weight_decay,
-                                   loss_scale=1.0 / self.update_freq))
+                                   loss_scale=1.0 / self.update_freq,
+                                   # data parallel: the non-finite guard reads the ALL-REDUCED loss, so every rank skips (or applies) the
+                                   # same update; with a rank-local guard one rank skipped while the others applied NaN-poisoned gradients
+                                   guard_loss=self.loss_buf if self.exchange else None))
             self.graph_mode = "program"
             # overlap "events" (default): the whole backward is ONE replay call and the communication stream waits for the
             # per-bucket "ready" events of the program; "segments": one replay call per bucket, each joining the side lane first
@@ -206,7 +209,7 @@ class StepRunner:
         self.eng._run(self.segments[i], self.eng._stream())
 
     def _opt(self, note=True):
-        self.eng.launch_adamw(self.wd, note=note)
+        self.eng.launch_adamw(self.wd, note=note, guard_loss=self.loss_buf if self.exchange else None)
 
     def _capture(self):
         eng = self.eng

@@ -81,6 +81,8 @@ class Engine:
             k, v = kv.split("=")
             if k.strip() in _lib.OPT:           # upper-case names are library options (process-wide, mpmae_set_option)
                 _lib.check(self.lib.mpmae_set_option(_lib.OPT[k.strip()], int(v)), "set_option " + k)
+                if k.strip() in ("RSC_PF", "RSC_SMALL"):      # the engine plans around these two (grn_fold needs the staged GRN prologue)
+                    self.opt[k.strip().lower()] = int(v)
             else:
                 self.opt[k.strip()] = int(v)
         self.opt.update(options or {})
@@ -1166,7 +1168,9 @@ class Engine:
                 self._loss_tabs[kind] = (kind_id, tab, len(mods))
                 maxc = max(om.chans for om in mods)
                 if (kind == "pix_cont" and bool(self.opt["loss_rows"]) and cfg.img_size % 4 == 0 and (self.p * self.p) % 4 == 0
-                        and maxc * (self.p * cfg.img_size + 4) * 4 <= 150 * 1024):
+                        and maxc * (self.p * cfg.img_size + 4) * 4 <= 150 * 1024
+                        # the kernel's per-thread vector counts (loss_pix_cont_rows_impl: mv, mp <= 12), else mpmae_loss_multi
+                        and -(-(maxc * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(maxc * self.p * self.p // 4) // 64) <= 12):
                     # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
                     self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows, dt, _p(tab), len(mods), N, maxc,
                              self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
@@ -1501,7 +1505,10 @@ class Engine:
         lo, hi = self._segment_bounds()[which]
         ops = list(self.fwd_ops[lo:hi])
         if which != "encoder":
-            ops = [self.fwd_ops[0]] + ops                      # "prep": weight staging
+            # "prep" (weight staging) and, in fp8 mode, the MX weight quantisers - ON THE MAIN LANE here: in the full program prep runs
+            # on the side lane and only the stem GEMM waits for it, so a slice that starts at `proj` would race its own re-staging
+            pre = [op for op in self.fwd_ops[:lo] if op[0] == "prep" or op[0].startswith("prep:")]
+            ops = [(n_, f_, a_, dict(m_, lane=0, wait=(), signal=None)) for n_, f_, a_, m_ in pre] + ops
         if which == "loss":
             self.loss_acc.zero_()
         elif which == "encoder":
@@ -1528,7 +1535,7 @@ class Engine:
                 self.pred_img[:, c:c + om.head_out] = v.reshape(N, om.head_out)
 
     # ------------------------------------------------------------------ native launch programs
-    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0):
+    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
         runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
         [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
@@ -1562,7 +1569,8 @@ class Engine:
                 op[3]["signal"] = f"j{self._evseq}"
             joins.append(op[3]["signal"])
         opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                                 _p(self.hp), _p(self.total)), dict(lane=0, wait=tuple(joins), signal=None)),
+                                                 _p(self.hp), _p(guard_loss if guard_loss is not None else self.total)),
+                dict(lane=0, wait=tuple(joins), signal=None)),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
         # "bucket ready" points for a data-parallel runner that replays the whole backward as ONE call: per segment the keys of its last
@@ -1655,10 +1663,12 @@ class Engine:
             self._hp_ev[self._hp_n % self.HP_SLOTS] = ev
         self._hp_n += 1
 
-    def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, note=True):
+    def launch_adamw(self, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, note=True, guard_loss=None):
+        """guard_loss: the device scalar whose non-finiteness skips the update (default: this rank's loss; a data-parallel runner
+        passes the all-reduced loss so that every rank takes the same decision)."""
         st = self._stream()
         _lib.check(self.lib.mpmae_hp_fetch(C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                           _p(self.hp), _p(self.total), st), "hp_fetch")
+                                           _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), st), "hp_fetch")
         err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                    beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), st)
         _lib.check(err, "adamw")

@@ -257,7 +257,8 @@ class _FakeEngine:
     def set_hyper(self, lr, t, grad_scale=1.0):
         self._hp = (lr, t, grad_scale)
 
-    def launch_adamw(self, wd, note=True):
+    def launch_adamw(self, wd, note=True, guard_loss=None):
+        self.guard_loss = guard_loss                 # data parallel: the all-reduced loss buffer (same skip decision on every rank)
         self.log.append("adamw")
         self.pflat -= self._hp[0] * self._hp[2] * self.gflat
 

@@ -217,6 +217,29 @@ def test_two_rank_step_driver_with_update_freq_2(tmp_path):
         assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
 
 
+def test_forward_decoder_sees_weights_changed_after_forward_encoder():
+    """forward_decoder / forward_loss re-stage the weights ON THE MAIN LANE before their first GEMM (in the full program
+    the staging runs on the side lane and only the stem waits for it). Changing proj.weight between the encoder and the decoder
+    segment must change the predictions exactly as a fresh full forward with the new weights does."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    for dtype in ("bf16", "fp8"):
+        eng = _engine(cfg, c["N"], dtype, sd, inputs, noise)
+        eng.run_segment("encoder")
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            eng.params["proj.weight"].mul_(1.5)
+            eng.params["decoder_dict.sentinel2.0.pwconv1.weight"].mul_(0.5)
+        eng.run_segment("decoder")
+        torch.cuda.synchronize()
+        got = {k: v.float().clone() for k, v in eng.preds().items()}
+        eng.forward()                                   # full program with the changed weights
+        torch.cuda.synchronize()
+        for k, v in eng.preds().items():
+            assert _rel(got[k], v.float()) < (2e-2 if dtype == "bf16" else 4e-2), (dtype, k)
+
+
 def test_rccl_exchange_runs_at_world_size_one():
     """The "nccl" backend (RCCL) on a one-rank process group drives the bucketed gradient exchange of StepRunner (program events ->
     communication stream -> async all-reduce) in both drivers; gradients, parameters and the logged loss equal the no-exchange step."""
