@@ -322,7 +322,7 @@ enum MpmaeOption {
   MPMAE_OPT_TN,   /* default 2: weight-gradient kernel: 2 = transpose-read (ds_read_b64_tr_b16), 1 = register-transposing */
   MPMAE_OPT_TN_BLOCKS,   /* default 512: target workgroup count of a weight gradient (row splits) */
   MPMAE_OPT_TN_MINROWS,   /* default 256: minimum rows per split */
-  MPMAE_OPT_TN_BLOCKS_BIG,   /* default 256: target workgroup count when dW >= 64K elements */
+  MPMAE_OPT_TN_BLOCKS_BIG,   /* default 512: target workgroup count when dW >= 64K elements (two workgroups per CU: 4.53 -> 4.49 ms / step) */
   MPMAE_OPT_CS_SPLIT,   /* default 1: column-statistics kernel: split rows over workgroups */
   MPMAE_OPT_RSC_BLOCKS,   /* default 1536: target workgroup count of the wide row-streaming kernels */
   MPMAE_OPT_RSC_PF,   /* default 1: LDS-staged GRN vectors / early operand issue in the narrow row-streaming kernels */

@@ -111,7 +111,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_TN */ 2,
     /* MPMAE_OPT_TN_BLOCKS */ 512,
     /* MPMAE_OPT_TN_MINROWS */ 256,
-    /* MPMAE_OPT_TN_BLOCKS_BIG */ 256,
+    /* MPMAE_OPT_TN_BLOCKS_BIG */ 512,
     /* MPMAE_OPT_CS_SPLIT */ 1,
     /* MPMAE_OPT_RSC_BLOCKS */ 1536,
     /* MPMAE_OPT_RSC_PF */ 1,

@@ -49,7 +49,7 @@ ENGINE_OPTIONS = dict(
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
-    ps=1,                   # persistent per-sample stage kernels (ps.cuh) at (C, S) = (160, 2) / (320, 1): one launch per stage
+    ps=3,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage
     ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
@@ -668,7 +668,7 @@ class Engine:
         if not self.opt["ps"] or self.dt != BF16 or self.disable_rs or (self.block_mode_override or "mat") != "mat":
             return False
         Cc, S, depth = self.cfg.dims[stage], self.S[stage], self.cfg.depths[stage]
-        if (Cc, S) not in ((160, 2), (320, 1)) or depth > _lib.PS_MAXBLK:
+        if (Cc, S) not in ((160, 2), (320, 1)) or depth > _lib.PS_MAXBLK or not (int(self.opt["ps"]) >> (S - 1)) & 1:
             return False
         if self.keep * S * S > (80 if S == 2 else 32) or self.keep * S * S * Cc * 4 >= 65535:
             return False

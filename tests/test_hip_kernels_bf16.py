@@ -415,7 +415,7 @@ def _ps_pair(N, seed, ps_bwd=0):
     inputs["sentinel2"] = inputs["sentinel2"] * (~z)
     engs = []
     for ps in (0, 1):
-        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=ps, ps_bwd=ps_bwd if ps else 0))
+        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=3 * ps, ps_bwd=ps_bwd if ps else 0))
         e.load_state_dict(sd)
         e.set_inputs(inputs, noise)
         engs.append(e)

@@ -186,6 +186,43 @@ def test_full_batch_256_against_the_oracle(dtype):
             assert cs >= 0.99, (k, cs)
 
 
+@pytest.mark.parametrize("model,img,patch,subset,dtype", [("convnextv2_tiny", 112, 16, "all_mod", "bf16"),
+                                                          ("convnextv2_atto", 56, 8, "pix_mod", "fp8")])
+def test_configs_4_and_5_at_full_batch_256(model, img, patch, subset, dtype):
+    """BASELINE configs[3] (all_mod tiny 112/16) and configs[4] (pix_mod atto 56/8, MX-fp8 decoder GEMMs) at their stated per-GPU batch
+    of 256: LDS fits, workspace sizing and statistics over 311 296 rows at the real sizes. The CPU oracle needs minutes per step at
+    these sizes, so the checker is this library's exact-f32 engine (itself pinned to the oracle by the small cases and by
+    test_full_batch_256_against_the_oracle): same seeded weights / inputs / noise. Bounds = the stated bf16 bounds (x 1.5 for fp8):
+    masks bit-exact with exactly `keep` visible patches per row, per-modality loss 2e-2, total 1e-2, flat gradient cosine >= 0.999,
+    finite everywhere; a second run of the same step reproduces the losses to 2e-3 (LDS / global float atomics reorder sums)."""
+    from mmearth_train_amd import MODALITIES as MM
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg(model, img, patch, out_modalities=MM.subset(subset))
+    N = 256
+    sd = make_state_dict(cfg, seed=11)
+    inputs, noise = make_inputs(cfg, N, seed=12)
+    ref = _engine(cfg, N, "f32", sd, inputs, noise)
+    ref.forward(); ref.backward(); torch.cuda.synchronize()
+    ref_losses, ref_total, ref_g, ref_mask = ref.losses.clone(), ref.total.item(), ref.gflat.clone(), ref.mask.clone()
+    del ref
+    torch.cuda.empty_cache()
+    eng = _engine(cfg, N, dtype, sd, inputs, noise)
+    eng.forward(); eng.backward(); torch.cuda.synchronize()
+    assert eng.fp8 == (dtype == "fp8")
+    assert torch.equal(eng.mask, ref_mask)
+    assert torch.all((eng.mask == 0).sum(1) == eng.keep) and torch.all(eng.vis.view(N, eng.keep)[:, 1:] > eng.vis.view(N, eng.keep)[:, :-1])
+    f = 1.5 if dtype == "fp8" else 1.0
+    assert torch.isfinite(eng.losses).all() and torch.isfinite(eng.gflat).all()
+    assert torch.all((eng.losses - ref_losses).abs() <= 2e-2 * f * ref_losses.abs()), (eng.losses.tolist(), ref_losses.tolist())
+    assert abs(eng.total.item() - ref_total) <= 1e-2 * f * abs(ref_total)
+    cos = torch.nn.functional.cosine_similarity(eng.gflat.double(), ref_g.double(), dim=0).item()
+    assert cos >= (0.995 if dtype == "fp8" else 0.999), cos
+    first = eng.losses.clone()
+    eng.forward(); torch.cuda.synchronize()
+    assert torch.allclose(eng.losses, first, rtol=2e-3)
+
+
 def test_fp32_materialised_block_program_matches_oracle():
     """the 'mat' block program (materialised xn / z / dh, statistics in GEMM epilogues) in exact-f32 mode"""
     c = CASES["allmod_atto_56"]
