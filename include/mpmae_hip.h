@@ -260,6 +260,16 @@ int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* args, mpmae_stream
 int mpmae_crop(const void* src, void* dst, int elem_bytes, int N, int C, int H, int S, const int* ty, const int* tx,
                mpmae_stream_t stream);
 
+/* The same crop fused with the per-sample preparation of RAW tiles that the reference does on the host in
+ * MMEarthDataset.__getitem__ (mmearth_dataset.py:100-142): continuous modalities dst = (src == nodata ? NaN : (src - mean[c]) / std[c])
+ * as fp32 (src_type 0 = fp32, 1 = uint16, 2 = uint8 raw storage; nodata = MODALITIES.NO_DATA_VAL, NaN disables the test);
+ * class maps dst = lut256[src] as int64 (the table carries the label remap of :95-107 and -1 for no-data / unknown codes).
+ * ty / tx may both be NULL (no crop: H == S). */
+int mpmae_crop_norm(const void* src, int src_type, float* dst, int N, int C, int H, int S, const int* ty, const int* tx,
+                    const float* mean, const float* stdv, float nodata, mpmae_stream_t stream);
+int mpmae_crop_lut(const uint8_t* src, long long* dst, int N, int H, int S, const int* ty, const int* tx, const int* lut256,
+                   mpmae_stream_t stream);
+
 /* ---- masks / activity --------------------------------------------------------------------- */
 /* FCMAE.gen_random_mask (models/fcmae.py:214-231) on explicit noise [N,L]: mask f32 [N,L]
  * (1 = removed), vis [N,keep], inv [N,L]. */

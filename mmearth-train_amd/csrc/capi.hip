@@ -1369,6 +1369,23 @@ int mpmae_crop(const void* src, void* dst, int elem_bytes, int N, int C, int H, 
   RET();
 }
 
+int mpmae_crop_norm(const void* src, int src_type, float* dst, int N, int C, int H, int S, const int* ty, const int* tx,
+                    const float* mean, const float* stdv, float nodata, mpmae_stream_t s) {
+  if (!src || !dst || !mean || !stdv || N < 1 || C < 1 || S < 1 || H < S || ((ty == nullptr) != (tx == nullptr))) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)N * C * S * S, 256, 16384);
+  if (src_type == 0) LAUNCH(crop_norm_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)src, dst, N, C, H, S, ty, tx, mean, stdv, nodata);
+  else if (src_type == 1) LAUNCH(crop_norm_kernel<uint16_t>, dim3(g), dim3(256), 0, S_(s), (const uint16_t*)src, dst, N, C, H, S, ty, tx, mean, stdv, nodata);
+  else if (src_type == 2) LAUNCH(crop_norm_kernel<uint8_t>, dim3(g), dim3(256), 0, S_(s), (const uint8_t*)src, dst, N, C, H, S, ty, tx, mean, stdv, nodata);
+  else return (int)hipErrorInvalidValue;
+  RET();
+}
+
+int mpmae_crop_lut(const uint8_t* src, long long* dst, int N, int H, int S, const int* ty, const int* tx, const int* lut256, mpmae_stream_t s) {
+  if (!src || !dst || !lut256 || N < 1 || S < 1 || H < S || ((ty == nullptr) != (tx == nullptr))) return (int)hipErrorInvalidValue;
+  LAUNCH(crop_lut_kernel, dim3(grid1d((long long)N * S * S, 256, 16384)), dim3(256), 0, S_(s), src, dst, N, H, S, ty, tx, lut256);
+  RET();
+}
+
 int mpmae_quant_mx(const void* x, int ld, int rows, int K, void* q, uint32_t* scales, int lds, mpmae_stream_t s) {
   if (!x || !q || !scales || rows < 1 || K < 128 || (K % 128) || (ld & 7) || lds < rows || (((uintptr_t)x | (uintptr_t)q) & 15))
     return (int)hipErrorInvalidValue;

@@ -298,3 +298,34 @@ __global__ __launch_bounds__(256) void crop_kernel(const E* __restrict__ src, E*
     dst[i] = src[(nc * H + ty[n] + y) * H + tx[n] + x];
   }
 }
+
+
+// Input stage from RAW tiles (the per-sample work of MMEarthDataset.__getitem__, /root/reference/mmearth_dataset.py:100-142, fused into
+// the crop): no-data value -> NaN, per-band z-score, fp32 out:  dst[n,c,y,x] = src == nodata ? NaN : (src - mean[c]) / stdv[c].
+// SrcT = the storage type of the raw tile (uint16 Sentinel-2 digital numbers, uint8 canopy height, fp32 Sentinel-1 / ASTER);
+// a NaN `nodata` disables the no-data test (the float modalities use -inf, which equality handles).
+template <typename SrcT>
+__global__ __launch_bounds__(256) void crop_norm_kernel(const SrcT* __restrict__ src, float* __restrict__ dst, int N, int C, int H, int S,
+                                                        const int* __restrict__ ty, const int* __restrict__ tx,
+                                                        const float* __restrict__ mean, const float* __restrict__ stdv, float nodata) {
+  const long long total = (long long)N * C * S * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % S), y = (int)((i / S) % S);
+    const long long nc = i / ((long long)S * S);
+    const int n = (int)(nc / C), c = (int)(nc - (long long)n * C);
+    const int oy = ty ? ty[n] : 0, ox = tx ? tx[n] : 0;
+    const float v = (float)src[(nc * H + oy + y) * H + ox + x];
+    dst[i] = (v == nodata) ? __int_as_float(0x7fc00000) : (v - mean[c]) / stdv[c];
+  }
+}
+// class maps: dst[n,0,y,x] = lut[src] (int64; the table holds the label remap of the modality and -1 for no-data / unknown codes)
+__global__ __launch_bounds__(256) void crop_lut_kernel(const uint8_t* __restrict__ src, long long* __restrict__ dst, int N, int H, int S,
+                                                       const int* __restrict__ ty, const int* __restrict__ tx, const int* __restrict__ lut) {
+  const long long total = (long long)N * S * S;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % S), y = (int)((i / S) % S);
+    const int n = (int)(i / ((long long)S * S));
+    const int oy = ty ? ty[n] : 0, ox = tx ? tx[n] : 0;
+    dst[i] = (long long)lut[src[((long long)n * H + oy + y) * H + ox + x]];
+  }
+}

@@ -182,6 +182,12 @@ class StepRunner:
                                    # same update; with a rank-local guard one rank skipped while the others applied NaN-poisoned gradients
                                    guard_loss=self.loss_buf if self.exchange else None))
             self.graph_mode = "program"
+            # "inputs free" point of the step (Engine.set_inputs_async): exported so that a stream outside the program can wait for it
+            self.inputs_free_signal = None
+            key = getattr(engine, "_inputs_free_key", None)
+            if key and key in engine._program_ids and engine.device.type == "cuda":
+                self.inputs_free_signal = engine._program_ids[key]
+                _check(engine.lib.mpmae_program_export_signal(self.prog, self.inputs_free_signal), "program_export_signal")
             # overlap "events" (default): the whole backward is ONE replay call and the communication stream waits for the
             # per-bucket "ready" events of the program; "segments": one replay call per bucket, each joining the side lane first
             self.bucket_signals = []
@@ -290,6 +296,8 @@ class StepRunner:
         first = self.micro == 0                       # zero the gradient buffer
         last = self.micro == self.update_freq - 1     # exchange + AdamW
         self.micro = 0 if last else self.micro + 1
+        if hasattr(eng, "wait_inputs"):
+            eng.wait_inputs()                         # a pending asynchronous input stage (Engine.set_inputs_async)
         if last:
             self.t += 1
             eng.set_hyper(self.lr, self.t, grad_scale=1.0 / self.world)

@@ -1277,6 +1277,13 @@ class Engine:
                 self._op(b, f"dloss:{om.name}", lib.mpmae_loss_pix_cat, dt, 1, C.byref(a), N * L)
             else:
                 self._op(b, f"dloss:{om.name}", lib.mpmae_loss_img, dt, 1, C.byref(a))
+        # the last reader of the static input buffers (targets, mask noise -> mask): everything after it may overlap the next input stage
+        last_dl = max((i for i, op in enumerate(b) if op[0].startswith("dloss:")), default=None)
+        self._inputs_free_key = None
+        if last_dl is not None:
+            if b[last_dl][3]["signal"] is None:
+                b[last_dl][3]["signal"] = "inputs_free"
+            self._inputs_free_key = b[last_dl][3]["signal"]
         ldp = self.pred_pix.shape[1]
 
         def contiguous(mods, suffix):
@@ -1475,21 +1482,109 @@ class Engine:
         for st in streams[1:]:
             main.wait_stream(st)                   # join
 
-    def set_inputs(self, imgs_dict, noise, crop=None):
-        """Copy a batch and the mask noise into the engine's static device buffers. crop = (ty, tx): int32 device tensors
-        [N] of per-sample window origins - the pixel-wise modalities (larger tiles than img_size, resident on the device)
-        are cut at the same window by mpmae_crop straight into the static buffers (fcmae.py:419-434)."""
+    def set_inputs(self, imgs_dict, noise, crop=None, raw=None):
+        """Copy a batch and the mask noise into the engine's static device buffers (on the current stream). crop = (ty, tx): int32
+        device tensors [N] of per-sample window origins - the pixel-wise modalities (larger tiles than img_size, resident on the
+        device) are cut at the same window by mpmae_crop straight into the static buffers (fcmae.py:419-434).
+        raw: optional dict modality -> preparation of a RAW tile fused into the same pass (mmearth_dataset.py:100-142):
+        dict(mean=, std=, nodata=) for a continuous modality stored as fp32 / uint16 / uint8 (-> no-data to NaN, z-score, fp32), or
+        dict(lut=int32[256]) for a class map stored as uint8 (-> remapped int64 labels, -1 = no data). noise=None: drawn on the device."""
         S = self.cfg.img_size
+        st = self._stream()
+        raw = raw or {}
         for k, dst in self.inp.items():
             src = imgs_dict[k]
-            if crop is not None and src.dim() == 4 and src.shape[-1] != S:
+            ty, tx = (crop if (crop is not None and src.dim() == 4 and src.shape[-1] != S) else (None, None))
+            if k in raw:
+                src, r = src.contiguous(), raw[k]
+                assert src.device == dst.device and src.dim() == 4 and src.shape[:2] == dst.shape[:2] and (ty is not None or src.shape[-1] == S), k
+                if "lut" in r:
+                    assert src.dtype == torch.uint8 and dst.dtype == torch.int64 and r["lut"].dtype == torch.int32 and r["lut"].numel() == 256
+                    _lib.check(self.lib.mpmae_crop_lut(_p(src), _p(dst), src.shape[0], src.shape[-1], S, _p(ty), _p(tx), _p(r["lut"]), st), "crop_lut")
+                else:
+                    code = {torch.float32: 0, torch.uint16: 1, torch.uint8: 2}[src.dtype]
+                    _lib.check(self.lib.mpmae_crop_norm(_p(src), code, _p(dst), src.shape[0], src.shape[1], src.shape[-1], S, _p(ty), _p(tx),
+                                                        _p(r["mean"]), _p(r["std"]), float(r.get("nodata", float("nan"))), st), "crop_norm")
+            elif ty is not None:
                 src = src.contiguous()
                 assert src.device == dst.device and src.dtype == dst.dtype and src.shape[:2] == dst.shape[:2], k
                 _lib.check(self.lib.mpmae_crop(_p(src), _p(dst), src.element_size(), src.shape[0], src.shape[1], src.shape[-1], S,
-                                               _p(crop[0]), _p(crop[1]), self._stream()), "crop")
+                                               _p(ty), _p(tx), st), "crop")
             else:
                 dst.copy_(src.reshape(dst.shape), non_blocking=True)
-        self.noise.copy_(noise, non_blocking=True)
+        if noise is None:
+            self.noise.normal_()
+        else:
+            self.noise.copy_(noise, non_blocking=True)
+        if self.device.type == "cuda":
+            cur = torch.cuda.current_stream(self.device)
+            if cur != getattr(self, "_in_stream", None):      # an in-order stage on the caller's stream: a later asynchronous stage must not overtake it
+                pe = torch.cuda.Event()
+                pe.record(cur)
+                self._pre_step_ev = pe
+
+    def input_stage(self, runner=None):
+        """Context manager: everything enqueued inside runs on the engine's INPUT STREAM, ordered behind the running step's last reader
+        of the static input buffers (the loss-gradient launch at the head of the backward: the program's exported "inputs free" event)
+        - so host-to-device copies, crop-window draws, Engine.set_inputs and the mask noise of step k+1 overlap the remaining ~2.5 ms of
+        step k's backward with no second set of buffers. The next forward waits for the stage's event (wait_inputs, called by
+        StepRunner.step). Work the stage depends on must be issued INSIDE the context (tensors produced on the main stream just
+        before it are not ordered against the input stream)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            if self.device.type != "cuda":
+                yield
+                return
+            if not hasattr(self, "_in_stream"):
+                self._in_stream = torch.cuda.Stream(device=self.device)
+            main, ins = torch.cuda.current_stream(self.device), self._in_stream
+            prog = getattr(runner, "prog", None) if runner is not None else None
+            sig = getattr(runner, "inputs_free_signal", None) if runner is not None else None
+            if prog is not None and sig:
+                # the "inputs free" event of the most recent replay (a no-op before the first one), and never ahead of the main-stream
+                # position in front of that replay (an in-order set_inputs of an older batch)
+                if getattr(self, "_pre_step_ev", None) is not None:
+                    ins.wait_event(self._pre_step_ev)
+                _lib.check(self.lib.mpmae_program_stream_wait(prog, sig, C.c_void_p(ins.cuda_stream)), "program_stream_wait")
+            else:
+                ins.wait_stream(main)
+            if getattr(self, "_pre_step_ev", None) is not None:
+                ins.wait_event(self._pre_step_ev)
+            with torch.cuda.stream(ins):
+                yield
+                ev = torch.cuda.Event()
+                ev.record(ins)
+            self._inputs_ready_ev = ev
+        return ctx()
+
+    def set_inputs_async(self, imgs_dict, noise=None, crop=None, raw=None, runner=None):
+        """set_inputs inside input_stage(). Host tensors are copied to the device on the input stream; device tensors must already be
+        complete (resident batches) - produce fresh ones inside `with eng.input_stage(runner):` instead."""
+        with self.input_stage(runner):
+            if self.device.type == "cuda":
+                ins = self._in_stream
+                imgs_dict = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and not v.is_cuda else v)
+                             for k, v in imgs_dict.items()}
+                for t in list(imgs_dict.values()) + ([noise] if noise is not None else []) + (list(crop) if crop is not None else []):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(ins)
+            self.set_inputs(imgs_dict, noise, crop=crop, raw=raw)
+
+    def wait_inputs(self):
+        """Called in front of a forward: the main stream waits for a pending asynchronous input stage; marks the stream position in
+        front of the step for the NEXT stage."""
+        if self.device.type != "cuda":
+            return
+        ev = getattr(self, "_inputs_ready_ev", None)
+        main = torch.cuda.current_stream(self.device)
+        if ev is not None:
+            main.wait_event(ev)
+            self._inputs_ready_ev = None
+        pe = torch.cuda.Event()
+        pe.record(main)
+        self._pre_step_ev = pe
 
     # ------------------------------------------------------------------ forward segments (FCMAE.forward_encoder / _decoder / _loss)
     def _segment_bounds(self):

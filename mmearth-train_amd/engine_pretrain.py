@@ -52,16 +52,19 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
         optimizer.zero_grad()
     for it, samples in enumerate(data_loader):
         lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args) if it % update_freq == 0 else None
-        samples = {k: v.to(device, non_blocking=True) for k, v in samples.items()}
         if runner is not None:
             if lr is not None:
                 runner.lr = lr
             eng = runner.eng
-            noise = torch.randn(eng.N, eng.L, device=device)
-            eng.set_inputs(samples, noise, crop=model._crop_windows(samples))
+            # input stage of this batch on its own stream, overlapped with the previous step's backward: host-to-device copies, the
+            # crop windows, crop / copy into the engine's buffers and the mask noise are all issued inside the stage
+            with eng.input_stage(runner):
+                samples = {k: v.to(device, non_blocking=True) for k, v in samples.items()}
+                eng.set_inputs(samples, None, crop=model._crop_windows(samples))
             runner.step()
             losses_t, total_t = eng.losses, eng.total
         else:
+            samples = {k: v.to(device, non_blocking=True) for k, v in samples.items()}
             loss, pred, mask, loss_dict_, log_vars, normalized = model(samples, mask_ratio=args.mask_ratio)
             if not math.isfinite(float(loss.item())):
                 print("Loss is {}, stopping training".format(float(loss.item())))

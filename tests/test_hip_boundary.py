@@ -305,3 +305,85 @@ def test_on_device_crop_matches_indexing_and_feeds_forward():
     (oloss, _, omask, _, _, _), _, _ = _oracle(cfg, sd, cropped, model._engine.noise.cpu())
     assert torch.equal(mask.cpu(), omask)
     assert abs(loss.item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+
+
+def test_raw_tile_preparation_fused_into_the_crop_matches_torch():
+    """mpmae_crop_norm / mpmae_crop_lut (the per-sample work of MMEarthDataset.__getitem__, /root/reference/mmearth_dataset.py:100-142,
+    fused into the aligned crop): no-data -> NaN, per-band z-score, label remap + -1, against torch indexing on the same raw tiles."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.engine import Engine
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg()
+    N, H, S = 5, 64, 56
+    eng = Engine(cfg, N, dtype="bf16", device="cuda:0")
+    eng.load_state_dict(make_state_dict(cfg, seed=2))
+    g = torch.Generator().manual_seed(9)
+    inputs, noise = make_inputs(cfg, N, seed=3)
+    s2 = torch.randint(0, 12000, (N, 12, H, H), generator=g).to(torch.uint16)          # digital numbers, 0 = no data
+    s2[:, :, :3, :5] = 0
+    s1 = torch.randn(N, 8, H, H, generator=g)
+    s1[:, 2:4] = float("-inf")                                                          # missing orbit
+    ch = torch.randint(0, 256, (N, 2, H, H), generator=g).to(torch.uint8)               # 255 = no data
+    esa = torch.tensor([0, 10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100, 255], dtype=torch.uint8)[torch.randint(0, 13, (N, 1, H, H), generator=g)]
+    lut = torch.full((256,), -1, dtype=torch.int32)
+    for new, old in enumerate([10, 20, 30, 40, 50, 60, 70, 80, 90, 95, 100]):
+        lut[old] = new
+    raw_in = dict(inputs)
+    raw_in.update(sentinel2=s2, sentinel1=s1, canopy_height_eth=ch, esa_worldcover=esa)
+    for k in ("aster", "dynamic_world"):
+        big = torch.zeros(N, inputs[k].shape[1], H, H, dtype=inputs[k].dtype)
+        big[:, :, 4:4 + S, 4:4 + S] = inputs[k]
+        raw_in[k] = big
+    dev = {k: v.cuda() for k, v in raw_in.items()}
+    stats = {k: (torch.rand(c, generator=g) * 100 + 1, torch.rand(c, generator=g) * 50 + 1) for k, c in (("sentinel2", 12), ("sentinel1", 8), ("canopy_height_eth", 2))}
+    raw = {k: dict(mean=m.cuda(), std=sd_.cuda(), nodata=nd) for (k, (m, sd_)), nd in zip(stats.items(), (0.0, float("-inf"), 255.0))}
+    raw["esa_worldcover"] = dict(lut=lut.cuda())
+    ty = torch.randint(0, H - S + 1, (N,), generator=g, dtype=torch.int32)
+    tx = torch.randint(0, H - S + 1, (N,), generator=g, dtype=torch.int32)
+    eng.set_inputs_async(dev, noise.cuda(), crop=(ty.cuda(), tx.cuda()), raw=raw)
+    eng.wait_inputs()
+    torch.cuda.synchronize()
+    for k in ("sentinel2", "sentinel1", "canopy_height_eth"):
+        m, sd_ = stats[k]
+        src = raw_in[k].float()
+        want = torch.stack([src[n, :, ty[n]:ty[n] + S, tx[n]:tx[n] + S] for n in range(N)])
+        nod = want == {"sentinel2": 0.0, "sentinel1": float("-inf"), "canopy_height_eth": 255.0}[k]
+        want = (want - m[None, :, None, None]) / sd_[None, :, None, None]
+        want[nod] = float("nan")
+        got = eng.inp[k].cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(want)), k
+        assert torch.allclose(torch.nan_to_num(got), torch.nan_to_num(want), rtol=1e-6, atol=1e-6), k
+    want = torch.stack([lut[raw_in["esa_worldcover"][n, :, ty[n]:ty[n] + S, tx[n]:tx[n] + S].long()] for n in range(N)]).long()
+    assert torch.equal(eng.inp["esa_worldcover"].cpu(), want)
+    want = torch.stack([raw_in["aster"][n, :, ty[n]:ty[n] + S, tx[n]:tx[n] + S] for n in range(N)])
+    assert torch.equal(eng.inp["aster"].cpu(), want)
+    eng.forward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.total).all()
+
+
+def test_asynchronous_input_stage_equals_the_in_order_one():
+    """Engine.set_inputs_async (input stream behind the running step's last reader of the input buffers, next forward waits for its
+    event) over several steps with a DIFFERENT batch each: parameters equal the run that stages every batch on the main stream."""
+    from mmearth_train_amd import dist as mdist
+    from mmearth_train_amd.synth import make_inputs
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    batches = [tuple(make_inputs(cfg, c["N"], seed=40 + i)) for i in range(4)]
+    dev = [({k: v.cuda() for k, v in b.items()}, nz.cuda()) for b, nz in batches]
+    out = []
+    for use_async in (False, True):
+        eng = _engine(cfg, c["N"], "f32", sd, inputs, noise)
+        run = mdist.StepRunner(eng, world_size=1, lr=1e-3, mode="program")
+        assert run.inputs_free_signal
+        for b, nz in dev:
+            if use_async:
+                eng.set_inputs_async(b, nz, runner=run)
+            else:
+                eng.set_inputs(b, nz)
+            run.step()
+        torch.cuda.synchronize()
+        out.append((eng.pflat.clone(), eng.total.item()))
+    r_, dl_ = _rel(out[1][0], out[0][0]), abs(out[1][1] - out[0][1]) / abs(out[0][1])
+    assert r_ < 2e-5 and dl_ < 2e-5, (r_, dl_)      # (float atomics reorder the fp32 statistics from run to run: 1e-7 per step)
