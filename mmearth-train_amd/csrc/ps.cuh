@@ -84,7 +84,10 @@ template <int C, int S> struct Cfg {
   static constexpr int NCHK = (RP + NRG_ - 1) / NRG_;                  // rows per thread of the element-wise passes
   static_assert(ZOFF + SS * C * 4 <= HA_B && ZOFF + SS * C * 4 < 65536, "XF alias + zero patch");
   static_assert(LDS <= 160 * 1024, "LDS");
-  static constexpr int CP = C / 2, NPG = NTHR / CP;                    // depthwise: channel pairs x patch groups
+  static constexpr int CP = C / 2;                                     // depthwise work items (patch, channel pair): a wave owns whole
+  static constexpr int NFG = CP / 64, CPF = NFG * 64, CPR = CP - CPF;  // patches for the first CPF pairs (wave-uniform neighbour skip) and
+  static constexpr int PPR = CPR ? 64 / CPR : 1;                       // passes of PPR patches x CPR pairs for the remaining CPR pairs
+  static_assert(8 % NFG == 0 && (CPR == 0 || 64 % CPR == 0), "depthwise item mapping");
   static constexpr int NCC = H / 8, NRG = NTHR / NCC;                  // z pass: 8-column chunks x row groups
 };
 
@@ -297,28 +300,42 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lg = lane >> 4;
 
     PS_STAMP(0);
-    // ---- P1: depthwise 7x7 (XF -> XA), thread = (channel pair, patch group)
+    // ---- P1: depthwise 7x7 (XF -> XA). Items = (patch, 64 channel pairs), dealt round-robin over the 8 waves: the first keep * NFG
+    // items cover pairs [0, CPF) of ONE patch each (masked neighbours are skipped by the whole wave), the rest cover the remaining CPR
+    // pairs of PPR patches at a time.
     {
-      const int cp = tid % K::CP, pg = tid / K::CP;
-      if (pg < K::NPG) {
-        f32x2_t w[49];
-#pragma unroll
-        for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cp);   // t = ky*7 + kx -> (kw*7 + kh)*C
-        const f32x2_t bias = *reinterpret_cast<const f32x2_t*>(B.dw_b + 2 * cp);
+      const int nU = keep * K::NFG, nT = nU + (K::CPR ? (keep + K::PPR - 1) / K::PPR : 0);
+      auto run_items = [&](int i0, int i1, bool rem, const f32x2_t (&w)[49], const f32x2_t bias) {
+        const int cp = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
 #pragma unroll 1
-        for (int k = pg; k < keep; k += K::NPG) {
+        for (int i = i0; i < i1; i += 8) {
+          const int kk = rem ? (i - nU) * K::PPR + lane / (K::CPR ? K::CPR : 1) : i / K::NFG;
+          const bool on = kk < keep;
+          const int k = on ? kk : keep - 1;
           f32x2_t acc[4];
 #pragma unroll
           for (int o = 0; o < 4; ++o) acc[o] = bias;
           dw_gather<C, S, 0>(smem, acc, k, cp, w);
+          if (on) {
 #pragma unroll
-          for (int o = 0; o < SS; ++o) {
-            const int row = k * SS + o;
-            const bool lv = live[row] != 0;
-            *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = lv ? f2bf2(acc[o].x, acc[o].y) : 0u;
+            for (int o = 0; o < SS; ++o) {
+              const int row = k * SS + o;
+              const bool lv = live[row] != 0;
+              *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = lv ? f2bf2(acc[o].x, acc[o].y) : 0u;
+            }
           }
         }
-      }
+      };
+      auto run_set = [&](int i0, int i1, bool rem) {      // (requesting the first weight set one block ahead moved its wait into pw2: no gain)
+        const int cpS = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
+        f32x2_t w[49];
+#pragma unroll
+        for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cpS);   // t = ky*7 + kx -> (kw*7 + kh)*C
+        run_items(i0, i1, rem, w, *reinterpret_cast<const f32x2_t*>(B.dw_b + 2 * cpS));
+      };
+      if (wave < nU) run_set(wave, nU, false);
+      const int r0 = nU + ((wave - nU % 8) + 8) % 8;        // this wave's first remainder item (items continue round-robin behind the uniform ones)
+      if (r0 < nT) run_set(r0, nT, true);
     }
     // LayerNorm vectors and pw1's first weight slabs: requested before the barrier in front of the LayerNorm phase
     constexpr int NCH = C / 8, NI = (NCH + 15) / 16;
@@ -868,32 +885,41 @@ __global__ __launch_bounds__(512) void ps_bwd_kernel(const MpmaePsBwdArgs a) {
     __syncthreads();
 
     PS_STAMP(5);
-    // ---- B6: dx = depthwise^T(dd) + dout (XA in place: the next block's dout), thread = (channel pair, patch group)
+    // ---- B6: dx = depthwise^T(dd) + dout (XA in place: the next block's dout); items as in the forward
     {
-      const int cp = tid % K::CP, pg = tid / K::CP;
-      if (pg < K::NPG) {
+      const int nU = keep * K::NFG, nT = nU + (K::CPR ? (keep + K::PPR - 1) / K::PPR : 0);
+      T* dxg = reinterpret_cast<T*>(B.dx) + rowbase * C;
+      auto run_items = [&](int i0, int i1, bool rem) {
+        const int cp = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
         f32x2_t w[49];
 #pragma unroll
         for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cp);
-        T* dxg = reinterpret_cast<T*>(B.dx) + rowbase * C;
 #pragma unroll 1
-        for (int k = pg; k < keep; k += K::NPG) {
+        for (int i = i0; i < i1; i += 8) {
+          const int kk = rem ? (i - nU) * K::PPR + lane / (K::CPR ? K::CPR : 1) : i / K::NFG;
+          const bool on = kk < keep;
+          const int k = on ? kk : keep - 1;
           f32x2_t acc[4];
 #pragma unroll
           for (int o = 0; o < 4; ++o) acc[o] = (f32x2_t){0.f, 0.f};
           dw_gather<C, S, 1>(smem, acc, k, cp, w);
+          if (on) {
 #pragma unroll
-          for (int o = 0; o < SS; ++o) {
-            const int row = k * SS + o;
-            const bool lv = live[row] != 0;
-            const unsigned dr = *reinterpret_cast<const unsigned*>(XA + row * LDX + 2 * cp);
-            const float d0 = __uint_as_float(dr << 16), d1 = __uint_as_float(dr & 0xffff0000u);
-            const unsigned pk = lv ? f2bf2(acc[o].x + d0, acc[o].y + d1) : 0u;
-            *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = pk;
-            *reinterpret_cast<unsigned*>(dxg + (size_t)row * C + 2 * cp) = pk;
+            for (int o = 0; o < SS; ++o) {
+              const int row = k * SS + o;
+              const bool lv = live[row] != 0;
+              const unsigned dr = *reinterpret_cast<const unsigned*>(XA + row * LDX + 2 * cp);
+              const float d0 = __uint_as_float(dr << 16), d1 = __uint_as_float(dr & 0xffff0000u);
+              const unsigned pk = lv ? f2bf2(acc[o].x + d0, acc[o].y + d1) : 0u;
+              *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = pk;
+              *reinterpret_cast<unsigned*>(dxg + (size_t)row * C + 2 * cp) = pk;
+            }
           }
         }
-      }
+      };
+      if (wave < nU) run_items(wave, nU, false);
+      const int r0 = nU + ((wave - nU % 8) + 8) % 8;
+      if (r0 < nT) run_items(r0, nT, true);
     }
     __syncthreads();
     PS_STAMP(6);
