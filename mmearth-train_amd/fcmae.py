@@ -85,6 +85,23 @@ class _StepFn(torch.autograd.Function):
         return (None, None) + outs
 
 
+class _PieceOutput(torch.autograd.Function):
+    """Marks the outputs of forward_encoder / forward_decoder / forward_loss: they are computed by the engine's forward segments and
+    are NOT connected to the fused backward. In the reference (models/fcmae.py:242-412) chaining the three pieces and calling
+    loss.backward() trains the model; here that chain must not silently produce no gradients, so its backward raises."""
+
+    @staticmethod
+    def forward(ctx, t, anchor, what):
+        ctx.what = what
+        return t.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        raise RuntimeError(f"FCMAE.{ctx.what}: the outputs of forward_encoder / forward_decoder / forward_loss are not connected to "
+                           "the fused backward (they would silently yield no gradients); call model(imgs_dict, mask_ratio=...) "
+                           "and loss.backward() on ITS loss to train")
+
+
 class FCMAE(nn.Module):
     """Fully Convolutional Masked Autoencoder with ConvNeXtV2 backbone (MP-MAE), HIP engine."""
 
@@ -252,7 +269,7 @@ class FCMAE(nn.Module):
         eng.noise.copy_(torch.randn(N, self.cfg.num_patches, device=self._device))
         eng.run_segment("encoder")
         x = eng.dense_map(eng.enc_out, self.cfg.dims[-1], 3).to(torch.float32)
-        return x, eng.mask.clone()
+        return self._piece(x, "forward_encoder"), eng.mask.clone()
 
     def forward_decoder(self, x: Tensor, mask: Tensor):
         """x [N, dims[-1], h, w], mask [N, L] (0 keep / 1 remove) -> dict modality -> prediction (fcmae.py:249-265).
@@ -269,7 +286,7 @@ class FCMAE(nn.Module):
         eng.enc_out.copy_(torch.gather(rows, 1, vis[:, :, None].expand(-1, -1, rows.shape[-1]))
                           .reshape(eng.enc_out.shape).to(eng.enc_out.dtype))
         eng.run_segment("decoder")
-        return OrderedDict((k, v.to(torch.float32).clone()) for k, v in eng.preds().items())
+        return OrderedDict((k, self._piece(v.to(torch.float32), "forward_decoder")) for k, v in eng.preds().items())
 
     def forward_loss(self, imgs_dict: Dict[AnyStr, Tensor], preds: Dict[AnyStr, Tensor], mask: Tensor):
         """-> (loss, loss_dict, log_vars, normalized_loss_list)  (fcmae.py:267-412)"""
@@ -282,7 +299,13 @@ class FCMAE(nn.Module):
                 dst.copy_(imgs_dict[k].reshape(dst.shape), non_blocking=True)
         eng.set_preds(preds)
         eng.run_segment("loss")
-        return self._loss_outputs(eng, eng.total.clone().reshape(()))
+        return self._loss_outputs(eng, self._piece(eng.total.clone().reshape(()), "forward_loss"))
+
+    def _piece(self, t, what):
+        """Output of a forward piece: a tensor whose backward RAISES (see _PieceOutput) when autograd is recording, else t itself."""
+        if not torch.is_grad_enabled():
+            return t
+        return _PieceOutput.apply(t.detach(), self._plist[0], what)
 
     def _loss_outputs(self, eng, loss):
         losses = eng.losses.clone()

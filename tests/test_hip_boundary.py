@@ -217,6 +217,29 @@ def test_two_rank_step_driver_with_update_freq_2(tmp_path):
         assert re.search(mode + r" ranks equal: True", r.stdout), r.stdout
 
 
+def test_chained_forward_pieces_refuse_backward_instead_of_yielding_no_gradients():
+    """/root/reference/models/fcmae.py:242-412: forward_encoder -> forward_decoder -> forward_loss -> loss.backward() trains the
+    reference model. The fused path runs those pieces as forward segments only: backward through them must RAISE (they
+    used to return detached tensors, i.e. silently no gradients); forward() is the trainable entry point."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    model = _module(cfg, sd)
+    dev = {k: v.cuda() for k, v in inputs.items()}
+    x, mask = model.forward_encoder(dev["sentinel2"].clone(), 0.6)
+    preds = model.forward_decoder(x, mask)
+    loss, loss_dict, log_vars, weighted = model.forward_loss(dev, preds, mask)
+    assert loss.requires_grad and torch.isfinite(loss)
+    with pytest.raises(RuntimeError, match="not connected to the fused backward"):
+        loss.backward()
+    with torch.no_grad():                      # inference use of the pieces is unchanged
+        x2, _ = model.forward_encoder(dev["sentinel2"].clone(), 0.6)
+    assert not x2.requires_grad
+    loss2 = model({k: v.clone() for k, v in dev.items()}, mask_ratio=0.6)[0]
+    loss2.backward()
+    assert model.proj.weight.grad is not None and model.proj.weight.grad.abs().sum() > 0
+
+
 def test_forward_decoder_sees_weights_changed_after_forward_encoder():
     """forward_decoder / forward_loss re-stage the weights ON THE MAIN LANE before their first GEMM (in the full program
     the staging runs on the side lane and only the stem waits for it). Changing proj.weight between the encoder and the decoder
