@@ -438,8 +438,9 @@ int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, f
 /* ---- optimizer (main_pretrain.py:312-320; helpers.py:509-526) ------------------------------ */
 /* hp (device, 8 floats) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale, skip, skipped_steps, -, -}:
  * when skip != 0 mpmae_adamw leaves p / m / v untouched (non-finite loss, engine_pretrain.py:83-85). */
+/* gnorm2 (may be NULL): += sum g^2 of the gradients this launch read (helpers.get_grad_norm_, :509-526, without a pass of its own). */
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
-                float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask,
+                float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
                 mpmae_stream_t stream);
 int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
 /* hyper-parameter hand-over for replayed steps: copies record (*counter % slots) of a pinned,
@@ -447,8 +448,16 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
  * increments *counter, in stream order (the host fills slot t % slots before enqueueing step t and
  * must not run more than `slots` steps ahead). `total` (may be NULL) is the step's loss on the device:
  * a non-finite value sets hp[4] (skip this update) and increments hp[5]. */
+/* meters (host pointer, may be NULL / ring == NULL): device-resident MetricLogger state updated by the same launch - record number
+ * `count` of ring [window][2T + 2] = {T losses, T weighted losses, total, gradient norm}, running sums [2T + 2] and the count in
+ * sums[2T + 2] (helpers.SmoothedValue, :49-109; engine_pretrain.py:71-113). The gradient norm of an update is sqrt(gnorm2) x
+ * grad_scale as accumulated by mpmae_adamw; it is written into that update's record by the NEXT fetch, which also clears gnorm2. */
+typedef struct MpmaeMeters {
+  const float* losses; const float* weighted; int T;
+  float* ring; int window; float* sums; float* gnorm2;
+} MpmaeMeters;
 int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total,
-                   mpmae_stream_t stream);
+                   const MpmaeMeters* meters, mpmae_stream_t stream);
 
 /* ---- launch programs ----------------------------------------------------------------------
  * The reference drives its step from Python (engine_pretrain.py:46-118, one autograd graph per

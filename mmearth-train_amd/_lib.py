@@ -137,6 +137,11 @@ class PsBwdArgs(C.Structure):
                 ("sync", c_void_p), ("ln_slab", c_void_p), ("blk", PsBwdBlock * PS_MAXBLK)]
 
 
+class Meters(C.Structure):
+    _fields_ = [("losses", c_void_p), ("weighted", c_void_p), ("T", c_int), ("ring", c_void_p), ("window", c_int),
+                ("sums", c_void_p), ("gnorm2", c_void_p)]
+
+
 class StemTailArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("xhat1", c_void_p), ("rstd1", c_void_p), ("xhat2", c_void_p), ("rstd2", c_void_p),
                 ("out", c_void_p), ("g1", c_void_p), ("b1", c_void_p), ("w", c_void_p), ("wb", c_void_p),
@@ -199,7 +204,7 @@ SYMBOLS = {
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
-                    c_size_t, c_void_p, c_void_p],
+                    c_size_t, c_void_p, c_void_p, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
     "mpmae_ln_fwd_down": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
                           c_void_p, c_void_p],
@@ -209,7 +214,7 @@ SYMBOLS = {
                       c_void_p],
     "mpmae_strided_add": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_stem_tail": [c_int, c_int, P(StemTailArgs), c_void_p],
-    "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, P(Meters), c_void_p],
     "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],
     "mpmae_program_end": [c_void_p],
     "mpmae_program_num_ops": [c_void_p],

@@ -829,9 +829,9 @@ int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, f
 }
 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
-                float wd, size_t n, const uint8_t* decay, mpmae_stream_t s) {
+                float wd, size_t n, const uint8_t* decay, float* gnorm2, mpmae_stream_t s) {
   LAUNCH(adamw_kernel, dim3(grid1d((long long)n, 256, 4096)), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2,
-                     eps, wd, n, decay);
+                     eps, wd, n, decay, gnorm2);
   RET();
 }
 
@@ -1574,9 +1574,15 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
   return launch_status();
 }
 
-int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total, mpmae_stream_t s) {
+int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total, const MpmaeMeters* meters,
+                   mpmae_stream_t s) {
   if (!ring_pinned || slots < 1 || !counter || !hp) return (int)hipErrorInvalidValue;
-  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp, total);
+  MeterP mt{nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr};
+  if (meters && meters->ring) {
+    if (!meters->losses || !meters->sums || !meters->gnorm2 || meters->T < 1 || meters->window < 1) return (int)hipErrorInvalidValue;
+    mt = MeterP{meters->losses, meters->weighted, meters->T, meters->ring, meters->window, meters->sums, meters->gnorm2};
+  }
+  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp, total, mt);
   RET();
 }
 

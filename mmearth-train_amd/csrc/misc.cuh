@@ -123,10 +123,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     const float* __restrict__ hp, float beta1, float beta2,
                                                     float eps, float wd, size_t n,
-                                                    const uint8_t* __restrict__ decay) {
+                                                    const uint8_t* __restrict__ decay, float* __restrict__ gnorm2) {
   if (hp[4] != 0.f) return;      // non-finite loss this step (hp_fetch): the update is skipped, p / m / v stay intact
   const float lr = hp[0], ibc1 = hp[1], isbc2 = hp[2], gs = hp[3];
+  float gsq = 0.f;               // sum g^2 (unscaled): the global gradient norm rides in the pass that reads every gradient anyway
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    gsq += g[i] * g[i];
     const float gi = g[i] * gs;
     float pi = p[i];
     if (decay[i]) pi *= (1.f - lr * wd);
@@ -135,6 +137,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     m[i] = mi; v[i] = vi;
     const float denom = sqrtf(vi) * isbc2 + eps;
     p[i] = pi - lr * ibc1 * mi / denom;
+  }
+  if (gnorm2) {
+    gsq = wave_sum(gsq);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(gnorm2, gsq);
   }
 }
 
@@ -210,9 +216,32 @@ __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ ds
 // ring; this kernel (one per optimizer step, in stream order) copies the slot its device-side
 // counter points at into `hp` and advances the counter. A plain async H2D copy would read the
 // pinned record when the copy EXECUTES, by which time a host running ahead has overwritten it.
+// Meters (optional, `mt.ring != nullptr`): the device-resident form of the reference's MetricLogger / SmoothedValue(window 20)
+// (/root/reference/helpers.py:49-109,111-206, engine_pretrain.py:71-113): record t of a ring [window][2T + 2] = {T losses, T weighted
+// losses, total loss, gradient norm} plus running sums [2T + 2] and a count, written here at no extra launch; the gradient norm of a
+// step is accumulated by adamw_kernel (sum g^2 of the exchanged gradients) and lands in ITS record at the next fetch. The host reads
+// ring + sums with one copy per print, ranks fold their sums with one all-reduce per epoch.
+struct MeterP { const float* losses; const float* weighted; int T; float* ring; int window; float* sums; float* gnorm2; };
 __global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
-                                const float* __restrict__ total) {
+                                const float* __restrict__ total, const MeterP mt) {
   const int c = *counter;
+  const float gs_prev = hp[3];
+  __syncthreads();
+  if (mt.ring) {
+    const int W = 2 * mt.T + 2, cnt = (int)mt.sums[W];
+    if (threadIdx.x == 0 && cnt > 0) {                     // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526)
+      const float gn = sqrtf(mt.gnorm2[0]) * gs_prev;
+      mt.ring[(size_t)((cnt - 1) % mt.window) * W + W - 1] = gn;
+      mt.sums[W - 1] += gn;
+    }
+    for (int i = threadIdx.x; i < W - 1; i += blockDim.x) {
+      const float v = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : (total ? *total : 0.f);
+      mt.ring[(size_t)(cnt % mt.window) * W + i] = v;
+      mt.sums[i] += v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { mt.gnorm2[0] = 0.f; mt.sums[W] = (float)(cnt + 1); }
+  }
   if (threadIdx.x < 4) hp[threadIdx.x] = ring[(size_t)(c % R) * 4 + threadIdx.x];
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -180,6 +180,11 @@ class Engine:
         self._hp_n = 0                              # optimizer launches enqueued so far
         self._hp_ev = [None] * self.HP_SLOTS
         self.gnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        # device-resident meters (reference MetricLogger / SmoothedValue(window_size=20), helpers.py:49-206): written by mpmae_hp_fetch
+        T = len(self.cfg.out_mods)
+        self.METER_WINDOW = 20
+        self.meter_ring = torch.zeros(self.METER_WINDOW, 2 * T + 2, dtype=torch.float32, device=dev)
+        self.meter_sums = torch.zeros(2 * T + 3, dtype=torch.float32, device=dev)      # running sums [2T + 2] + count
 
     def load_state_dict(self, sd):
         """sd: reference-layout state dict (aliases of the shared decoder block are accepted)."""
@@ -1630,6 +1635,55 @@ class Engine:
                 self.pred_img[:, c:c + om.head_out] = v.reshape(N, om.head_out)
 
     # ------------------------------------------------------------------ native launch programs
+    def _meters(self):
+        if not hasattr(self, "_meters_rec"):
+            m = _lib.Meters()
+            m.losses, m.T = self.losses.data_ptr(), len(self.cfg.out_mods)
+            m.weighted = self.weighted.data_ptr() if self.cfg.loss_aggr == "uncertainty" else 0
+            m.ring, m.window, m.sums, m.gnorm2 = self.meter_ring.data_ptr(), self.METER_WINDOW, self.meter_sums.data_ptr(), self.gnorm2.data_ptr()
+            self._meters_rec = m
+        return C.byref(self._meters_rec)
+
+    def reset_meters(self):
+        """New epoch: the reference builds a fresh MetricLogger per epoch (engine_pretrain.py:34)."""
+        self.meter_ring.zero_()
+        self.meter_sums.zero_()
+
+    def meter_global_averages(self):
+        """Per-epoch statistics, synchronised between the ranks with ONE all-reduce of the running sums
+        (MetricLogger.synchronize_between_processes, helpers.py:66-77,134-136): dict column -> global average over all ranks' updates."""
+        import torch.distributed as tdist
+        sums = self.meter_sums.clone()
+        T = len(self.cfg.out_mods)
+        sums[2 * T + 1] = sums[2 * T + 1] + torch.sqrt(self.gnorm2[0]) * self.hp[3]      # the last update's norm has not been fetched yet
+        if tdist.is_initialized() and tdist.get_world_size() > 1:
+            tdist.all_reduce(sums)
+        sums = sums.cpu()
+        cnt = max(float(sums[-1]), 1.0)
+        names = [om.name for om in self.cfg.out_mods]
+        cols = [f"loss_{n}" for n in names] + [f"weighted_{n}" for n in names] + ["loss", "grad_norm"]
+        return {c: float(sums[i]) / cnt for i, c in enumerate(cols)}
+
+    def read_meters(self):
+        """ONE device-to-host copy: dict name -> dict(value, median, avg (both over the last <= 20 updates), global_avg) for every
+        per-modality loss, its uncertainty-weighted form, the total loss and the gradient norm (reference SmoothedValue properties)."""
+        T, W = len(self.cfg.out_mods), self.METER_WINDOW
+        buf = torch.cat([self.meter_ring.reshape(-1), self.meter_sums]).cpu()
+        ring, sums = buf[:W * (2 * T + 2)].view(W, 2 * T + 2), buf[W * (2 * T + 2):]
+        cnt = int(sums[-1].item())
+        names = [om.name for om in self.cfg.out_mods]
+        cols = [f"loss_{n}" for n in names] + [f"weighted_{n}" for n in names] + ["loss", "grad_norm"]
+        out = {"count": cnt}
+        for i, c in enumerate(cols):
+            n = cnt - 1 if c == "grad_norm" else cnt          # the norm of the latest update lands with the next fetch
+            if n <= 0:
+                continue
+            k = min(n, W)
+            idx = [(n - 1 - j) % W for j in range(k)]
+            win = ring[idx, i]
+            out[c] = dict(value=float(win[0]), median=float(win.median()), avg=float(win.mean()), global_avg=float(sums[i]) / n)
+        return out
+
     def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
         runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
@@ -1664,10 +1718,10 @@ class Engine:
                 op[3]["signal"] = f"j{self._evseq}"
             joins.append(op[3]["signal"])
         opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                                 _p(self.hp), _p(guard_loss if guard_loss is not None else self.total)),
+                                                 _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), self._meters()),
                 dict(lane=0, wait=tuple(joins), signal=None)),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
-                                           beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask)), m0)]
+                                           beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), _p(self.gnorm2)), m0)]
         # "bucket ready" points for a data-parallel runner that replays the whole backward as ONE call: per segment the keys of its last
         # main-lane op and of the last side-lane op seen so far (in-order lanes: they imply everything before them)
         self._bucket_keys = []
@@ -1763,17 +1817,19 @@ class Engine:
         passes the all-reduced loss so that every rank takes the same decision)."""
         st = self._stream()
         _lib.check(self.lib.mpmae_hp_fetch(C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                           _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), st), "hp_fetch")
+                                           _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), self._meters(), st), "hp_fetch")
         err = self.lib.mpmae_adamw(_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
-                                   beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), st)
+                                   beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), _p(self.gnorm2), st)
         _lib.check(err, "adamw")
         if note:
             self.note_optimizer_launch()
 
     def grad_norm(self):
-        self.gnorm2.zero_()
-        _lib.check(self.lib.mpmae_sumsq(_p(self.gflat), self.n_params, _p(self.gnorm2), self._stream()), "sumsq")
-        return self.gnorm2.sqrt()
+        """Global L2 norm of the flat gradient buffer NOW (a pass of its own: mpmae_sumsq). The training loop does not call this - the
+        norm of every update rides in the AdamW launch and is read through read_meters()["grad_norm"]."""
+        t = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mpmae_sumsq(_p(self.gflat), self.n_params, _p(t), self._stream()), "sumsq")
+        return t.sqrt()
 
     # ------------------------------------------------------------------ results (reference shapes)
     def preds(self):

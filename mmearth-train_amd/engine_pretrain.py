@@ -50,6 +50,8 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
     loss_value, loss_dict, log_vars, normalized = float("nan"), {}, None, None
     if optimizer is not None:
         optimizer.zero_grad()
+    if runner is not None:
+        runner.eng.reset_meters()          # device-resident SmoothedValue(window 20) meters, written by the optimizer launch itself
     for it, samples in enumerate(data_loader):
         lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args) if it % update_freq == 0 else None
         if runner is not None:
@@ -75,8 +77,26 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
                 optimizer.step()
                 optimizer.zero_grad()
             losses_t, total_t = model._engine.losses, loss.detach()
-        if it % print_freq == 0 or it == n_iter - 1:
-            loss_value = float(total_t.item())           # the only host sync of the fused loop
+        if runner is not None and (it % print_freq == 0 or it == n_iter - 1):
+            # the only host sync of the fused loop: ONE copy of the meter ring (loss, 12 per-modality losses, their weighted forms, the
+            # gradient norm; median / window average / global average as in MetricLogger.log_every, helpers.py:147-206)
+            m = runner.eng.read_meters()
+            if "loss" in m:
+                loss_value = m["loss"]["value"]
+                if not math.isfinite(loss_value) or runner.skipped_steps() > 0:
+                    print("Loss is {}, stopping training".format(loss_value))
+                    sys.exit(1)
+                names = [om.name for om in model.cfg.out_mods]
+                loss_dict = {n: m[f"loss_{n}"]["value"] for n in names}
+                if model.cfg.loss_aggr == "uncertainty":
+                    log_vars = model.loss_fn.log_vars.tolist()
+                    normalized = torch.tensor([m[f"weighted_{n}"]["value"] for n in names])
+                gn = m.get("grad_norm")
+                print(f"Epoch: [{epoch}]  [{it}/{n_iter}]  loss: {m['loss']['median']:.4f} ({m['loss']['global_avg']:.4f})  "
+                      + (f"grad_norm: {gn['median']:.4f} ({gn['global_avg']:.4f})  " if gn else "")
+                      + f"img/s: {(it + 1) * samples['sentinel2'].shape[0] / (time.time() - t0):.0f}", flush=True)
+        elif runner is None and (it % print_freq == 0 or it == n_iter - 1):
+            loss_value = float(total_t.item())
             if not math.isfinite(loss_value) or (runner is not None and runner.skipped_steps() > 0):
                 print("Loss is {}, stopping training".format(loss_value))
                 sys.exit(1)
@@ -88,4 +108,12 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
             mean = mdist.mean_scalar(loss_value)
             print(f"Epoch: [{epoch}]  [{it}/{n_iter}]  loss: {mean:.4f}  "
                   f"img/s: {(it + 1) * samples['sentinel2'].shape[0] / (time.time() - t0):.0f}", flush=True)
+    if runner is not None:
+        # "Averaged stats" of the epoch, one fused all-reduce across the ranks (engine_pretrain.py:115-118)
+        g = runner.eng.meter_global_averages()
+        names = [om.name for om in model.cfg.out_mods]
+        loss_dict = {n: g[f"loss_{n}"] for n in names}
+        if model.cfg.loss_aggr == "uncertainty":
+            normalized = torch.tensor([g[f"weighted_{n}"] for n in names])
+        return {"loss": g["loss"], "grad_norm": g["grad_norm"], "loss_last": loss_value}, loss_dict, log_vars, normalized
     return {"loss": loss_value}, loss_dict, log_vars, normalized

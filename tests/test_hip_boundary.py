@@ -410,3 +410,39 @@ def test_asynchronous_input_stage_equals_the_in_order_one():
         out.append((eng.pflat.clone(), eng.total.item()))
     r_, dl_ = _rel(out[1][0], out[0][0]), abs(out[1][1] - out[0][1]) / abs(out[0][1])
     assert r_ < 2e-5 and dl_ < 2e-5, (r_, dl_)      # (float atomics reorder the fp32 statistics from run to run: 1e-7 per step)
+
+
+@pytest.mark.parametrize("mode", ["program", "eager"])
+def test_device_meters_match_host_recomputation(mode):
+    """the MetricLogger / SmoothedValue(window 20) statistics of /root/reference/helpers.py:49-206 kept on the device
+    (written by the optimizer launch: mpmae_hp_fetch; gradient norm accumulated inside mpmae_adamw, helpers.get_grad_norm_ :509-526)
+    against a host recomputation from per-step read-backs: value / median / window average / global average of the total loss,
+    every per-modality loss, its uncertainty-weighted form and the global gradient norm, over more steps than the window holds."""
+    from mmearth_train_amd import dist as mdist
+    from mmearth_train_amd.synth import make_inputs
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], "f32", sd, inputs, noise)
+    run = mdist.StepRunner(eng, world_size=1, lr=2e-4, mode=mode)
+    eng.reset_meters()
+    hist = []
+    for i in range(27):
+        b, nz = make_inputs(cfg, c["N"], seed=300 + i)
+        eng.set_inputs(b, nz)
+        run.step()
+        hist.append((eng.total.item(), eng.losses.cpu().clone(), eng.weighted.cpu().clone(), eng.grad_norm().item()))
+    m = eng.read_meters()
+    assert m["count"] == 27
+    tot = torch.tensor([h[0] for h in hist]); gn = torch.tensor([h[3] for h in hist])
+    for name, series, n in (("loss", tot, 27), ("grad_norm", gn[:26], 26),
+                            ("loss_sentinel1", torch.stack([h[1] for h in hist])[:, 1], 27),
+                            ("weighted_esa_worldcover", torch.stack([h[2] for h in hist])[:, 11], 27)):
+        win = series[max(0, n - 20):n]
+        got = m[name]
+        assert abs(got["value"] - series[n - 1].item()) <= 1e-5 * abs(series[n - 1].item()), name
+        assert abs(got["median"] - win.median().item()) <= 1e-5 * abs(win.median().item()), name
+        assert abs(got["avg"] - win.mean().item()) <= 1e-5 * abs(win.mean().item()), name
+        assert abs(got["global_avg"] - series[:n].mean().item()) <= 1e-4 * abs(series[:n].mean().item()), name
+    g = eng.meter_global_averages()           # per-epoch form: includes the last update's norm, one (here trivial) cross-rank fold
+    assert abs(g["grad_norm"] - gn.mean().item()) <= 1e-4 * gn.mean().item() and abs(g["loss"] - tot.mean().item()) <= 1e-4 * tot.mean().item()
