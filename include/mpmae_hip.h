@@ -341,6 +341,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40 */
   MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80 */
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
+  MPMAE_OPT_TN3_BLOCKS,   /* default 256: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);
@@ -438,7 +439,8 @@ int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, f
 /* ---- optimizer (main_pretrain.py:312-320; helpers.py:509-526) ------------------------------ */
 /* hp (device, 8 floats) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale, skip, skipped_steps, -, -}:
  * when skip != 0 mpmae_adamw leaves p / m / v untouched (non-finite loss, engine_pretrain.py:83-85). */
-/* gnorm2 (may be NULL): += sum g^2 of the gradients this launch read (helpers.get_grad_norm_, :509-526, without a pass of its own). */
+/* gnorm2 (may be NULL; 1 + 4096 floats): {number of partials, one partial sum of g^2 per workgroup} of the gradients this launch read
+ * (helpers.get_grad_norm_, :509-526, without a pass of its own and without atomics); folded by the next mpmae_hp_fetch. */
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
                 float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
                 mpmae_stream_t stream);
@@ -450,8 +452,8 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
  * a non-finite value sets hp[4] (skip this update) and increments hp[5]. */
 /* meters (host pointer, may be NULL / ring == NULL): device-resident MetricLogger state updated by the same launch - record number
  * `count` of ring [window][2T + 2] = {T losses, T weighted losses, total, gradient norm}, running sums [2T + 2] and the count in
- * sums[2T + 2] (helpers.SmoothedValue, :49-109; engine_pretrain.py:71-113). The gradient norm of an update is sqrt(gnorm2) x
- * grad_scale as accumulated by mpmae_adamw; it is written into that update's record by the NEXT fetch, which also clears gnorm2. */
+ * sums[2T + 2] (helpers.SmoothedValue, :49-109; engine_pretrain.py:71-113). The gradient norm of an update is sqrt(sum of the
+ * partials mpmae_adamw left in gnorm2) x grad_scale; it is written into that update's record by the NEXT fetch, which clears gnorm2[0]. */
 typedef struct MpmaeMeters {
   const float* losses; const float* weighted; int T;
   float* ring; int window; float* sums; float* gnorm2;

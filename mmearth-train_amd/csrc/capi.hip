@@ -17,6 +17,7 @@
 #include "gemm_nt3.cuh"
 #include "dwband.cuh"
 #include "ps.cuh"
+#include "gemm_tn3.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -120,6 +121,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC_N40 */ 2,
     /* MPMAE_OPT_RSC_N80 */ 1,
     /* MPMAE_OPT_STB_BLOCKS */ 512,
+    /* MPMAE_OPT_TN3_BLOCKS */ 256,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -977,10 +979,44 @@ static bool tn2_ok(const WgradP& a) {
   return WX >= 32;
 }
 
+// decoder / head shapes: DMA ring + 128 x 256 tiles (gemm_tn3.cuh); one workgroup per CU (144 KB of LDS)
+static int launch_wgrad_tn3(WgradP a, bool swap, hipStream_t st) {
+  const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
+  const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
+  const int tiles = (WX / TN3_BX) * (WY / TN3_BY);
+  int splits = g_opt[MPMAE_OPT_TN3_BLOCKS] / tiles;
+  if (tiles * 8 <= g_opt[MPMAE_OPT_TN3_BLOCKS] && splits < 8) splits = 8;      // one row range per XCD
+  if (splits > a.M / (4 * TN3_SL)) splits = a.M / (4 * TN3_SL);
+  if (splits > (int)(a.ws_floats / per)) splits = (int)(a.ws_floats / per);
+  if (splits < 1) splits = 1;
+  const int rps = cdiv(cdiv(a.M, splits), TN3_SL) * TN3_SL;
+  a.rows_per_split = rps;
+  splits = cdiv(a.M, rps);
+  static bool attr[2] = {false, false};
+  if (!attr[swap]) {
+    const void* f = swap ? (const void*)gemm_tn3_kernel<true> : (const void*)gemm_tn3_kernel<false>;
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TN3_LDS) != hipSuccess) return (int)hipGetLastError();
+    attr[swap] = true;
+  }
+  dim3 g(splits, WX / TN3_BX, WY / TN3_BY);        // split fastest: one row range per XCD when splits == 8 (gemm_tn3.cuh)
+  if (swap) LAUNCH((gemm_tn3_kernel<true>), g, dim3(256), TN3_LDS, st, a, splits);
+  else LAUNCH((gemm_tn3_kernel<false>), g, dim3(256), TN3_LDS, st, a, splits);
+  const int nk = a.Nn * a.Kk;
+  if (a.sn == a.Kk && a.sk == 1) {
+    launch_reduce(3, a.ws, splits, nk + a.Nn, a.dW, a.db, nk, 0, 0, 0, st);
+  } else {
+    launch_reduce(1, a.ws, splits, nk + a.Nn, a.dW, nullptr, a.Kk, a.sn, a.sk, nk, st);
+    if (a.db) launch_reduce(3, a.ws, splits, nk + a.Nn, nullptr, a.db, nk, 1, 0, 0, st);
+  }
+  return launch_status();
+}
+
 static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   const bool swap = a.Kk < a.Nn;
   const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
+  if (g_opt[MPMAE_OPT_TN3_BLOCKS] > 0 && WX >= 256 && WX % TN3_BX == 0 && WY % TN3_BY == 0 && a.M % TN3_SL == 0 && a.M >= 16 * TN3_SL)
+    return launch_wgrad_tn3(a, swap, st);
   int nt, kt;
   if (WX <= 48) { nt = 3; kt = 3; }
   else if (WX % 80 == 0) { nt = 5; kt = 5; }

@@ -138,9 +138,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float denom = sqrtf(vi) * isbc2 + eps;
     p[i] = pi - lr * ibc1 * mi / denom;
   }
-  if (gnorm2) {
+  if (gnorm2) {                  // one partial per workgroup (plain store: 16 k same-address atomics cost 0.2 ms); hp_fetch_kernel folds them
+    __shared__ float gred[4];
     gsq = wave_sum(gsq);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(gnorm2, gsq);
+    if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gsq;
+    __syncthreads();
+    if (threadIdx.x == 0) gnorm2[1 + blockIdx.x] = gred[0] + gred[1] + gred[2] + gred[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0) gnorm2[0] = (float)gridDim.x;
   }
 }
 
@@ -229,10 +233,16 @@ __global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __re
   __syncthreads();
   if (mt.ring) {
     const int W = 2 * mt.T + 2, cnt = (int)mt.sums[W];
-    if (threadIdx.x == 0 && cnt > 0) {                     // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526)
-      const float gn = sqrtf(mt.gnorm2[0]) * gs_prev;
-      mt.ring[(size_t)((cnt - 1) % mt.window) * W + W - 1] = gn;
-      mt.sums[W - 1] += gn;
+    if (cnt > 0) {                                         // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526):
+      const int nb = (int)mt.gnorm2[0];                    // gnorm2 = {partial count, per-workgroup sums of g^2 written by adamw_kernel}
+      float t = 0.f;
+      for (int i = threadIdx.x; i < nb; i += blockDim.x) t += mt.gnorm2[1 + i];
+      t = wave_sum(t);
+      if (threadIdx.x == 0) {
+        const float gn = sqrtf(t) * gs_prev;
+        mt.ring[(size_t)((cnt - 1) % mt.window) * W + W - 1] = gn;
+        mt.sums[W - 1] += gn;
+      }
     }
     for (int i = threadIdx.x; i < W - 1; i += blockDim.x) {
       const float v = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : (total ? *total : 0.f);
@@ -240,7 +250,7 @@ __global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __re
       mt.sums[i] += v;
     }
     __syncthreads();
-    if (threadIdx.x == 0) { mt.gnorm2[0] = 0.f; mt.sums[W] = (float)(cnt + 1); }
+    if (threadIdx.x == 0) { mt.gnorm2[0] = 0.f; mt.sums[W] = (float)(cnt + 1); }      // (partial count 0: a skipped update leaves no norm)
   }
   if (threadIdx.x < 4) hp[threadIdx.x] = ring[(size_t)(c % R) * 4 + threadIdx.x];
   __syncthreads();

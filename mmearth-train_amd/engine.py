@@ -179,7 +179,7 @@ class Engine:
         self.hp_counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self._hp_n = 0                              # optimizer launches enqueued so far
         self._hp_ev = [None] * self.HP_SLOTS
-        self.gnorm2 = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.gnorm2 = torch.zeros(1 + 4096, dtype=torch.float32, device=dev)      # {count, per-workgroup sums of g^2} written by mpmae_adamw (<= 4096 workgroups)
         # device-resident meters (reference MetricLogger / SmoothedValue(window_size=20), helpers.py:49-206): written by mpmae_hp_fetch
         T = len(self.cfg.out_mods)
         self.METER_WINDOW = 20
@@ -1655,7 +1655,8 @@ class Engine:
         import torch.distributed as tdist
         sums = self.meter_sums.clone()
         T = len(self.cfg.out_mods)
-        sums[2 * T + 1] = sums[2 * T + 1] + torch.sqrt(self.gnorm2[0]) * self.hp[3]      # the last update's norm has not been fetched yet
+        nb = int(self.gnorm2[0].item())
+        sums[2 * T + 1] = sums[2 * T + 1] + torch.sqrt(self.gnorm2[1:1 + nb].sum()) * self.hp[3]      # the last update's norm has not been fetched yet
         if tdist.is_initialized() and tdist.get_world_size() > 1:
             tdist.all_reduce(sums)
         sums = sums.cpu()

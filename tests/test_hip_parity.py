@@ -260,7 +260,10 @@ def test_adamw_step_matches_oracle():
 
 
 @pytest.mark.parametrize("M,N,K", [(4864, 40, 160), (4864, 160, 40), (3001, 80, 320), (2048, 640, 160), (777, 320, 1280),
-                                   (1500, 2048, 512), (33, 160, 40), (1000, 24, 512), (640, 8, 512)])
+                                   (1500, 2048, 512), (33, 160, 40), (1000, 24, 512), (640, 8, 512),
+                                   # the DMA-ring kernel of the decoder / head shapes (gemm_tn3.cuh): both operand orders, the stated
+                                   # head shape, a row count that leaves uneven splits
+                                   (12544, 2816, 512), (1024, 512, 2048), (2048, 2048, 512), (4032, 768, 512)])
 def test_weight_gradient_kernel_matches_fp32_matmul(M, N, K):
     """mpmae_wgrad in bf16 (transpose-read MFMA kernel, its register-transposing fallback for
     narrow / unaligned operands, split slabs + second-stage reduce) against torch fp32 on the same
