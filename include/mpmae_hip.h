@@ -336,10 +336,10 @@ enum MpmaeOption {
   MPMAE_OPT_CS_SPLIT,   /* default 1: column-statistics kernel: split rows over workgroups */
   MPMAE_OPT_RSC_BLOCKS,   /* default 1536: target workgroup count of the wide row-streaming kernels */
   MPMAE_OPT_RSC_PF,   /* default 1: LDS-staged GRN vectors / early operand issue in the narrow row-streaming kernels */
-  MPMAE_OPT_RSC_NC32,   /* default 1: 32-column weight chunks at C = 160 */
+  MPMAE_OPT_RSC_NC32,   /* (retired in round 3: 32-column weight chunks at C = 160 are the only variant; the value is ignored) */
   MPMAE_OPT_RSC_SMALL,   /* default 1: chunked row-streaming kernels at C = 40 / 80 too */
-  MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40 */
-  MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80 */
+  MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40: 1 = two row tiles per wave, otherwise one */
+  MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80: 0 = two row tiles per wave, otherwise one */
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
   MPMAE_OPT_TN3_BLOCKS,   /* default 256: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2) */
   MPMAE_OPT_COUNT_

@@ -1285,25 +1285,20 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
 
 int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
-  if (a->C == 160 && a->H == 640) {
-    const int nc32 = g_opt[MPMAE_OPT_RSC_NC32];     // 32-column chunks: the N range splits 4 ways (measured 27.7 -> 24.1 us)
-    if (nc32) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));
-    return launch_rsc<160, 1, 64, 64>(which, *a, S_(s));
-  }
+  if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));      // 32-column chunks: the N range splits 4 ways (27.7 -> 24.1 us vs 64)
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
   const int small = g_opt[MPMAE_OPT_RSC_SMALL];      // 0: keep the LDS-resident-weights kernels for which 0-3
   if (which > 3 || (small && which < 2)) {
     const int v40 = g_opt[MPMAE_OPT_RSC_N40], v80 = g_opt[MPMAE_OPT_RSC_N80];
+    // (variants without the staged-vector prologue - no folded GRN finalisation, no operand recomputation - were removed in round 3:
+    // the engine's program needs both, and nothing tested them)
     if (a->C == 40 && a->H == 160) {
       if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2, 6>(which, *a, S_(s));
-      if (v40 == 2) return launch_rsc<40, 4, 160, 32, 1, 6>(which, *a, S_(s));
-      if (v40 == 3) return launch_rsc<40, 4, 160, 160, 1>(which, *a, S_(s));
-      return launch_rsc<40, 4, 160, 160, 2>(which, *a, S_(s));
+      return launch_rsc<40, 4, 160, 32, 1, 6>(which, *a, S_(s));
     }
     if (a->C == 80 && a->H == 320) {
-      if (v80 == 1) return launch_rsc<80, 2, 64, 64, 1, 6>(which, *a, S_(s));
-      if (v80 == 2) return launch_rsc<80, 2, 64, 32, 1>(which, *a, S_(s));
-      return launch_rsc<80, 2, 64, 64, 2, 6>(which, *a, S_(s));
+      if (v80 == 0) return launch_rsc<80, 2, 64, 64, 2, 6>(which, *a, S_(s));
+      return launch_rsc<80, 2, 64, 64, 1, 6>(which, *a, S_(s));
     }
   }
   if (which > 3 || (a->M & 15)) return (int)hipErrorInvalidValue;

@@ -70,16 +70,6 @@ __global__ __launch_bounds__(256) void activity_pool_kernel(const uint8_t* __res
 // ---------------------------------------------------------------------------------
 typedef MpmaePrepDesc PrepDesc;
 
-template <typename T>
-__global__ __launch_bounds__(256) void prep_kernel(const PrepDesc* __restrict__ table) {
-  const PrepDesc d = table[blockIdx.y];
-  const size_t total = (size_t)d.rows * d.cols;
-  T* dst = reinterpret_cast<T*>(d.dst);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int r = i / d.cols, c = i - (size_t)r * d.cols;
-    stf<T>(dst + (size_t)r * d.dst_ld + c, d.src[(size_t)r * d.sr + (size_t)c * d.sc]);
-  }
-}
 
 // Tiled form: a workgroup moves one 64x64 tile through LDS so that the fp32 reads run along
 // whichever source dimension is contiguous (plain copies: columns; transposed copies W^T: rows) and

@@ -214,45 +214,6 @@ __global__ __launch_bounds__(256) void ln_bwd_v2_kernel(const T* __restrict__ dy
     ws[(size_t)blockIdx.x * 2 * C + i] = ln2_comb[i] + ln2_comb[2 * C + i] + ln2_comb[4 * C + i] + ln2_comb[6 * C + i];
 }
 
-// column statistics v2: each wave owns a slab of rows and ALL columns in 16-byte vectors
-//   mode 0: s0[j] = sum gelu(h)^2 ; mode 1: s0[j] = sum dz, s1[j] = sum dz*gelu(h)
-// grid.x = row slabs (one wave each, 4 per block), partial slab ws[(slab)*(mode+1)*H ...]
-template <typename T>
-__global__ __launch_bounds__(256) void colstats_v2_kernel(const T* __restrict__ h, const T* __restrict__ dz, int mode,
-                                                          float* __restrict__ out0, float* __restrict__ out1,
-                                                          int M, int H, int rows_per_wave) {
-  const int lane = threadIdx.x & 63;
-  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int mb = wave_global * rows_per_wave, me = min(M, mb + rows_per_wave);
-  const int nvec = H / 8;
-  if (mb >= M) return;
-  for (int v0 = lane; v0 < nvec; v0 += 64) {
-    float a0[8], a1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
-    for (int m = mb; m < me; ++m) {
-      float hv[8];
-      ld8<T>(h + (size_t)m * H + v0 * 8, hv);
-      if (mode == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float g = gelu_t<T>(hv[e]); a0[e] += g * g; }
-      } else {
-        float d[8];
-        ld8<T>(dz + (size_t)m * H + v0 * 8, d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { a0[e] += d[e]; a1[e] += d[e] * gelu_t<T>(hv[e]); }
-      }
-    }
-    float* o0 = out0 + (size_t)wave_global * H + v0 * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o0[e] = a0[e];
-    if (mode == 1) {
-      float* o1 = out1 + (size_t)wave_global * H + v0 * 8;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o1[e] = a1[e];
-    }
-  }
-}
 
 // column statistics v3: one 256-thread block per slab of `rows_per_block` rows (= one statistics
 // group in grouped mode); wave w takes rows w, w+4, ...; lanes own 16-byte column vectors

@@ -456,3 +456,56 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N, ps_bwd):
         g0, g1 = e0.grads[k].double().flatten(), e1.grads[k].double().flatten()
         c = torch.nn.functional.cosine_similarity(g0, g1, dim=0).item()
         assert c > 0.995 and abs((g1.norm() / (g0.norm() + 1e-30)).item() - 1) < 5e-2, (k, c)
+
+
+@pytest.mark.parametrize("opts", ["DW=6", "DW=5", "DW=4", "DW=3", "TN=1", "TN3_BLOCKS=0", "RSC_SMALL=0", "RSC_PF=0,RSC_SMALL=0",
+                                  "RSC_N40=1,RSC_N80=0", "NT_GLDS=0", "NT_GLDS64=0,NT_BK32=0", "CS_SPLIT=0", "DWW=6",
+                                  # engine (launch-program) options: lower-case names go to Engine(options=...)
+                                  "stem_fused=0", "stem_im2col=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "grouped_epi=1",
+                                  "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
+                                  "img_side=0,prep_side=0", "wgrad_late=0", "hr_maxc=80", "ring=2,dz_ring=2"])
+def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
+    """Every kernel generation still in the library is reachable through mpmae_set_option (include/mpmae_hip.h): a full bf16 step with
+    the option set against the step on the default kernels - same losses (1e-2: bf16 rounding points differ between generations) and
+    gradients (flat cosine >= 0.9995, every tensor >= 0.99). Options are process-wide: restored afterwards."""
+    from mmearth_train_amd import _lib
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.engine import Engine
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    lib = _lib.load()
+    cfg = make_cfg()
+    N = 4
+    sd = make_state_dict(cfg, seed=61)
+    inputs, noise = make_inputs(cfg, N, seed=62)
+
+    def run(engine_opts):
+        e = Engine(cfg, N, dtype="bf16", device=DEV, options=engine_opts)
+        e.load_state_dict(sd)
+        e.set_inputs(inputs, noise)
+        e.forward(); e.backward()
+        torch.cuda.synchronize()
+        return e.losses.clone(), e.gflat.clone(), {k: v.clone() for k, v in e.grads.items()}
+
+    eopts = dict(ps=0)                      # the per-block kernels are the ones the options select between
+    ref = run(eopts)
+    saved = {}
+    try:
+        for kv in opts.split(","):
+            k, v = kv.split("=")
+            if k not in _lib.OPT:
+                eopts = dict(eopts, **{k: int(v)})
+                continue
+            saved[k] = lib.mpmae_get_option(_lib.OPT[k])
+            assert lib.mpmae_set_option(_lib.OPT[k], int(v)) == 0
+            if k in ("RSC_PF", "RSC_SMALL"):
+                eopts = dict(eopts, **{k.lower(): int(v)})       # the engine plans around these two (ADVICE r2)
+        got = run(eopts)
+    finally:
+        for k, v in saved.items():
+            lib.mpmae_set_option(_lib.OPT[k], v)
+    assert torch.allclose(got[0], ref[0], rtol=1e-2), (opts, got[0].tolist(), ref[0].tolist())
+    assert torch.nn.functional.cosine_similarity(got[1].double(), ref[1].double(), dim=0).item() >= 0.9995
+    for k in ref[2]:
+        a, b = got[2][k].double().flatten(), ref[2][k].double().flatten()
+        if b.numel() >= 8 and b.norm() > 0:
+            assert torch.nn.functional.cosine_similarity(a, b, dim=0).item() >= 0.99, (opts, k)
