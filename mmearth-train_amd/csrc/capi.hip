@@ -1613,7 +1613,7 @@ int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp,
     if (!meters->losses || !meters->sums || !meters->gnorm2 || meters->T < 1 || meters->window < 1) return (int)hipErrorInvalidValue;
     mt = MeterP{meters->losses, meters->weighted, meters->T, meters->ring, meters->window, meters->sums, meters->gnorm2};
   }
-  LAUNCH(hp_fetch_kernel, dim3(1), dim3(64), 0, S_(s), ring_pinned, slots, counter, hp, total, mt);
+  LAUNCH(hp_fetch_kernel, dim3(1), dim3(1024), 0, S_(s), ring_pinned, slots, counter, hp, total, mt);
   RET();
 }
 

@@ -216,40 +216,53 @@ __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ ds
 // step is accumulated by adamw_kernel (sum g^2 of the exchanged gradients) and lands in ITS record at the next fetch. The host reads
 // ring + sums with one copy per print, ranks fold their sums with one all-reduce per epoch.
 struct MeterP { const float* losses; const float* weighted; int T; float* ring; int window; float* sums; float* gnorm2; };
-__global__ void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
-                                const float* __restrict__ total, const MeterP mt) {
+__global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
+                                                       const float* __restrict__ total, const MeterP mt) {
+  // 1024 threads, every global read issued up front from a clamped address (a runtime-length loop of dependent loads was 64 serial
+  // round trips = 30 us at the head of every step); the partial count only masks what was loaded
+  __shared__ float red[16];
   const int c = *counter;
   const float gs_prev = hp[3];
-  __syncthreads();
+  const float tot = total ? *total : 0.f;
   if (mt.ring) {
-    const int W = 2 * mt.T + 2, cnt = (int)mt.sums[W];
-    if (cnt > 0) {                                         // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526):
-      const int nb = (int)mt.gnorm2[0];                    // gnorm2 = {partial count, per-workgroup sums of g^2 written by adamw_kernel}
-      float t = 0.f;
-      for (int i = threadIdx.x; i < nb; i += blockDim.x) t += mt.gnorm2[1 + i];
-      t = wave_sum(t);
-      if (threadIdx.x == 0) {
-        const float gn = sqrtf(t) * gs_prev;
-        mt.ring[(size_t)((cnt - 1) % mt.window) * W + W - 1] = gn;
-        mt.sums[W - 1] += gn;
-      }
-    }
-    for (int i = threadIdx.x; i < W - 1; i += blockDim.x) {
-      const float v = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : (total ? *total : 0.f);
-      mt.ring[(size_t)(cnt % mt.window) * W + i] = v;
-      mt.sums[i] += v;
-    }
+    const int W = 2 * mt.T + 2;
+    const float cntf = mt.sums[W], nbf = mt.gnorm2[0];
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = mt.gnorm2[1 + threadIdx.x + j * 1024];           // capacity 4096 partials (engine.gnorm2)
+    const int i = min((int)threadIdx.x, W - 2);
+    const float lv = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : tot;
+    const float sv = mt.sums[i], sg = mt.sums[W - 1];
+    const int cnt = (int)cntf, nb = (int)nbf;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t += ((int)threadIdx.x + j * 1024 < nb) ? g[j] : 0.f;
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
     __syncthreads();
+    if (threadIdx.x == 0 && cnt > 0) {                       // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526)
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a += red[j];
+      const float gn = sqrtf(a) * gs_prev;
+      mt.ring[(size_t)((cnt - 1) % mt.window) * W + W - 1] = gn;
+      mt.sums[W - 1] = sg + gn;
+    }
+    if ((int)threadIdx.x < W - 1) {
+      mt.ring[(size_t)(cnt % mt.window) * W + i] = lv;
+      mt.sums[i] = sv + lv;
+    }
     if (threadIdx.x == 0) { mt.gnorm2[0] = 0.f; mt.sums[W] = (float)(cnt + 1); }      // (partial count 0: a skipped update leaves no norm)
   }
-  if (threadIdx.x < 4) hp[threadIdx.x] = ring[(size_t)(c % R) * 4 + threadIdx.x];
-  __syncthreads();
+  float h = 0.f;
+  if (threadIdx.x < 4) h = ring[(size_t)(c % R) * 4 + threadIdx.x];
+  __syncthreads();                                           // hp[3] (previous grad scale) was read above by every thread
+  if (threadIdx.x < 4) hp[threadIdx.x] = h;
   if (threadIdx.x == 0) {
     *counter = c + 1;
     // engine_pretrain.py:83-85 stops on a non-finite loss BEFORE the optimizer step; here the check stays on the
     // device: hp[4] makes this step's AdamW a no-op, hp[5] counts skipped steps (the host polls it lazily)
-    const float t = total ? *total : 0.f;
-    const bool bad = !(fabsf(t) <= 3.0e38f);
+    const bool bad = !(fabsf(tot) <= 3.0e38f);
     hp[4] = bad ? 1.f : 0.f;
     if (bad) hp[5] += 1.f;
   }

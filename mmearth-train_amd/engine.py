@@ -48,6 +48,8 @@ ENGINE_OPTIONS = dict(
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
+    front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
+    zero_side=1,            # the step's zero fills (statistics, flat gradients, padded stem dW) on the side lane, ONE loss finalisation per step
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     ps=3,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage
     ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
@@ -989,15 +991,22 @@ class Engine:
         prep_side = self.lanes and bool(self.opt["prep_side"]) and not self.fp8
         self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max,
                  **(dict(lane=1, signal="prep_done") if prep_side else {}))
-        self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv))
+        # the pixel-activity map and its poolings also only read the inputs (and the mask tables): with `front_side` they follow the weight
+        # staging on the side lane, so the main lane goes mask -> im2col directly and the stem GEMM waits for ONE side-lane event
+        front_side = prep_side and bool(self.opt["front_side"]) and self.track_activity
+        self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv),
+                 **(dict(signal="mask_done") if front_side else {}))
         img = self.inp["sentinel2"]
         if self.track_activity:
+            fl = dict(lane=1) if front_side else {}
             self._op(f, "act0", lib.mpmae_activity, _p(img), _p(self.vis), _p(self.act_full), N, cfg.in_chans,
-                     cfg.img_size, self.keep, self.grid, p)
+                     cfg.img_size, self.keep, self.grid, p, **(dict(lane=1, wait=("mask_done",)) if front_side else {}))
             if k > 1:
-                self._op(f, "actpool_stem", lib.mpmae_activity_pool, _p(self.act_full), _p(self.act[0]), self.M[0], 8, k)
+                self._op(f, "actpool_stem", lib.mpmae_activity_pool, _p(self.act_full), _p(self.act[0]), self.M[0], 8, k, **fl)
             for i in range(1, 4):
-                self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2)
+                self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2, **fl)
+            if front_side:
+                f[-1][3]["signal"] = "front_done"
         wt = self.w["stem.Wt"]
         self.stem_im2col = bool(self.opt["stem_im2col"])
         if self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
@@ -1014,7 +1023,7 @@ class Engine:
                        vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
                        grid=self.grid, H=cfg.img_size)
         if prep_side:
-            f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + ("prep_done",)
+            f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + (("front_done",) if front_side else ("prep_done",))
         self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
         if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
@@ -1432,9 +1441,11 @@ class Engine:
             self.dw_stem_pad = torch.zeros(C0 * self.ldk, dtype=torch.float32, device=self.device)
             # zeroed at the START of the backward: in the tail it sat on the critical path between the last data gradient
             # and AdamW (profiles/r01/timeline_final.txt)
-            self._op(b, "stem:conv.dWpad.zero", lib.mpmae_memset_async, _p(self.dw_stem_pad), 0, C0 * self.ldk * 4)
+            zs = self.lanes and bool(self.opt["zero_side"])      # (side lane: idle at that point, the weight gradient below waits for it)
+            self._op(b, "stem:conv.dWpad.zero", lib.mpmae_memset_async, _p(self.dw_stem_pad), 0, C0 * self.ldk * 4,
+                     **(dict(lane=1, signal="stem_pad_zero") if zs else {}))
             b.insert(0, b.pop())
-            self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", P=dc1, Q=self.col, M=self.Mfull, Nn=C0, Kk=self.ldk, ldp=C0,
+            self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", wait=("stem_pad_zero",) if zs else (), P=dc1, Q=self.col, M=self.Mfull, Nn=C0, Kk=self.ldk, ldp=C0,
                         ldq=self.ldk, dW=self.dw_stem_pad, sn=self.ldk, sk=1, db=Gd["encoder.initial_conv.0.bias"])
             # (C0, 9*Cin) padded row-major -> ME kernel layout (9, Cin, C0)
             self._op(b, "stem:conv.dW.fold", lib.mpmae_strided_add, _p(Gd["encoder.initial_conv.0.kernel"]),
@@ -1687,21 +1698,30 @@ class Engine:
 
     def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
-        runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
-        [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
+        runner issues separately: [gradient zeroing], [forward + loss], [backward segment 0], [segment 1], ...,
+        [AdamW] (a gradient-accumulating runner skips the first piece on all but the first micro-step of a window). Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
         mpmae_program_run call (the plain single-GPU step is the whole range)."""
         lib, a = self.lib, self._fin_args
         m0 = dict(lane=0, wait=(), signal=None)
 
+        zs = self.lanes and bool(self.opt["zero_side"])
+        zl = dict(lane=1, wait=(), signal=None) if zs else m0
+
         def fin(dlv):      # the forward finalisation also joins the image-head chain that ran on the side lane
-            m = dict(lane=0, wait=tuple(getattr(self, "_fwd_join_keys", ())) if not dlv else (), signal=None)
+            w = tuple(getattr(self, "_fwd_join_keys", ())) if (zs or not dlv) else ()
+            m = dict(lane=0, wait=w + (("grads_zero",) if dlv and zs else ()), signal=None)
             return ("loss.finalize", lib.mpmae_loss_finalize,
                     (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
-        fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), m0)]
-        fwd += list(self.fwd_ops) + [fin(False)]
-        zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4), m0)]
+        # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane
+        # event - the stem GEMM waiting for the weight staging - covers the statistics; the gradient finalisation waits for "grads_zero")
+        fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), zl)]
+        # ... and the forward's own finalisation is dropped: the one in front of the backward computes the same losses / total plus
+        # d total / d log_vars (a caller that replays ONLY the forward piece reads its losses through Engine.forward instead)
+        fwd += list(self.fwd_ops) + ([] if zs else [fin(False)])
+        zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4),
+                 dict(zl, signal="grads_zero") if zs else m0)]
         first = [fin(True)] + list(segs[0])
         # AdamW reads every gradient: when the optimizer is replayed in the SAME mpmae_program_run call as the backward (the
         # single-GPU step), the side lanes are only joined at the end of that call, so its first op waits for the last op of
@@ -1741,7 +1761,8 @@ class Engine:
             elif last_side_key is not None:
                 keys.append(last_side_key)
             self._bucket_keys.append(keys)
-        return [fwd, zero, first] + [list(sg) for sg in segs[1:]] + [opt]
+        # piece order: [gradient zeroing, forward + loss, backward segments ..., AdamW]
+        return [zero, fwd, first] + [list(sg) for sg in segs[1:]] + [opt]
 
     def record_program(self, pieces):
         """Record op tuples into a native launch program (include/mpmae_hip.h, "launch programs").
