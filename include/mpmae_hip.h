@@ -253,6 +253,26 @@ typedef struct MpmaeStemTailArgs {
 } MpmaeStemTailArgs;
 int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* args, mpmae_stream_t stream);
 
+/* The whole sparse stem forward of patch size 8 in one launch (bf16 storage): masked 3x3 convolution of the fp32 image
+ * (convnextv2_sparse.py:113-117 on MinkowskiOps.to_sparse input; taps outside the image or inside masked patches are absent) with the
+ * bf16-rounded weights (staged W [C0][ldw] or the fp32 master W_master; k = (kw*3 + kh)*Cin + cin, the order of mpmae_im2col3) + bias, followed by mpmae_stem_tail's forward.
+ * Replaces mpmae_im2col3 + the stem GEMM + mpmae_stem_tail(fwd); the convolution output is not materialised
+ * (the backward reads xhat1 / rstd1 / xhat2 / rstd2 only). track_activity != 0: rows whose pixel is all-zero are inactive (zeros
+ * everywhere), as the activity map of mpmae_activity says. Requires S = 8, Cin <= 12, C0 <= 48, C0 % 4 == 0, ldw % 8 == 0. */
+typedef struct MpmaeStemFrontArgs {
+  const float* img; const int* vis; const int* inv;       /* [N,Cin,H,H], mask tables of mpmae_mask_gen */
+  const void* W; int ldw;   /* staged bf16 weights [C0][ldw], or NULL when W_master is given */
+  const float* W_master;    /* fp32 parameter in ME layout [9*Cin][C0] (k = (kw*3 + kh)*Cin + cin): rounded to bf16 in the kernel's prologue,
+                               the launch then depends on no weight staging */
+  const float* bias;
+  void* xhat1; float* rstd1; void* xhat2; float* rstd2; void* out;      /* [N*keep*64, C0] / [N*keep*64] */
+  const float* g1; const float* b1; const float* w; const float* wb; const float* g2; const float* b2;
+  void* col; int ldc;       /* optional (NULL): also write the bf16 im2col matrix [N*keep*64][ldc] (ldc % 8 == 0, ldc >= 9 Cin, the layout
+                               of mpmae_im2col3) that the stem's weight gradient reads - from the kernel's own MFMA operand fragments */
+  int N, keep, grid, H, Cin, C0, track_activity;
+} MpmaeStemFrontArgs;
+int mpmae_stem_front(const MpmaeStemFrontArgs* args, mpmae_stream_t stream);
+
 /* ---- input stage ---------------------------------------------------------------------------- */
 /* Aligned random crop of FCMAE.forward (kornia RandomCrop, models/fcmae.py:419-434): dst[n,c,y,x] = src[n,c,ty[n]+y,tx[n]+x]
  * for one pixel-wise modality ([N,C,H,H] -> [N,C,S,S]; elem_bytes 4 = fp32 bands, 8 = int64 class maps); the same per-sample

@@ -150,6 +150,15 @@ class StemTailArgs(C.Structure):
                 ("db2", c_void_p), ("ws", c_void_p), ("ws_floats", c_size_t), ("M", c_int), ("C", c_int)]
 
 
+class StemFrontArgs(C.Structure):
+    _fields_ = [("img", c_void_p), ("vis", c_void_p), ("inv", c_void_p), ("W", c_void_p), ("ldw", c_int), ("W_master", c_void_p), ("bias", c_void_p),
+                ("xhat1", c_void_p), ("rstd1", c_void_p), ("xhat2", c_void_p), ("rstd2", c_void_p), ("out", c_void_p),
+                ("g1", c_void_p), ("b1", c_void_p), ("w", c_void_p), ("wb", c_void_p), ("g2", c_void_p), ("b2", c_void_p),
+                ("col", c_void_p), ("ldc", c_int),
+                ("N", c_int), ("keep", c_int), ("grid", c_int), ("H", c_int), ("Cin", c_int), ("C0", c_int),
+                ("track_activity", c_int)]
+
+
 OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
@@ -214,6 +223,7 @@ SYMBOLS = {
                       c_void_p],
     "mpmae_strided_add": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_stem_tail": [c_int, c_int, P(StemTailArgs), c_void_p],
+    "mpmae_stem_front": [P(StemFrontArgs), c_void_p],
     "mpmae_hp_fetch": [c_void_p, c_int, c_void_p, c_void_p, c_void_p, P(Meters), c_void_p],
     "mpmae_program_begin_op": [c_void_p, c_int, C.POINTER(c_int), c_int, c_int],
     "mpmae_program_end": [c_void_p],

@@ -1453,6 +1453,35 @@ int mpmae_strided_add(float* dst, const float* src, int rows, int cols, int src_
   RET();
 }
 
+int mpmae_stem_front(const MpmaeStemFrontArgs* a, mpmae_stream_t s) {
+  if (!a || !a->img || !a->vis || !a->inv || (!a->W && !a->W_master) || !a->bias || !a->out || !a->xhat1 || !a->xhat2 || !a->rstd1 || !a->rstd2)
+    return (int)hipErrorInvalidValue;
+  if (a->Cin < 1 || a->Cin > 12 || a->C0 < 4 || a->C0 > 48 || (a->C0 & 3) || (a->W && ((a->ldw & 7) || a->ldw < 9 * a->Cin)) || a->N < 1 ||
+      a->keep < 1 || a->H != a->grid * 8)
+    return (int)hipErrorInvalidValue;
+  StemFrontP p;
+  p.img = a->img; p.vis = a->vis; p.inv = a->inv; p.W = reinterpret_cast<const bf16_t*>(a->W); p.ldw = a->ldw; p.Wm = a->W_master; p.bias = a->bias;
+  p.xhat1 = a->xhat1; p.rstd1 = a->rstd1; p.xhat2 = a->xhat2; p.rstd2 = a->rstd2; p.out = a->out;
+  p.g1 = a->g1; p.b1 = a->b1; p.w = a->w; p.wb = a->wb; p.g2 = a->g2; p.b2 = a->b2;
+  if (a->col && ((a->ldc & 7) || a->ldc < 9 * a->Cin || a->ldc > 128)) return (int)hipErrorInvalidValue;
+  p.col = reinterpret_cast<bf16_t*>(a->col); p.ldc = a->ldc;
+  p.keep = a->keep; p.grid = a->grid; p.H = a->H; p.Cin = a->Cin; p.C0 = a->C0; p.track = a->track_activity;
+  p.npatch = a->N * a->keep;
+  static int per_cu[2] = {0, 0};                                   // resident workgroups per CU of the two instantiations (asked once)
+  const int which = a->Cin == 12 ? 1 : 0;
+  if (!per_cu[which]) {
+    int nb = 0;
+    const hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_front_kernel<12>, 256, 0)
+                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stem_front_kernel<0>, 256, 0);
+    if (e != hipSuccess) (void)hipGetLastError();
+    per_cu[which] = (e == hipSuccess && nb > 0) ? nb : 2;
+  }
+  const int blocks = std::min(p.npatch, per_cu[which] * ps_num_cus());      // persistent: one resident wave of workgroups walks all patches
+  if (a->Cin == 12) LAUNCH(stem_front_kernel<12>, dim3(blocks), dim3(256), 0, S_(s), p);
+  else LAUNCH(stem_front_kernel<0>, dim3(blocks), dim3(256), 0, S_(s), p);
+  RET();
+}
+
 int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t s) {
   if (!a || (a->C & 7) || a->C > 512 || a->M < 1) return (int)hipErrorInvalidValue;
   const int nvec = a->C / 8;

@@ -339,17 +339,21 @@ class StepRunner:
             self._opt()
 
     def _span(self, i, j):
-        """Program range covering pieces i..j (inclusive): [zero, fwd, seg0, seg1, ..., opt]."""
+        """Program range covering pieces i..j (inclusive): [fwd, zero, seg0, seg1, ..., opt]."""
         lo = self.spans[i][0]
         return (lo, self.spans[j][0] + self.spans[j][1] - lo)
 
     def _step_program(self, first, last):
         eng = self.eng
         nseg = len(self.segments)
-        ZERO, FWD, SEG0, OPT = 0, 1, 2, 2 + nseg
+        FWD, ZERO, SEG0, OPT = 0, 1, 2, 2 + nseg
         if not self.exchange or not last:
             hi = OPT if last else OPT - 1
-            eng.run_program(self.prog, self._span(ZERO if first else FWD, hi))            # the whole micro-step in one call
+            if first:
+                eng.run_program(self.prog, self._span(FWD, hi))            # the whole micro-step in one call
+            else:
+                eng.run_program(self.prog, self._span(FWD, FWD))
+                eng.run_program(self.prog, self._span(SEG0, hi))
             if last:
                 eng.note_optimizer_launch()
             return
@@ -357,14 +361,18 @@ class StepRunner:
         if self.bucket_signals:
             # ONE replay call for forward + the whole backward (no side-lane join between buckets: the main lane never waits for
             # the weight-gradient lane at a bucket boundary); the communication stream waits for each bucket's "ready" events
-            eng.run_program(self.prog, self._span(ZERO if first else FWD, SEG0 + nseg - 1))
+            if first:
+                eng.run_program(self.prog, self._span(FWD, SEG0 + nseg - 1))
+            else:
+                eng.run_program(self.prog, self._span(FWD, FWD))
+                eng.run_program(self.prog, self._span(SEG0, SEG0 + nseg - 1))
             comm = _c_stream(self.comm_stream)
             for i in range(nseg):
                 for sig in self.bucket_signals[i]:
                     _check(eng.lib.mpmae_program_stream_wait(self.prog, sig, comm), "program_stream_wait")
                 self._launch_allreduce(i, works, ready=True)
         else:
-            eng.run_program(self.prog, self._span(ZERO if first else FWD, FWD))
+            eng.run_program(self.prog, self._span(FWD, ZERO if first else FWD))
             for i in range(nseg):
                 eng.run_program(self.prog, self._span(SEG0 + i, SEG0 + i))
                 self._launch_allreduce(i, works)

@@ -43,6 +43,7 @@ ENGINE_OPTIONS = dict(
     heads_merged=1,         # one GEMM / weight gradient per head family
     stem_im2col=1,          # 3x3 stem convolution through a materialised im2col
     stem_fused=1,           # fused stem tail (patch 8)
+    stem_front=1,           # ... and the 3x3 convolution in front of it in the same launch (stem_front_kernel), which also writes the im2col matrix of the weight gradient
     loss_multi=1,           # one launch per loss kind
     loss_rows=1,            # continuous pixel losses: row-band forward kernel
     loss_rows_bwd=1,        # ... and its gradient twin
@@ -1009,23 +1010,53 @@ class Engine:
                 f[-1][3]["signal"] = "front_done"
         wt = self.w["stem.Wt"]
         self.stem_im2col = bool(self.opt["stem_im2col"])
+        self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
+        # one launch for the whole stem forward (bf16, patch 8): the convolution output never exists, and the im2col matrix of the weight
+        # gradient is written from the kernel's own MFMA operand fragments (no mpmae_im2col3 launch at all)
+        self.stem_front = (self.stem_fused and self.stem_im2col and dt != F32 and bool(self.opt["stem_front"]) and p == 8
+                           and cfg.in_chans <= 12 and C0 <= 48 and wt["ld"] % 8 == 0)
         if self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
             self.ldk = _rup(9 * cfg.in_chans, 8)
             self.col = self._t(self.Mfull * self.ldk)
-            self._op(f, "stem:im2col", lib.mpmae_im2col3, dt, _p(img), _p(self.vis), _p(self.inv), _p(self.col), self.ldk,
-                     N, self.keep, self.grid, p, cfg.in_chans, cfg.img_size, kind="im2col3",
-                     nbytes=self.Mfull * self.ldk * (4 if dt == F32 else 2) + img.numel() * 4)
-            self._gemm(f, "stem:conv", "NONE", "STORE", A=self.col, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
-                       C=self.c1, M=self.Mfull, N=C0, K=self.ldk, lda=self.ldk, ldb=wt["ld"], ldc=C0, act=self.act_full)
+            if not self.stem_front:
+                self._op(f, "stem:im2col", lib.mpmae_im2col3, dt, _p(img), _p(self.vis), _p(self.inv), _p(self.col), self.ldk,
+                         N, self.keep, self.grid, p, cfg.in_chans, cfg.img_size, kind="im2col3",
+                         nbytes=self.Mfull * self.ldk * (4 if dt == F32 else 2) + img.numel() * 4)
+            if not self.stem_front:
+                self._gemm(f, "stem:conv", "NONE", "STORE", A=self.col, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
+                           C=self.c1, M=self.Mfull, N=C0, K=self.ldk, lda=self.ldk, ldb=wt["ld"], ldc=C0, act=self.act_full)
         else:
             self._gemm(f, "stem:conv", "IM2COL3", "STORE", A=img, B=wt["t"], bias=P["encoder.initial_conv.0.bias"],
                        C=self.c1, M=self.Mfull, N=C0, K=9 * cfg.in_chans, lda=0, ldb=wt["ld"], ldc=C0,
                        vis=self.vis, inv=self.inv, act=self.act_full, keep=self.keep, L=L, S=p, Cseg=cfg.in_chans,
                        grid=self.grid, H=cfg.img_size)
+        if self.stem_front:
+            a = _lib.StemFrontArgs()
+            a.img, a.vis, a.inv = img.data_ptr(), self.vis.data_ptr(), self.inv.data_ptr()
+            # the fp32 parameter itself (ME layout [9 Cin][C0], the k order of the im2col matrix): the kernel rounds it to bf16 as the staging
+            # does, so the launch waits for nothing on the side lane
+            a.W, a.ldw, a.W_master = 0, 0, P["encoder.initial_conv.0.kernel"].data_ptr()
+            a.bias = P["encoder.initial_conv.0.bias"].data_ptr()
+            a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (self.c1hat, self.rstd1, self.s0hat, self.rstd2))
+            a.out = self.x0.data_ptr()
+            a.g1, a.b1 = P["encoder.initial_conv.1.ln.weight"].data_ptr(), P["encoder.initial_conv.1.ln.bias"].data_ptr()
+            a.w, a.wb = P["encoder.stem.0.kernel"].data_ptr(), P["encoder.stem.0.bias"].data_ptr()
+            a.g2, a.b2 = P["encoder.stem.1.ln.weight"].data_ptr(), P["encoder.stem.1.ln.bias"].data_ptr()
+            a.N, a.keep, a.grid, a.H, a.Cin, a.C0 = N, self.keep, self.grid, cfg.img_size, cfg.in_chans, C0
+            a.track_activity = 1 if self.track_activity else 0
+            a.col, a.ldc = self.col.data_ptr(), self.ldk          # the weight gradient's im2col matrix, from the kernel's own A fragments
+            self._keepalive.append(a)
+            self._op(f, "stem:conv+ln+gelu+dw+ln", lib.mpmae_stem_front, C.byref(a), kind="stem_front",
+                     nbytes=3 * self.Mfull * C0 * 2 + self.Mfull * self.ldk * 2 + N * self.keep * 100 * cfg.in_chans * 4,
+                     flops=2 * self.Mfull * C0 * 9 * cfg.in_chans)
         if prep_side:
-            f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + (("front_done",) if front_side else ("prep_done",))
-        self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
-        if self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
+            if self.stem_front:       # the fused stem kernel reads the fp32 parameter itself; whatever follows it waits for the side-lane front
+                stem_at, rest_key = len(f) - 1, ("front_done" if front_side else "prep_done")
+            else:
+                f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + (("front_done",) if front_side else ("prep_done",))
+        if self.stem_front:
+            pass
+        elif self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
             a.x, a.out = self.c1.data_ptr(), self.x0.data_ptr()
             a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (self.c1hat, self.rstd1, self.s0hat, self.rstd2))
@@ -1050,6 +1081,7 @@ class Engine:
                  _p(self.act[0]))
         x = self.x0
         bi = 0
+        self._front_rest = (stem_at, rest_key) if (prep_side and self.stem_front) else None
         for i in range(4):
             if i > 0:
                 dn = self.down[i - 1]
@@ -1220,6 +1252,10 @@ class Engine:
                         m["wait"] = tuple(m["wait"]) + (prod["signal"],)
                 f[idx[-1]][3]["signal"] = "img_side_done"
                 self._fwd_join_keys = ["img_side_done"]
+        if self._front_rest is not None:          # the first main-lane op behind the fused stem kernel waits for the rest of the side-lane front
+            at, key = self._front_rest
+            nxt = next(op for op in f[at + 1:] if op[3]["lane"] == 0)
+            nxt[3]["wait"] = tuple(nxt[3]["wait"]) + (key,)
         self.loss_scale = 1.0
         lv = P.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
         glv = self.grads.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
@@ -1698,8 +1734,8 @@ class Engine:
 
     def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
-        runner issues separately: [gradient zeroing], [forward + loss], [backward segment 0], [segment 1], ...,
-        [AdamW] (a gradient-accumulating runner skips the first piece on all but the first micro-step of a window). Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
+        runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
+        [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
         mpmae_program_run call (the plain single-GPU step is the whole range)."""
         lib, a = self.lib, self._fin_args
         m0 = dict(lane=0, wait=(), signal=None)
@@ -1761,8 +1797,7 @@ class Engine:
             elif last_side_key is not None:
                 keys.append(last_side_key)
             self._bucket_keys.append(keys)
-        # piece order: [gradient zeroing, forward + loss, backward segments ..., AdamW]
-        return [zero, fwd, first] + [list(sg) for sg in segs[1:]] + [opt]
+        return [fwd, zero, first] + [list(sg) for sg in segs[1:]] + [opt]
 
     def record_program(self, pieces):
         """Record op tuples into a native launch program (include/mpmae_hip.h, "launch programs").

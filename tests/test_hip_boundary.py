@@ -249,6 +249,9 @@ def test_forward_decoder_sees_weights_changed_after_forward_encoder():
     sd, inputs, noise = case_data(c, cfg)
     for dtype in ("bf16", "fp8"):
         eng = _engine(cfg, c["N"], dtype, sd, inputs, noise)
+        eng.forward()
+        torch.cuda.synchronize()
+        before = {k: v.float().clone() for k, v in eng.preds().items()}
         eng.run_segment("encoder")
         torch.cuda.synchronize()
         with torch.no_grad():
@@ -259,8 +262,15 @@ def test_forward_decoder_sees_weights_changed_after_forward_encoder():
         got = {k: v.float().clone() for k, v in eng.preds().items()}
         eng.forward()                                   # full program with the changed weights
         torch.cuda.synchronize()
+        # Two forwards of the SAME weights are not bit-identical: the GRN column sums fold through LDS float atomics whose order varies,
+        # the fp32 sums differ in their last bits and now and then a bf16 (fp8) rounding downstream flips - measured run-to-run floor on
+        # this 2-sample case: <= 1.5 % of max|pred| in bf16, <= 6.2 % with the MX-fp8 decoder. Stale weights are off by far more.
+        tol = 4e-2 if dtype == "bf16" else 1.2e-1
+        moved = 0.0
         for k, v in eng.preds().items():
-            assert _rel(got[k], v.float()) < (2e-2 if dtype == "bf16" else 4e-2), (dtype, k)
+            assert _rel(got[k], v.float()) < tol, (dtype, k)
+            moved = max(moved, _rel(before[k], v.float()))
+        assert moved > 3 * tol, (dtype, moved, "the weight change must move the predictions far beyond the tolerance")
 
 
 def test_rccl_exchange_runs_at_world_size_one():

@@ -57,7 +57,8 @@ def eng():
     inputs["sentinel2"] = inputs["sentinel2"] * (~z)
     e.set_inputs(inputs, noise)
     names = [o[0] for o in e.fwd_ops]
-    e._run(e.fwd_ops[:names.index("stem:im2col")], e._stream())        # prep, mask, activity maps
+    stem = next(i for i, n_ in enumerate(names) if n_.startswith("stem:"))
+    e._run(e.fwd_ops[:stem], e._stream())        # prep, mask, activity maps
     torch.cuda.synchronize()
     e.test_inputs = inputs
     return e
@@ -422,6 +423,44 @@ def _ps_pair(N, seed, ps_bwd=0):
     return engs
 
 
+@pytest.mark.parametrize("N", [2, 37])
+def test_fused_stem_front_matches_im2col_gemm_and_stem_tail(N):
+    """mpmae_stem_front (masked 3x3 convolution + LN + GELU + affine + LN in one launch, convolution output never stored) against the
+    three launches it replaces (mpmae_im2col3 -> NT GEMM -> mpmae_stem_tail) inside the same engine program: same rounding points, so
+    every saved tensor agrees to 1 bf16 ulp; all-zero pixels (inactive rows), image borders and masked neighbour patches included."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.engine import Engine
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg()
+    sd = make_state_dict(cfg, seed=71)
+    inputs, noise = make_inputs(cfg, N, seed=72)
+    g = torch.Generator().manual_seed(73)
+    s2 = inputs["sentinel2"]
+    dead = torch.rand(s2.shape[0], 1, s2.shape[2], s2.shape[3], generator=g) < 0.1
+    inputs = dict(inputs, sentinel2=torch.where(dead, torch.zeros_like(s2), s2))
+    out = {}
+    for sf in (0, 1):
+        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(stem_front=sf))
+        e.load_state_dict(sd)
+        e.set_inputs(inputs, noise)
+        e.forward()
+        torch.cuda.synchronize()
+        assert e.stem_front == bool(sf)
+        out[sf] = {k: getattr(e, k).clone() for k in ("x0", "c1hat", "s0hat", "rstd1", "rstd2", "mask", "act_full", "col")}
+        out[sf]["losses"] = e.losses.clone()
+    assert torch.equal(out[0]["mask"], out[1]["mask"])
+    assert torch.equal(out[0]["col"], out[1]["col"]), "im2col matrix written from the MFMA operand fragments == mpmae_im2col3"
+    act = out[0]["act_full"].bool()
+    assert 0.05 < (~act).float().mean() < 0.2
+    for k in ("x0", "c1hat", "s0hat"):
+        _assert_bf16_close(out[1][k], out[0][k], k)
+        assert (out[1][k].view(act.numel(), -1)[~act] == 0).all(), (k, "inactive rows are zero")
+    for k in ("rstd1", "rstd2"):
+        assert _rel(out[1][k], out[0][k]) < 2e-3, k
+        assert (out[1][k][~act] == 0).all(), k
+    assert torch.allclose(out[1]["losses"], out[0]["losses"], rtol=1e-2)      # (1-ulp differences of the stem output, amplified over a 2-sample batch)
+
+
 @pytest.mark.parametrize("N,ps_bwd", [(3, 0), (40, 0), (5, 1), (40, 1)])
 def test_persistent_stage_kernels_match_the_per_block_kernels(N, ps_bwd):
     """mpmae_ps_fwd (one launch per stage, grid barrier per block) against mpmae_dwconv7_fwd + mpmae_rs + GEMMs on the same bf16
@@ -461,7 +500,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N, ps_bwd):
 @pytest.mark.parametrize("opts", ["DW=6", "DW=5", "DW=4", "DW=3", "TN=1", "TN3_BLOCKS=0", "RSC_SMALL=0", "RSC_PF=0,RSC_SMALL=0",
                                   "RSC_N40=1,RSC_N80=0", "NT_GLDS=0", "NT_GLDS64=0,NT_BK32=0", "CS_SPLIT=0", "DWW=6",
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
-                                  "stem_fused=0", "stem_im2col=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "grouped_epi=1",
+                                  "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "grouped_epi=1",
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
                                   "img_side=0,prep_side=0", "front_side=0,zero_side=0", "wgrad_late=0", "hr_maxc=80", "ring=2,dz_ring=2"])
 def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
