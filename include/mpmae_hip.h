@@ -19,8 +19,11 @@
  *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless marked "host";
  *   - `dt` selects the activation storage type: 0 = fp32 (exact-f32 MFMA, parity mode),
  *     1 = bf16 (bf16 MFMA, fp32 accumulate). Parameters, gradients and statistics are fp32;
- *   - no allocation, no synchronisation, no global state: the caller owns all memory and passes
- *     workspace; work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - the compute entry points allocate nothing and never synchronise the host: the caller owns all memory and passes
+ *     workspace; work is enqueued on `stream` (a hipStream_t passed as void*). The library's only state is explicit:
+ *     the process-wide option table (mpmae_set_option: developer A/B switches, defaults are the measured-best kernels), the
+ *     launch-program handles a caller creates (mpmae_program_*: they own HIP events and side streams until destroyed), and a
+ *     cached device-property query (CU count / resident workgroups of the persistent kernels);
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch.
  *
  * Row layout. A sparse stage holds only the visible patches: row = (n*keep + slot)*S*S + iy*S + ix
