@@ -420,11 +420,14 @@ int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const 
 int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, const float* w,
                        float* dw, float* db, int Mout, int C, int S, int k, const uint8_t* act_in,
                        float* ws, size_t ws_floats, mpmae_stream_t stream);
-/* mask-token blend of forward_decoder (fcmae.py:253-255) and its parameter gradient. */
-int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D,
-                          mpmae_stream_t stream);
-int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D,
-                         mpmae_stream_t stream);
+/* mask-token blend of forward_decoder (fcmae.py:249-255) and its parameter gradient. With `vis_rows` (compact [N*keep, D] output of the
+ * proj layer as a PLAIN GEMM) the forward writes the whole decoder input [rows = N*L, D] in one pass - the slot's row at visible
+ * patches, the token elsewhere - instead of relying on a scatter epilogue; with `vis_rows_out` the backward's pass over dxdec also
+ * gathers the rows of the visible patches into a compact [N*keep, D] matrix, the operand of proj's data and weight gradients. */
+int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D, const void* vis_rows, int keep,
+                          int L, mpmae_stream_t stream);
+int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, void* vis_rows_out, int keep,
+                         int L, mpmae_stream_t stream);
 /* global average pool over the L positions of each sample (fcmae.py:262). */
 int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mpmae_stream_t stream);
 

@@ -200,8 +200,8 @@ SYMBOLS = {
                            c_void_p, c_void_p, c_void_p],
     "mpmae_dwstride_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                            c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
-    "mpmae_fill_mask_token": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
-    "mpmae_mask_token_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
+    "mpmae_fill_mask_token": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    "mpmae_mask_token_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "mpmae_pool_rows": [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont": [c_int, c_int, P(PixContArgs), c_int, c_void_p],
     "mpmae_loss_pix_cat": [c_int, c_int, P(PixCatArgs), c_int, c_void_p],

@@ -711,21 +711,31 @@ int mpmae_dwstride_bwd(int dt, const void* dout, const void* in, void* din, cons
   RET();
 }
 
-int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D, mpmae_stream_t s) {
+int mpmae_fill_mask_token(int dt, void* xdec, const float* token, const int* inv, int rows, int D, const void* vis_rows, int keep,
+                          int L, mpmae_stream_t s) {
+  if (vis_rows) {
+    if ((D & 7) || keep < 1 || L < keep || rows % L) return (int)hipErrorInvalidValue;
+    const int g = grid1d((long long)rows * (D / 8));
+    if (dt == 0) LAUNCH(assemble_tokens_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)xdec, token, inv, (const float*)vis_rows, rows, D, keep, L);
+    else LAUNCH(assemble_tokens_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)xdec, token, inv, (const bf16_t*)vis_rows, rows, D, keep, L);
+    RET();
+  }
   const int g = grid1d((long long)rows * D);
   if (dt == 0) LAUNCH(fill_mask_token_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)xdec, token, inv, rows, D);
   else LAUNCH(fill_mask_token_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)xdec, token, inv, rows, D);
   RET();
 }
 
-int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, mpmae_stream_t s) {
+int mpmae_mask_token_bwd(int dt, const void* dxdec, const int* inv, float* dtoken, int rows, int D, void* vis_rows_out, int keep,
+                         int L, mpmae_stream_t s) {
   if ((D & 7) || D / 8 > 256) return (int)hipErrorInvalidValue;
+  if (vis_rows_out && (keep < 1 || L < keep || rows % L)) return (int)hipErrorInvalidValue;
   const int rl_n = 256 / (D / 8);
   int blocks = cdiv(rows, rl_n * 8);             // ~8 rows per thread
   if (blocks > 1024) blocks = 1024;
   if (blocks < 1) blocks = 1;
-  if (dt == 0) LAUNCH(mask_token_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D);
-  else LAUNCH(mask_token_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D);
+  if (dt == 0) LAUNCH(mask_token_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dxdec, inv, dtoken, rows, D, (float*)vis_rows_out, keep, L);
+  else LAUNCH(mask_token_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dxdec, inv, dtoken, rows, D, (bf16_t*)vis_rows_out, keep, L);
   RET();
 }
 

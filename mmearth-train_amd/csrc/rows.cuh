@@ -429,11 +429,33 @@ __global__ __launch_bounds__(256) void fill_mask_token_kernel(T* __restrict__ xd
   }
 }
 
+// The whole decoder input in one pass (fcmae.py:249-255): row (n, patch) = the projected encoder row of its slot when the patch is visible,
+// the mask token otherwise. `vis_rows` is the COMPACT output [N*keep, D] of the proj GEMM (a plain NT GEMM then, no scatter epilogue).
+// 8 elements per thread, both candidate sources loaded unconditionally (clamped slot), selected afterwards.
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(T* __restrict__ xdec, const float* __restrict__ token,
+                                                              const int* __restrict__ inv, const T* __restrict__ vis_rows,
+                                                              int rows, int D, int keep, int L) {
+  const int vpr = D / 8;
+  const size_t total = (size_t)rows * vpr;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / vpr), v = (int)(idx - (size_t)r * vpr);
+    const int s = inv[r];
+    float a[8], t[8];
+    ld8<T>(vis_rows + ((size_t)(r / L) * keep + max(s, 0)) * D + v * 8, a);
+    ld8<float>(token + v * 8, t);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = s >= 0 ? a[e] : t[e];
+    st8<T>(xdec + (size_t)r * D + v * 8, a);
+  }
+}
+
 // d(mask_token)[c] += sum over masked rows of dxdec[r, c]
 // block = 256 threads = RL row lanes x D/8 column vectors (16-byte loads); grid strides over rows
 template <typename T>
 __global__ __launch_bounds__(256) void mask_token_bwd_kernel(const T* __restrict__ dxdec, const int* __restrict__ inv,
-                                                             float* __restrict__ dtoken, int rows, int D) {
+                                                             float* __restrict__ dtoken, int rows, int D,
+                                                             T* __restrict__ vis_out, int keepn, int L) {
   __shared__ float red[256 * 8];
   const int vpr = D / 8;                         // D % 8 == 0 and vpr <= 256 checked by the launcher
   const int rl_n = 256 / vpr;
@@ -454,6 +476,13 @@ __global__ __launch_bounds__(256) void mask_token_bwd_kernel(const T* __restrict
       for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] += keep[u] < 0 ? x[u][e] : 0.f;
+      if (vis_out) {      // the same pass gathers the rows of the visible patches into the compact [N*keep, D] operand of proj's gradients
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u * stride;
+          if (r < rows && keep[u] >= 0) st8<T>(vis_out + ((size_t)(r / L) * keepn + keep[u]) * D + v * 8, x[u]);
+        }
+      }
     }
   }
 #pragma unroll

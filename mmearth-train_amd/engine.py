@@ -50,6 +50,7 @@ ENGINE_OPTIONS = dict(
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
     front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
+    proj_compact=1,         # proj as a plain NT GEMM on compact rows: the token kernel assembles the decoder input, its backward gathers the visible rows (no scatter / gather GEMM variants)
     zero_side=1,            # the step's zero fills (statistics, flat gradients, padded stem dW) on the side lane, ONE loss finalisation per step
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     ps=3,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage
@@ -1117,9 +1118,19 @@ class Engine:
                 bi += 1
         self.enc_out = x
         wp = self.w["proj.W"]
-        self._gemm(f, "proj", "NONE", "SCATTER_ROWS", A=x, B=wp["t"], bias=P["proj.bias"], C=self.xdec, M=self.M[3],
-                   N=D, K=dims[3], lda=dims[3], ldb=wp["ld"], ldc=D, vis=self.vis, keep=self.keep, L=L)
-        self._op(f, "mask_token", lib.mpmae_fill_mask_token, dt, _p(self.xdec), _p(P["mask_token"]), _p(self.inv), N * L, D)
+        self.proj_compact = bool(self.opt["proj_compact"]) and D % 8 == 0
+        if self.proj_compact:
+            # proj on the COMPACT rows through the plain (fast) NT GEMM; the token kernel then writes the whole decoder input in one pass
+            self.proj_rows = self._t(self.M[3], D)
+            self._gemm(f, "proj", "NONE", "STORE", A=x, B=wp["t"], bias=P["proj.bias"], C=self.proj_rows, M=self.M[3],
+                       N=D, K=dims[3], lda=dims[3], ldb=wp["ld"], ldc=D)
+            self._op(f, "mask_token", lib.mpmae_fill_mask_token, dt, _p(self.xdec), _p(P["mask_token"]), _p(self.inv), N * L, D,
+                     _p(self.proj_rows), self.keep, L)
+        else:
+            self._gemm(f, "proj", "NONE", "SCATTER_ROWS", A=x, B=wp["t"], bias=P["proj.bias"], C=self.xdec, M=self.M[3],
+                       N=D, K=dims[3], lda=dims[3], ldb=wp["ld"], ldc=D, vis=self.vis, keep=self.keep, L=L)
+            self._op(f, "mask_token", lib.mpmae_fill_mask_token, dt, _p(self.xdec), _p(P["mask_token"]), _p(self.inv), N * L, D,
+                     None, 0, 0)
         y = self._block_fwd(f, self.dec, self.xdec)
         self.dec_out = y
         # heads
@@ -1378,14 +1389,25 @@ class Engine:
         # decoder block
         dxdec = self.scr_dxA[:N * L * D]
         self._block_bwd(b, self.dec, self.dy, dxdec)
-        self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D)
-        self._side_wgrad(b, "proj.wgrad", "ROW_GATHER", "NONE", [dxdec], P=dxdec, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
-                    ldq=dims[3], dW=Gd["proj.weight"], sn=dims[3], sk=1, db=Gd["proj.bias"], vis=self.vis,
-                    keep=self.keep, L=L)
         wpt = self.w["proj.WT"]
         cur = self.scr_dxB[:self.M[3] * dims[3]]
-        self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
-                   ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
+        if self.proj_compact:
+            # the token-gradient pass over dxdec also gathers the visible rows: proj's two gradients are plain GEMMs on [M3, D]
+            dyv = self.proj_rows                       # (the forward's compact rows are dead by now)
+            self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D,
+                     _p(dyv), self.keep, L)
+            self._side_wgrad(b, "proj.wgrad", "NONE", "NONE", [dyv], P=dyv, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
+                             ldq=dims[3], dW=Gd["proj.weight"], sn=dims[3], sk=1, db=Gd["proj.bias"])
+            self._gemm(b, "proj.dgrad", "NONE", "STORE", A=dyv, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
+                       ldb=wpt["ld"], ldc=dims[3], act=self.act[3])
+        else:
+            self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D,
+                     None, 0, 0)
+            self._side_wgrad(b, "proj.wgrad", "ROW_GATHER", "NONE", [dxdec], P=dxdec, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
+                        ldq=dims[3], dW=Gd["proj.weight"], sn=dims[3], sk=1, db=Gd["proj.bias"], vis=self.vis,
+                        keep=self.keep, L=L)
+            self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
+                       ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
         self._guard(b, cur)
         ring, ri = self.scr_dx, 2 % len(self.scr_dx)      # dxdec = ring[0], cur = ring[1]
         other = ring[ri]

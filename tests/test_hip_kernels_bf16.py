@@ -329,13 +329,29 @@ def test_pool_rows_and_mask_token_bf16(eng):
     _assert_bf16_close(pooled, x.float().view(N, L, D).mean(1), "pool")
     tok = torch.randn(D, device=DEV)
     xd = x.clone()
-    assert lib.mpmae_fill_mask_token(1, P(xd), P(tok), P(e.inv), N * L, D, _st()) == 0
+    assert lib.mpmae_fill_mask_token(1, P(xd), P(tok), P(e.inv), N * L, D, None, 0, 0, _st()) == 0
     masked = (e.inv.view(-1) < 0)[:, None]
     ref = torch.where(masked, tok.to(bf)[None, :].expand(N * L, D), x)
     assert torch.equal(xd, ref)
     dtok = torch.zeros(D, device=DEV)
-    assert lib.mpmae_mask_token_bwd(1, P(x), P(e.inv), P(dtok), N * L, D, _st()) == 0
+    assert lib.mpmae_mask_token_bwd(1, P(x), P(e.inv), P(dtok), N * L, D, None, 0, 0, _st()) == 0
     assert _rel(dtok, (x.float() * masked).sum(0)) < 2e-4
+    # compact forms (proj as a plain GEMM): the forward assembles the whole decoder input from [N*keep, D] rows + the token, the backward's
+    # pass also gathers the visible rows
+    keep = e.keep
+    vrows = torch.randn(N * keep, D, device=DEV).to(bf)
+    xd2 = torch.full((N * L, D), 7.0, device=DEV, dtype=bf)
+    assert lib.mpmae_fill_mask_token(1, P(xd2), P(tok), P(e.inv), N * L, D, P(vrows), keep, L, _st()) == 0
+    inv = e.inv.view(N, L).long()
+    src = (torch.arange(N, device=DEV)[:, None] * keep + inv.clamp(min=0)).view(-1)
+    ref2 = torch.where(masked, tok.to(bf)[None, :].expand(N * L, D), vrows[src])
+    assert torch.equal(xd2, ref2)
+    dtok2 = torch.zeros(D, device=DEV)
+    gath = torch.full((N * keep, D), 9.0, device=DEV, dtype=bf)
+    assert lib.mpmae_mask_token_bwd(1, P(x), P(e.inv), P(dtok2), N * L, D, P(gath), keep, L, _st()) == 0
+    assert torch.equal(dtok2, dtok)
+    vis_rows = (torch.arange(N, device=DEV)[:, None] * L + e.vis.view(N, keep).long()).view(-1)
+    assert torch.equal(gath, x[vis_rows])
 
 
 @pytest.mark.parametrize("M,N,K", [(1200, 512, 320), (114, 512, 320), (3000, 160, 320), (700, 2816, 512), (6, 896, 512)])
@@ -502,7 +518,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N, ps_bwd):
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
                                   "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "grouped_epi=1",
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
-                                  "img_side=0,prep_side=0", "front_side=0,zero_side=0", "wgrad_late=0", "hr_maxc=80", "ring=2,dz_ring=2"])
+                                  "img_side=0,prep_side=0", "front_side=0,zero_side=0", "proj_compact=0", "wgrad_late=0", "hr_maxc=80", "ring=2,dz_ring=2"])
 def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
     """Every kernel generation still in the library is reachable through mpmae_set_option (include/mpmae_hip.h): a full bf16 step with
     the option set against the step on the default kernels - same losses (1e-2: bf16 rounding points differ between generations) and

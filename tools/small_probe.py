@@ -36,4 +36,4 @@ M, D, L = 12544, 512, 49
 inv = torch.full((M,), -1, dtype=torch.int32, device=dev)
 inv[torch.randperm(M, device=dev)[:4864]] = 1
 dxdec = torch.randn(M, D, device=dev).to(bf); dtok = torch.zeros(D, device=dev)
-print(f"mask_token_bwd     {t(lambda: lib.mpmae_mask_token_bwd(1, P(dxdec), P(inv), P(dtok), M, D, st)):7.1f} us")
+print(f"mask_token_bwd     {t(lambda: lib.mpmae_mask_token_bwd(1, P(dxdec), P(inv), P(dtok), M, D, None, 0, 0, st)):7.1f} us")
