@@ -1297,6 +1297,10 @@ int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
   if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));      // 32-column chunks: the N range splits 4 ways (27.7 -> 24.1 us vs 64)
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
+  // ConvNeXtV2-tiny widths (BASELINE config 4: 96 / 192 / 384; 768 stays on the tiled GEMMs)
+  if (a->C == 96 && a->H == 384 && g_opt[MPMAE_OPT_RSC_SMALL]) return launch_rsc<96, 2, 64, 64, 1, 3>(which, *a, S_(s));
+  if (a->C == 192 && a->H == 768) return launch_rsc<192, 1, 32, 64, 1, 3>(which, *a, S_(s));
+  if (a->C == 384 && a->H == 1536) return launch_rsc<384, 1, 32, 32, 1, 3>(which, *a, S_(s));
   const int small = g_opt[MPMAE_OPT_RSC_SMALL];      // 0: keep the LDS-resident-weights kernels for which 0-3
   if (which > 3 || (small && which < 2)) {
     const int v40 = g_opt[MPMAE_OPT_RSC_N40], v80 = g_opt[MPMAE_OPT_RSC_N80];

@@ -581,12 +581,13 @@ class Engine:
         if not self._rs_ok(blk) or blk["C"] > int(self.opt["rs_maxc"]):
             return False, None
         if self._rsc_ok(blk):
-            return True, ("fused" if blk["C"] <= 160 else None)
+            return True, ("fused" if blk["C"] <= 192 else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
         return True, "plain"
 
     def _rsc_ok(self, blk):
         """chunked row-streaming kernels (rsc.cuh) with the GRN application / its backward fused in"""
-        shapes = ((160, 640), (320, 1280)) + (((40, 160), (80, 320)) if self.rsc_small else ())
+        shapes = (((160, 640), (320, 1280), (192, 768), (384, 1536))      # (atto stages 2-3; tiny stages 1-2, BASELINE config 4)
+                  + (((40, 160), (80, 320), (96, 384)) if self.rsc_small else ()))
         return (self.dt == BF16 and blk["sparse"] and not self.disable_rs and not self.disable_rsc
                 and (blk["C"], blk["H"]) in shapes)
 

@@ -349,7 +349,7 @@ def test_pool_rows_and_mask_token_bf16(eng):
     dtok2 = torch.zeros(D, device=DEV)
     gath = torch.full((N * keep, D), 9.0, device=DEV, dtype=bf)
     assert lib.mpmae_mask_token_bwd(1, P(x), P(e.inv), P(dtok2), N * L, D, P(gath), keep, L, _st()) == 0
-    assert torch.equal(dtok2, dtok)
+    assert _rel(dtok2, dtok) < 1e-5            # (workgroup partials meet in float atomics: equal up to summation order)
     vis_rows = (torch.arange(N, device=DEV)[:, None] * L + e.vis.view(N, keep).long()).view(-1)
     assert torch.equal(gath, x[vis_rows])
 
