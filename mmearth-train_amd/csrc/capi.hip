@@ -23,6 +23,7 @@ static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
 static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a);
 static int launch_wgrad_fast(WgradP a, hipStream_t st);
+static thread_local bool g_tn2_qgrn = false;      // the Q prologue of the mpmae_wgrad call being issued (read by launch_tn2)
 
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 
@@ -230,7 +231,12 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
 
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits, mpmae_stream_t s) {
   if (!args || splits < 1) return (int)hipErrorInvalidValue;
-  if (wgrad_fast_ok(dt, ppro, qpro, *args)) return launch_wgrad_fast(*args, S_(s));
+  if (wgrad_fast_ok(dt, ppro, qpro, *args)) {
+    g_tn2_qgrn = qpro == PRO_GRN;
+    const int e = launch_wgrad_fast(*args, S_(s));
+    g_tn2_qgrn = false;
+    return e;
+  }
   WgradP a = *args;
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
@@ -962,8 +968,14 @@ static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   return err;
 }
 
+static bool tn2_ok(const WgradP& a);
 static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a) {
-  return dt == 1 && ppro == PRO_NONE && qpro == PRO_NONE && !((a.ldp | a.ldq | a.Nn | a.Kk) & 1);
+  if (dt != 1 || ppro != PRO_NONE || ((a.ldp | a.ldq | a.Nn | a.Kk) & 1)) return false;
+  if (qpro == PRO_NONE) return true;
+  // GRN prologue on the wide operand (pwconv2's weight gradient from h instead of a stored z): transpose-read kernel only, one GRN group,
+  // narrow side = P, not a decoder / head shape (the DMA-ring kernel moves its operands global -> LDS untouched)
+  return qpro == PRO_GRN && a.qp0 && a.qp1 && a.rpg >= a.M && a.Nn <= a.Kk && a.Nn < 256 && tn2_ok(a) &&
+         !(((uintptr_t)a.qp0 | (uintptr_t)a.qp1) & 3);
 }
 
 static int tn_variant() {      // MPMAE_TN=1 forces the register-transposing kernel (A/B measurements)
@@ -978,6 +990,7 @@ static void launch_tn2(const WgradP& a, bool swap, int splits, hipStream_t st) {
   const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
   dim3 g(cdiv(WX, 16 * NT), cdiv(WY, 64 * KT), splits);
   if (swap) LAUNCH((gemm_tn2_kernel<NT, KT, true>), g, dim3(256), 0, st, a, splits);
+  else if (g_tn2_qgrn) LAUNCH((gemm_tn2_kernel<NT, KT, false, true>), g, dim3(256), 0, st, a, splits);
   else LAUNCH((gemm_tn2_kernel<NT, KT, false>), g, dim3(256), 0, st, a, splits);
 }
 

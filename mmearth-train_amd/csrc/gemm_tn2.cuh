@@ -31,14 +31,19 @@ __device__ __forceinline__ bf16x8_t tn2_frag(const bf16_t* p, int half_stride) {
 
 constexpr int tn2_ld(int b) { return ((b / 16) & 1) ? b : b + 16; }     // odd multiple of 16
 
-template <int NT, int KT, bool SWAP>
+// QGRN (pwconv2's weight gradient, !SWAP): the wide operand is given as h and becomes z = gelu(h) * qp0[k] + qp1[k] (GRN of the GELU,
+// qp0 = 1 + gamma * Nx) on its way from the load registers to LDS - the forward then never stores z (100 MB per stage-0 block). Rows
+// past the split and the zero rows of inactive sites need no mask: their P rows are zero.
+template <int NT, int KT, bool SWAP, bool QGRN = false>
 __global__ __launch_bounds__(256) void gemm_tn2_kernel(const WgradP w, int splits) {
+  static_assert(!QGRN || !SWAP, "the GRN prologue is applied to the wide (Y) operand");
   constexpr int BX = 16 * NT, BY = 64 * KT, SL = 32;
   constexpr int LDX = tn2_ld(BX), LDY = tn2_ld(BY);
   constexpr int XVR = BX / 8, YVR = BY / 8;                  // 16-byte vectors per slab row
   constexpr int XV = (SL * XVR + 255) / 256, YV = (SL * YVR + 255) / 256;
   __shared__ __attribute__((aligned(16))) bf16_t Xs[2][SL * LDX];
   __shared__ __attribute__((aligned(16))) bf16_t Ys[2][SL * LDY];
+  __shared__ __attribute__((aligned(16))) float qsc[QGRN ? BY : 4], qbt[QGRN ? BY : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const bf16_t* X = reinterpret_cast<const bf16_t*>(SWAP ? w.Q : w.P);
@@ -87,9 +92,32 @@ __global__ __launch_bounds__(256) void gemm_tn2_kernel(const WgradP w, int split
 #pragma unroll
     for (int i = 0; i < YV; ++i) {
       const int v = tid + 256 * i, r = v / YVR, c = (v - r * YVR) * 8;
-      if (v < SL * YVR) *reinterpret_cast<uint4*>(&Ys[buf][r * LDY + c]) = yr[i];
+      if (v < SL * YVR) {
+        uint4 y = yr[i];
+        if (QGRN && y0 + c < WY) {      // (columns past the operand stay zero: at C = 40 half of the 320-column tile is padding)
+          float h[8], g[8];
+          h[0] = __uint_as_float(y.x << 16); h[1] = __uint_as_float(y.x & 0xffff0000u);
+          h[2] = __uint_as_float(y.y << 16); h[3] = __uint_as_float(y.y & 0xffff0000u);
+          h[4] = __uint_as_float(y.z << 16); h[5] = __uint_as_float(y.z & 0xffff0000u);
+          h[6] = __uint_as_float(y.w << 16); h[7] = __uint_as_float(y.w & 0xffff0000u);
+          gelu_n<bf16_t, 8>(h, g);
+          const float4 s0 = *reinterpret_cast<const float4*>(&qsc[c]), s1 = *reinterpret_cast<const float4*>(&qsc[c + 4]);
+          const float4 b0 = *reinterpret_cast<const float4*>(&qbt[c]), b1 = *reinterpret_cast<const float4*>(&qbt[c + 4]);
+          y.x = f2bf2(g[0] * s0.x + b0.x, g[1] * s0.y + b0.y); y.y = f2bf2(g[2] * s0.z + b0.z, g[3] * s0.w + b0.w);
+          y.z = f2bf2(g[4] * s1.x + b1.x, g[5] * s1.y + b1.y); y.w = f2bf2(g[6] * s1.z + b1.z, g[7] * s1.w + b1.w);
+        }
+        *reinterpret_cast<uint4*>(&Ys[buf][r * LDY + c]) = y;
+      }
     }
   };
+  if (QGRN) {
+    for (int i = tid; i < BY; i += 256) {
+      const bool in = y0 + i < WY;
+      qsc[i] = in ? w.qp0[y0 + i] : 0.f;
+      qbt[i] = in ? w.qp1[y0 + i] : 0.f;
+    }
+    __syncthreads();
+  }
 
   const int xoff = (lg * 4 + (lr >> 2)) * LDX + 4 * (lr & 3);
   const int yoff = (lg * 4 + (lr >> 2)) * LDY + wave * 16 * KT + 4 * (lr & 3);

@@ -288,6 +288,36 @@ def test_weight_gradient_kernel_matches_fp32_matmul(M, N, K):
     assert _rel(db, Pm.float().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(4864, 40, 160), (3001, 80, 320), (2048, 160, 640), (1000, 96, 384)])
+def test_weight_gradient_with_grn_prologue_matches_fp32(M, N, K):
+    """pwconv2's weight gradient from h instead of a stored z (mpmae_wgrad, Q prologue MPMAE_PRO_GRN on the transpose-read kernel):
+    dW = P^T z with z = bf16(gelu(h) * qp0 + qp1) rebuilt slab by slab, against torch fp32 on the same bf16 values (the bf16 GELU is
+    the library's polynomial: |error| <= 3.1e-5, below the bf16 rounding of z)."""
+    import ctypes as C
+    from mmearth_train_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + N + K + 1)
+    Pm = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+    Hm = (2 * torch.randn(M, K, device="cuda")).to(torch.bfloat16)
+    sc = 1.0 + 0.3 * torch.randn(K, device="cuda")
+    bt = 0.2 * torch.randn(K, device="cuda")
+    dW = torch.zeros(N, K, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    ws = torch.empty(8 << 20, dtype=torch.float32, device="cuda")
+    a = _lib.WgradArgs()
+    a.P, a.Q, a.M, a.Nn, a.Kk, a.ldp, a.ldq = Pm.data_ptr(), Hm.data_ptr(), M, N, K, N, K
+    a.dW, a.sn, a.sk, a.db = dW.data_ptr(), K, 1, db.data_ptr()
+    a.qp0, a.qp1, a.rpg = sc.data_ptr(), bt.data_ptr(), M
+    a.ws, a.ws_floats = ws.data_ptr(), ws.numel()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mpmae_wgrad(1, _lib.PRO["NONE"], _lib.PRO["GRN"], C.byref(a), 16, st) == 0
+    torch.cuda.synchronize()
+    z = (torch.nn.functional.gelu(Hm.float()) * sc + bt).to(torch.bfloat16).float()
+    ref = Pm.float().t() @ z
+    assert _rel(dW, ref) < 2e-3            # a bf16 ulp of z where the polynomial GELU rounds the other way
+    assert _rel(db, Pm.float().sum(0)) < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["program", "hipgraph"])
 def test_step_drivers_agree_with_python_loop(mode):
     """The native launch program (C replay, weight gradients on a side HIP stream) and the HIP-graph

@@ -48,7 +48,7 @@ def main():
     inputs, noise = make_inputs(cfg, a.batch, seed=4)
     engs = {}
     for ps in (0, 1):
-        eng = Engine(cfg, a.batch, dtype="bf16", device="cuda:0", options=dict(ps=3 * ps))
+        eng = Engine(cfg, a.batch, dtype="bf16", device="cuda:0", options=dict(ps=3 * ps, z_free=0))
         eng.load_state_dict(sd)
         eng.set_inputs(inputs, noise)
         eng.forward()
