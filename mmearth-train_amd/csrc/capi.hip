@@ -22,8 +22,7 @@
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
 static bool wgrad_fast_ok(int dt, int ppro, int qpro, const WgradP& a);
-static int launch_wgrad_fast(WgradP a, hipStream_t st);
-static thread_local bool g_tn2_qgrn = false;      // the Q prologue of the mpmae_wgrad call being issued (read by launch_tn2)
+static int launch_wgrad_fast(WgradP a, hipStream_t st, bool qgrn = false);
 
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 
@@ -231,12 +230,7 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
 
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits, mpmae_stream_t s) {
   if (!args || splits < 1) return (int)hipErrorInvalidValue;
-  if (wgrad_fast_ok(dt, ppro, qpro, *args)) {
-    g_tn2_qgrn = qpro == PRO_GRN;
-    const int e = launch_wgrad_fast(*args, S_(s));
-    g_tn2_qgrn = false;
-    return e;
-  }
+  if (wgrad_fast_ok(dt, ppro, qpro, *args)) return launch_wgrad_fast(*args, S_(s), qpro == PRO_GRN);
   WgradP a = *args;
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
@@ -986,11 +980,11 @@ static int tn_variant() {      // MPMAE_TN=1 forces the register-transposing ker
 
 // transpose-read kernel: 16-byte row vectors, narrow side <= wide side
 template <int NT, int KT>
-static void launch_tn2(const WgradP& a, bool swap, int splits, hipStream_t st) {
+static void launch_tn2(const WgradP& a, bool swap, int splits, hipStream_t st, bool qgrn) {
   const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
   dim3 g(cdiv(WX, 16 * NT), cdiv(WY, 64 * KT), splits);
   if (swap) LAUNCH((gemm_tn2_kernel<NT, KT, true>), g, dim3(256), 0, st, a, splits);
-  else if (g_tn2_qgrn) LAUNCH((gemm_tn2_kernel<NT, KT, false, true>), g, dim3(256), 0, st, a, splits);
+  else if (qgrn) LAUNCH((gemm_tn2_kernel<NT, KT, false, true>), g, dim3(256), 0, st, a, splits);
   else LAUNCH((gemm_tn2_kernel<NT, KT, false>), g, dim3(256), 0, st, a, splits);
 }
 
@@ -1034,7 +1028,7 @@ static int launch_wgrad_tn3(WgradP a, bool swap, hipStream_t st) {
   return launch_status();
 }
 
-static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
+static int launch_wgrad_tn2(WgradP a, hipStream_t st, bool qgrn) {
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   const bool swap = a.Kk < a.Nn;
   const int WX = swap ? a.Kk : a.Nn, WY = swap ? a.Nn : a.Kk;
@@ -1060,9 +1054,9 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   int rps = cdiv(cdiv(a.M, splits), 32) * 32;
   a.rows_per_split = rps;
   splits = cdiv(a.M, rps);
-  if (nt == 3) launch_tn2<3, 3>(a, swap, splits, st);
-  else if (nt == 5) launch_tn2<5, 5>(a, swap, splits, st);
-  else launch_tn2<4, 4>(a, swap, splits, st);
+  if (nt == 3) launch_tn2<3, 3>(a, swap, splits, st, qgrn);
+  else if (nt == 5) launch_tn2<5, 5>(a, swap, splits, st, qgrn);
+  else launch_tn2<4, 4>(a, swap, splits, st, qgrn);
   const int nk = a.Nn * a.Kk;
   if (a.sn == a.Kk && a.sk == 1) {               // contiguous dW: weights and bias fold in one launch
     launch_reduce(3, a.ws, splits, nk + a.Nn, a.dW, a.db, nk, 0, 0, 0, st);
@@ -1073,10 +1067,10 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st) {
   return launch_status();
 }
 
-static int launch_wgrad_fast(WgradP a, hipStream_t st) {
+static int launch_wgrad_fast(WgradP a, hipStream_t st, bool qgrn) {
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
   if (!a.ws || a.ws_floats < per) return (int)hipErrorInvalidValue;
-  if (tn2_ok(a)) return launch_wgrad_tn2(a, st);
+  if (tn2_ok(a)) return launch_wgrad_tn2(a, st, qgrn);
   const int tiles = cdiv(a.Nn, 128) * cdiv(a.Kk, 128);
   int splits = cdiv(512, tiles);                 // ~2 workgroups per CU
   if (splits > 128) splits = 128;               // bound the second-stage reduction
