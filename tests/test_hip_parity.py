@@ -148,6 +148,41 @@ def test_bf16_step_within_stated_tolerance(name):
             assert cs >= 0.99, (k, cs)
 
 
+@pytest.mark.parametrize("N,dead_sample,ratio", [(1, None, 0.6), (3, 1, 0.6), (2, 0, 0.9), (2, None, 0.05)])
+def test_edge_batches_against_the_oracle(N, dead_sample, ratio):
+    """Edges of the row geometry: a one-image batch; a sample whose Sentinel-2 tile is all zero (every row of its visible patches
+    inactive: the encoder sees nothing of it, the fused stem kernel / activity maps / persistent stage kernels must write zeros); very
+    few (keep = 4) and nearly all (keep = 46, beyond the persistent kernels' per-sample row budget: per-block fallback) visible
+    patches. fp32 mode to the fp32 bound, bf16 mode to the stated bf16 bounds on losses and the flat gradient."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg(mask_ratio=ratio)
+    sd = make_state_dict(cfg, seed=91)
+    inputs, noise = make_inputs(cfg, N, seed=92)
+    if dead_sample is not None:
+        inputs["sentinel2"][dead_sample] = 0.0
+    (loss, pred, mask, loss_dict, log_vars, weighted), taps, grads = _oracle(cfg, sd, inputs, noise)
+    ref = np.array([v.item() for v in loss_dict.values()])
+    flat_o = torch.cat([grads[k].reshape(-1) for k in sd])
+    for dtype, ltol, ttol, cos_min in (("f32", 1e-4, 1e-4, 0.99999), ("bf16", 2e-2, 1e-2, 0.999)):
+        eng = _engine(cfg, N, dtype, sd, inputs, noise)
+        eng.forward()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.mask.cpu(), mask)
+        assert int((eng.mask == 0).sum(1).min()) == int((eng.mask == 0).sum(1).max()) == eng.keep == int(49 * (1 - ratio))
+        got = np.array(eng.losses.tolist())
+        assert np.all(np.abs(got - ref) <= ltol * np.abs(ref) + 1e-6), (dtype, got, ref)
+        assert abs(eng.total.item() - loss.item()) <= ttol * abs(loss.item()), dtype
+        flat_e = torch.cat([eng.grads[k].cpu().reshape(-1) for k in sd])
+        assert torch.isfinite(flat_e).all()
+        cs = torch.nn.functional.cosine_similarity(flat_e.double(), flat_o.double(), dim=0).item()
+        assert cs >= cos_min, (dtype, cs)
+        if dead_sample is not None:       # nothing of the dead sample reaches the encoder output
+            enc = eng.dense_map(eng.enc_out, cfg.dims[3], 3)
+            assert float(enc[dead_sample].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_full_batch_256_against_the_oracle(dtype):
     """BASELINE configs[1] at its stated size (all_mod atto 56/8, 256 tiles) against oracle.mpmae_ref on the same seeded
