@@ -503,6 +503,15 @@ int mpmae_program_begin_op(MpmaeProgram* p, int lane, const int* waits, int nwai
 int mpmae_program_end(MpmaeProgram* p);
 int mpmae_program_num_ops(const MpmaeProgram* p);
 int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_stream);
+/* Hardware queues. ROCm maps HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, balancing by stream count; streams that
+ * share a queue are serialised. A side lane that lands on the main stream's queue costs the whole overlap of the backward (measured
+ * 5.4 instead of 4.4 ms per step, and which streams collide depends on how many streams torch / RCCL created earlier). run() therefore
+ * PROBES its side lanes at the first replay against a given main stream (two 30 us spin kernels started together: ~50 us when the
+ * streams are concurrent, ~80 us on a shared queue) and replaces a colliding lane by a freshly created stream - one host
+ * synchronisation, once per (program, main stream). mpmae_program_stream_overlaps() applies the same probe to a stream OUTSIDE the
+ * program (gradient-exchange stream, input-stage stream) against the main stream and every side lane: 1 = concurrent with all of them,
+ * 0 = shares a queue with one (the caller creates another stream and asks again), < 0 = -(hipError). */
+int mpmae_program_stream_overlaps(MpmaeProgram* p, mpmae_stream_t main_stream, mpmae_stream_t other);
 /* Hand an op's `signal` event to a stream outside the program (the gradient exchange waits for "bucket ready" points of a backward that
  * is replayed as ONE run() call): export_signal keeps the event recorded although no op of the program waits for it (call after
  * mpmae_program_end); stream_wait makes `stream` wait for the event as recorded by the most recent run() (no-op if that run did not

@@ -231,6 +231,7 @@ SYMBOLS = {
     "mpmae_program_export_signal": [c_void_p, c_int],
     "mpmae_program_stream_wait": [c_void_p, c_int, c_void_p],
     "mpmae_program_run": [c_void_p, c_int, c_int, c_void_p],
+    "mpmae_program_stream_overlaps": [c_void_p, c_void_p, c_void_p],
     "mpmae_memset_async": [c_void_p, c_int, c_size_t, c_void_p],
     "mpmae_memcpy_h2d_async": [c_void_p, c_void_p, c_size_t, c_void_p],
 }

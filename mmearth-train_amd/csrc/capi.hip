@@ -51,6 +51,8 @@ struct MpmaeProgram {
   int nlanes = 1;
   std::vector<int> sig_op, sig_lane;      // by signal id: index / lane of the op that records it (program_end)
   std::vector<char> waited;               // by signal id: some op of another lane waits for it
+  hipStream_t lanes_checked_for = nullptr;   // main stream the side lanes were last checked against (see lanes_overlap_check)
+  bool lanes_checked = false;
 };
 static thread_local MpmaeProgram* g_rec = nullptr;
 
@@ -1615,12 +1617,105 @@ int mpmae_program_stream_wait(MpmaeProgram* p, int signal, mpmae_stream_t stream
   return hipStreamWaitEvent(S_(stream), p->events[signal], 0) == hipSuccess ? 0 : (int)hipGetLastError();
 }
 
+// ---- a side lane must not share the main stream's HARDWARE queue ------------------------------------------------------------------
+// ROCm maps HIP streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues round-robin in creation order; streams that land on the
+// same queue are serialised. Whether the weight-gradient lane overlaps with the main lane therefore depended on how many streams
+// torch / RCCL had created before the program: measured 4.38 ms per step when the lanes sat on different queues and 5.38 ms when a
+// one-rank RCCL communicator had shifted the side lane onto the main stream's queue (kernel trace: both lanes on queue 4). At the
+// first replay against a given main stream every side lane is therefore PROBED - two 30 us spin kernels, one per stream, started
+// together: concurrent streams finish in ~30 us, a shared queue in ~60 - and a lane that does not overlap is replaced by a freshly
+// created stream (the next queue in the rotation), up to eight times. One host synchronisation, once per (program, main stream).
+__global__ void lane_probe_spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// elapsed time (us) of one spin on `main` [+ one on `side`, started together]; < 0 on any runtime error
+static float lane_probe_us(hipStream_t main, hipStream_t side, hipEvent_t e0, hipEvent_t e1, hipEvent_t es) {
+  const unsigned long long ticks = 3000;                                // 30 us
+  if (hipStreamSynchronize(main) != hipSuccess || (side && hipStreamSynchronize(side) != hipSuccess)) return -1.f;
+  if (hipEventRecord(e0, main) != hipSuccess || (side && hipStreamWaitEvent(side, e0, 0) != hipSuccess)) return -1.f;
+  hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, main, ticks);
+  if (side) {
+    hipLaunchKernelGGL(lane_probe_spin_kernel, dim3(1), dim3(64), 0, side, ticks);
+    if (hipEventRecord(es, side) != hipSuccess || hipStreamWaitEvent(main, es, 0) != hipSuccess) return -1.f;
+  }
+  if (hipEventRecord(e1, main) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.f;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+  return ms * 1e3f;
+}
+
+static bool lane_overlaps(hipStream_t main, hipStream_t side, hipEvent_t e0, hipEvent_t e1, hipEvent_t es, float alone_us) {
+  const float both = lane_probe_us(main, side, e0, e1, es);
+  if (getenv("MPMAE_LANE_DEBUG")) fprintf(stderr, "[lane probe] side %p: alone %.1f us, with the side lane %.1f us\n", (void*)side, alone_us, both);
+  return both < 0.f || both < alone_us + 33.f;      // measured: +19 us (the cross-stream event) when concurrent, +48 us on a shared hardware queue
+}
+
+static void lanes_overlap_check(MpmaeProgram* p, hipStream_t main) {
+  p->lanes_checked = true;
+  p->lanes_checked_for = main;
+  hipEvent_t e0 = nullptr, e1 = nullptr, es = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  std::vector<hipStream_t> rejected;
+  (void)lane_probe_us(main, nullptr, e0, e1, es);
+  float alone = lane_probe_us(main, nullptr, e0, e1, es);
+  for (int i = 0; i < 2; ++i) { const float t = lane_probe_us(main, nullptr, e0, e1, es); if (t > 0.f && t < alone) alone = t; }
+  if (alone > 0.f) {
+    for (auto& lane : p->side) {
+      (void)lane_probe_us(main, lane, e0, e1, es);                     // warm-up (the first launch on a new stream creates its queue)
+      for (int attempt = 0; attempt < 8 && !lane_overlaps(main, lane, e0, e1, es, alone); ++attempt) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+        rejected.push_back(lane);                                       // kept alive until the end: the rotation must move on
+        lane = s;
+        (void)lane_probe_us(main, lane, e0, e1, es);
+      }
+    }
+  }
+  for (auto s : rejected) (void)hipStreamDestroy(s);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(es);
+  (void)hipGetLastError();
+}
+
+// `other` (a stream outside the program: the gradient-exchange stream, the input-stage stream) against the main stream and every side lane
+int mpmae_program_stream_overlaps(MpmaeProgram* p, mpmae_stream_t main_, mpmae_stream_t other_) {
+  if (!p || g_rec) return -(int)hipErrorInvalidValue;
+  hipStream_t main = S_(main_), other = S_(other_);
+  if (other == main) return 0;
+  if (!p->side.empty() && (!p->lanes_checked || p->lanes_checked_for != main)) lanes_overlap_check(p, main);
+  hipEvent_t e0 = nullptr, e1 = nullptr, es = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess)
+    return -(int)hipGetLastError();
+  int ok = 1;
+  std::vector<hipStream_t> against{main};
+  for (auto s : p->side) against.push_back(s);
+  for (auto a : against) {
+    (void)lane_probe_us(a, nullptr, e0, e1, es);
+    float alone = lane_probe_us(a, nullptr, e0, e1, es);
+    const float t = lane_probe_us(a, nullptr, e0, e1, es);
+    if (t > 0.f && t < alone) alone = t;
+    (void)lane_probe_us(a, other, e0, e1, es);
+    if (alone > 0.f && !lane_overlaps(a, other, e0, e1, es, alone)) ok = 0;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(es);
+  (void)hipGetLastError();
+  return ok;
+}
+
 int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main_) {
   if (!p || g_rec || first < 0 || count < 0 || first + count > (int)p->ops.size()) return (int)hipErrorInvalidValue;
   hipStream_t main = S_(main_);
   bool lanes = false;
   for (int i = first; i < first + count; ++i) lanes |= p->ops[i].lane != 0;
   ++p->run;
+  if (lanes && (!p->lanes_checked || p->lanes_checked_for != main)) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) lanes_overlap_check(p, main);
+  }
   if (lanes) {                                   // fork the side lanes from the main stream
     if (hipEventRecord(p->fork, main) != hipSuccess) return (int)hipGetLastError();
     for (auto s : p->side) if (hipStreamWaitEvent(s, p->fork, 0) != hipSuccess) return (int)hipGetLastError();

@@ -20,6 +20,7 @@ joins the side lane first). Averaging (1/world) is folded into the AdamW kernel'
 torch.bfloat16` sends the buckets as bf16 (half the xGMI bytes; the sum then carries bf16 rounding). With HIP
 graphs the forward, every backward segment and the optimizer are separate captured graphs.
 """
+import ctypes
 import os
 
 import torch
@@ -35,7 +36,11 @@ def init(backend="nccl", local_rank=0):
     kw = {}
     if backend == "nccl":
         torch.cuda.set_device(local_rank)
-        kw["device_id"] = torch.device("cuda", local_rank)
+        # eager communicator binding only when there is someone to talk to: on ROCm 7 / torch 2.10 a ONE-rank group created with
+        # device_id makes the plain (no-exchange) step 1.0 ms slower (5.38 vs 4.38 ms, tools/exchange_cost_probe.py); the N > 1
+        # path - exchange on - runs at 4.55 ms per rank with it and keeps it (no lazy-init stalls at the first collective)
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            kw["device_id"] = torch.device("cuda", local_rank)
     dist.init_process_group(backend=backend, init_method="env://", **kw)
 
 
@@ -133,6 +138,25 @@ class _EventWork:
 
 
 # ----------------------------------------------------------------------------- step runner
+def pick_concurrent_stream(engine, prog, tries=8):
+    """A new torch stream that runs CONCURRENTLY with the current (main) stream and with the side lanes of `prog`: ROCm balances HIP
+    streams over GPU_MAX_HW_QUEUES (default 4) hardware queues and serialises streams that share one - an exchange stream on the main
+    lane's queue parks its bucket waits in front of the main lane's kernels (measured 7-8 ms per step instead of 4.6). Candidates are
+    probed by mpmae_program_stream_overlaps (include/mpmae_hip.h); rejected ones stay alive until the choice is made, so that the
+    runtime's stream-count balancing moves on to another queue."""
+    main = torch.cuda.current_stream(engine.device)
+    cands = []
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=engine.device)
+        cands.append(s)
+        if prog is None:
+            break
+        ok = engine.lib.mpmae_program_stream_overlaps(prog, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(s.cuda_stream))
+        if ok != 0:              # 1 = concurrent; < 0 = the probe itself failed: take the stream as it is
+            break
+    return cands[-1]
+
+
 class StepRunner:
     """Runs pretraining micro-steps of an Engine: forward, backward (+ overlapped bucketed
     all-reduce when world_size > 1), AdamW. mode "program" records the step once into a native
@@ -162,8 +186,7 @@ class StepRunner:
         self.graph_mode = "eager"
         self.buckets = plan_buckets(engine.offsets, engine.n_params) if self.exchange else []
         self.segments = split_bwd_segments(engine.bwd_ops) if self.exchange else [engine.bwd_ops]
-        self.comm_stream = (torch.cuda.Stream(device=engine.device)
-                            if self.exchange and engine.device.type == "cuda" else None)
+        self.comm_stream = None             # created behind the program (below): it must not share a hardware queue with a lane
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
         # optional low-precision exchange: one staging buffer per bucket in the wire dtype
         self.wire = ([torch.empty(hi - lo, dtype=allreduce_dtype, device=engine.device) for lo, hi in self.buckets]
@@ -191,7 +214,7 @@ class StepRunner:
             # overlap "events" (default): the whole backward is ONE replay call and the communication stream waits for the
             # per-bucket "ready" events of the program; "segments": one replay call per bucket, each joining the side lane first
             self.bucket_signals = []
-            if self.exchange and overlap == "events" and self.comm_stream is not None:
+            if self.exchange and overlap == "events" and engine.device.type == "cuda":
                 for keys in engine._bucket_keys:
                     sig = [engine._program_ids[k] for k in keys]
                     for i_ in sig:
@@ -199,6 +222,9 @@ class StepRunner:
                     self.bucket_signals.append(sig)
         elif mode == "hipgraph":
             self._capture()
+        if self.exchange and engine.device.type == "cuda" and self.comm_stream is None:
+            self.comm_stream = pick_concurrent_stream(engine, self.prog)
+
 
     # -- program pieces (all enqueue on the current stream)
     def _fwd(self):

@@ -1622,7 +1622,9 @@ class Engine:
                 yield
                 return
             if not hasattr(self, "_in_stream"):
-                self._in_stream = torch.cuda.Stream(device=self.device)
+                # (not on a hardware queue of the main stream or of a lane: dist.pick_concurrent_stream)
+                from . import dist as _mdist
+                self._in_stream = _mdist.pick_concurrent_stream(self, getattr(runner, "prog", None) if runner is not None else None)
             main, ins = torch.cuda.current_stream(self.device), self._in_stream
             prog = getattr(runner, "prog", None) if runner is not None else None
             sig = getattr(runner, "inputs_free_signal", None) if runner is not None else None
