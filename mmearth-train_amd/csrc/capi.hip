@@ -1648,7 +1648,6 @@ static float lane_probe_us(hipStream_t main, hipStream_t side, hipEvent_t e0, hi
 
 static bool lane_overlaps(hipStream_t main, hipStream_t side, hipEvent_t e0, hipEvent_t e1, hipEvent_t es, float alone_us) {
   const float both = lane_probe_us(main, side, e0, e1, es);
-  if (getenv("MPMAE_LANE_DEBUG")) fprintf(stderr, "[lane probe] side %p: alone %.1f us, with the side lane %.1f us\n", (void*)side, alone_us, both);
   return both < 0.f || both < alone_us + 33.f;      // measured: +19 us (the cross-stream event) when concurrent, +48 us on a shared hardware queue
 }
 
