@@ -510,7 +510,8 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
  * streams are concurrent, ~80 us on a shared queue) and replaces a colliding lane by a freshly created stream - one host
  * synchronisation, once per (program, main stream). mpmae_program_stream_overlaps() applies the same probe to a stream OUTSIDE the
  * program (gradient-exchange stream, input-stage stream) against the main stream and every side lane: 1 = concurrent with all of them,
- * 0 = shares a queue with one (the caller creates another stream and asks again), < 0 = -(hipError). */
+ * 0 = shares a queue with one (the caller creates another stream and asks again), < 0 = -(hipError). p == NULL: against the main stream
+ * only (the Python-loop driver's side streams). */
 int mpmae_program_stream_overlaps(MpmaeProgram* p, mpmae_stream_t main_stream, mpmae_stream_t other);
 /* Hand an op's `signal` event to a stream outside the program (the gradient exchange waits for "bucket ready" points of a backward that
  * is replayed as ONE run() call): export_signal keeps the event recorded although no op of the program waits for it (call after

@@ -1682,16 +1682,16 @@ static void lanes_overlap_check(MpmaeProgram* p, hipStream_t main) {
 
 // `other` (a stream outside the program: the gradient-exchange stream, the input-stage stream) against the main stream and every side lane
 int mpmae_program_stream_overlaps(MpmaeProgram* p, mpmae_stream_t main_, mpmae_stream_t other_) {
-  if (!p || g_rec) return -(int)hipErrorInvalidValue;
+  if (g_rec) return -(int)hipErrorInvalidValue;
   hipStream_t main = S_(main_), other = S_(other_);
   if (other == main) return 0;
-  if (!p->side.empty() && (!p->lanes_checked || p->lanes_checked_for != main)) lanes_overlap_check(p, main);
+  if (p && !p->side.empty() && (!p->lanes_checked || p->lanes_checked_for != main)) lanes_overlap_check(p, main);
   hipEvent_t e0 = nullptr, e1 = nullptr, es = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess)
     return -(int)hipGetLastError();
   int ok = 1;
   std::vector<hipStream_t> against{main};
-  for (auto s : p->side) against.push_back(s);
+  if (p) for (auto s : p->side) against.push_back(s);
   for (auto a : against) {
     (void)lane_probe_us(a, nullptr, e0, e1, es);
     float alone = lane_probe_us(a, nullptr, e0, e1, es);

@@ -149,8 +149,6 @@ def pick_concurrent_stream(engine, prog, tries=8):
     for _ in range(tries):
         s = torch.cuda.Stream(device=engine.device)
         cands.append(s)
-        if prog is None:
-            break
         ok = engine.lib.mpmae_program_stream_overlaps(prog, ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(s.cuda_stream))
         if ok != 0:              # 1 = concurrent; < 0 = the probe itself failed: take the stream as it is
             break

@@ -1544,7 +1544,8 @@ class Engine:
         if not hasattr(self, "_side_streams"):
             self._side_streams = []
         while len(self._side_streams) < nl - 1:
-            self._side_streams.append(torch.cuda.Stream(device=self.device))
+            from . import dist as _mdist      # (a stream that does not share the main stream's hardware queue)
+            self._side_streams.append(_mdist.pick_concurrent_stream(self, None))
         streams = [main] + self._side_streams[:nl - 1]
         for st in streams[1:]:
             st.wait_stream(main)                   # fork
