@@ -51,8 +51,7 @@ struct MpmaeProgram {
   int nlanes = 1;
   std::vector<int> sig_op, sig_lane;      // by signal id: index / lane of the op that records it (program_end)
   std::vector<char> waited;               // by signal id: some op of another lane waits for it
-  hipStream_t lanes_checked_for = nullptr;   // main stream the side lanes were last checked against (see lanes_overlap_check)
-  bool lanes_checked = false;
+  std::vector<hipStream_t> lanes_checked_for;   // main streams the side lanes were probed against (see lanes_overlap_check), at most 8
 };
 static thread_local MpmaeProgram* g_rec = nullptr;
 
@@ -1651,9 +1650,15 @@ static bool lane_overlaps(hipStream_t main, hipStream_t side, hipEvent_t e0, hip
   return both < 0.f || both < alone_us + 33.f;      // measured: +19 us (the cross-stream event) when concurrent, +48 us on a shared hardware queue
 }
 
+// (once per distinct main stream, and for at most 8 of them: a caller that rotates main streams is not probed - and synchronised - forever)
+static bool lanes_need_check(const MpmaeProgram* p, hipStream_t main) {
+  if (p->lanes_checked_for.size() >= 8) return false;
+  for (auto m : p->lanes_checked_for) if (m == main) return false;
+  return true;
+}
+
 static void lanes_overlap_check(MpmaeProgram* p, hipStream_t main) {
-  p->lanes_checked = true;
-  p->lanes_checked_for = main;
+  p->lanes_checked_for.push_back(main);
   hipEvent_t e0 = nullptr, e1 = nullptr, es = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
@@ -1685,7 +1690,7 @@ int mpmae_program_stream_overlaps(MpmaeProgram* p, mpmae_stream_t main_, mpmae_s
   if (g_rec) return -(int)hipErrorInvalidValue;
   hipStream_t main = S_(main_), other = S_(other_);
   if (other == main) return 0;
-  if (p && !p->side.empty() && (!p->lanes_checked || p->lanes_checked_for != main)) lanes_overlap_check(p, main);
+  if (p && !p->side.empty() && lanes_need_check(p, main)) lanes_overlap_check(p, main);
   hipEvent_t e0 = nullptr, e1 = nullptr, es = nullptr;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreateWithFlags(&es, hipEventDisableTiming) != hipSuccess)
     return -(int)hipGetLastError();
@@ -1711,7 +1716,7 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
   bool lanes = false;
   for (int i = first; i < first + count; ++i) lanes |= p->ops[i].lane != 0;
   ++p->run;
-  if (lanes && (!p->lanes_checked || p->lanes_checked_for != main)) {
+  if (lanes && lanes_need_check(p, main)) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(main, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) lanes_overlap_check(p, main);
   }
