@@ -186,7 +186,16 @@ class StepRunner:
         self.segments = split_bwd_segments(engine.bwd_ops) if self.exchange else [engine.bwd_ops]
         self.comm_stream = None             # created behind the program (below): it must not share a hardware queue with a lane
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
+        # fold_loss: the scalar loss is element n_params of the flat gradient buffer (engine.gflat_ext) and is all-reduced WITH the first
+        # bucket (the heads end the buffer; the loss exists before any gradient does) - one collective fewer at the tail of the step
+        ext = getattr(engine, "gflat_ext", None)
+        opt = getattr(engine, "opt", None)
+        self.fold_loss = False
         # optional low-precision exchange: one staging buffer per bucket in the wire dtype
+        if (self.exchange and ext is not None and allreduce_dtype in (None, torch.float32) and (opt is None or bool(opt.get("fold_loss", 1)))
+                and self.buckets and self.buckets[0][1] == engine.n_params):
+            self.fold_loss = True
+            self.loss_buf = ext[engine.n_params:engine.n_params + 1]
         self.wire = ([torch.empty(hi - lo, dtype=allreduce_dtype, device=engine.device) for lo, hi in self.buckets]
                      if allreduce_dtype not in (None, torch.float32) else None)
         self.graphs = None
@@ -291,13 +300,19 @@ class StepRunner:
         """ready=True: the communication stream already waits for the bucket (program events); otherwise it waits for the
         current stream's position."""
         lo, hi = self.buckets[b]
+        grad = self.eng.gflat[lo:hi]
+        fold = self.fold_loss and b == 0
+        if fold:                             # the heads' bucket + the loss slot behind it
+            grad = self.eng.gflat_ext[lo:hi + 1]
         if self.comm_stream is None:         # host tensors (gloo logic tests): the collective is synchronous
+            if fold:
+                self.loss_buf.copy_(self.eng.total.reshape(1))
             if self.wire is not None:
                 self.wire[b].copy_(self.eng.gflat[lo:hi])
                 dist.all_reduce(self.wire[b], op=dist.ReduceOp.SUM)
                 self.eng.gflat[lo:hi].copy_(self.wire[b])
             else:
-                dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM)
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM)
             return
         if not ready:
             ev = torch.cuda.Event()
@@ -312,7 +327,9 @@ class StepRunner:
                 ev2.record(self.comm_stream)
                 works.append(_EventWork(ev2))
             else:
-                works.append(dist.all_reduce(self.eng.gflat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                if fold:
+                    self.loss_buf.copy_(self.eng.total.reshape(1))
+                works.append(dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True))
 
     def step(self):
         """One micro-step. Returns True when it ended with an optimizer update."""
@@ -352,8 +369,9 @@ class StepRunner:
             return
         if self.exchange:
             # scalar loss all-reduce for logging (engine_pretrain.py:104), no host sync
-            self.loss_buf.copy_(eng.total)
-            works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
+            if not self.fold_loss:
+                self.loss_buf.copy_(eng.total)
+                works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
             for w in works:
                 w.wait()                     # current stream waits for the collectives
         if self.graphs:
@@ -400,8 +418,9 @@ class StepRunner:
             for i in range(nseg):
                 eng.run_program(self.prog, self._span(SEG0 + i, SEG0 + i))
                 self._launch_allreduce(i, works)
-        self.loss_buf.copy_(eng.total)
-        works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
+        if not self.fold_loss:
+            self.loss_buf.copy_(eng.total)
+            works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()
         eng.run_program(self.prog, self._span(OPT, OPT))

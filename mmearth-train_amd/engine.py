@@ -52,6 +52,7 @@ ENGINE_OPTIONS = dict(
     front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
     z_free=1,               # fused blocks: z = GRN(gelu(h)) is not stored by the forward; pwconv2's weight gradient rebuilds it from h in its operand prologue
     z_free_maxc=40,         # ... up to this width (the prologue's GELU costs the weight-gradient lane 17 us per launch; the forward saves 27 us per block at C = 40, 13 at C = 80)
+    fold_loss=1,            # data parallel: the scalar loss rides in the first gradient bucket's all-reduce (no collective of its own)
     proj_compact=1,         # proj as a plain NT GEMM on compact rows: the token kernel assembles the decoder input, its backward gathers the visible rows (no scatter / gather GEMM variants)
     zero_side=1,            # the step's zero fills (statistics, flat gradients, padded stem dW) on the side lane, ONE loss finalisation per step
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
@@ -154,13 +155,21 @@ class Engine:
         spec = flat_param_spec(self.cfg)      # state-dict order with the prediction heads regrouped (see synth.py)
         total = sum(math.prod(s) for _, s, _ in spec)
         dev = self.device
+        # gflat_ext: the flat gradient buffer + 4 floats; element `total` is the LOSS SLOT of the data-parallel exchange (dist.StepRunner
+        # all-reduces the scalar loss as one more element of the first gradient bucket - the heads, which end the flat buffer - instead
+        # of a collective of its own: 70 us per step at the tail)
         if self._ext_buffers is not None:
             self.pflat, self.gflat = self._ext_buffers
             assert self.pflat.numel() == total and self.gflat.numel() == total
             assert self.pflat.device == dev and self.pflat.dtype == torch.float32
+            st = self.gflat.untyped_storage()
+            self.gflat_ext = None
+            if self.gflat.is_contiguous() and st.nbytes() >= (self.gflat.storage_offset() + total + 1) * 4:      # the caller left room behind it
+                self.gflat_ext = torch.as_strided(self.gflat, (total + 1,), (1,))
         else:
             self.pflat = torch.zeros(total, dtype=torch.float32, device=dev)
-            self.gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.gflat_ext = torch.zeros(total + 4, dtype=torch.float32, device=dev)
+            self.gflat = self.gflat_ext[:total]
         self.mflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.vflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.decay_mask = torch.zeros(total, dtype=torch.uint8, device=dev)

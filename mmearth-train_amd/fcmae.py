@@ -138,7 +138,7 @@ class FCMAE(nn.Module):
         spec = state_dict_spec(self.cfg)
         total = sum(math.prod(s) for _, s, _ in spec)
         self._pflat = torch.zeros(total, dtype=torch.float32, device=self._device)
-        self._gflat = torch.zeros(total, dtype=torch.float32, device=self._device)
+        self._gflat = torch.zeros(total + 4, dtype=torch.float32, device=self._device)[:total]      # (+ the loss slot of the exchange, engine.gflat_ext)
         self._plist, self._poffs, views = [], [], OrderedDict()
         first = self.cfg.out_mods[0].name
         offs, off = {}, 0
