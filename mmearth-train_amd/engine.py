@@ -49,6 +49,7 @@ ENGINE_OPTIONS = dict(
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
     prep_side=1,            # weight staging of the forward on the side lane
+    prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
     front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
     z_free=1,               # fused blocks: z = GRN(gelu(h)) is not stored by the forward; pwconv2's weight gradient rebuilds it from h in its operand prologue
     z_free_maxc=40,         # ... up to this width (the prologue's GELU costs the weight-gradient lane 17 us per launch; the forward saves 27 us per block at C = 40, 13 at C = 80)
@@ -1010,8 +1011,13 @@ class Engine:
         C0, p, k = dims[0], self.p, cfg.stem_k
         # weight staging only feeds the first GEMM: on the side lane next to mask / activity / im2col (which only read the inputs)
         prep_side = self.lanes and bool(self.opt["prep_side"]) and not self.fp8
-        self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max,
-                 **(dict(lane=1, signal="prep_done") if prep_side else {}))
+        # (prep_late: issued behind the activity ops instead, see below)
+        prep_late = (prep_side and bool(self.opt["prep_late"]) and bool(self.opt["front_side"]) and self.track_activity
+                     and bool(self.opt["stem_front"]) and bool(self.opt["stem_fused"]) and bool(self.opt["stem_im2col"]) and dt != F32 and p == 8
+                     and k == 1 and C0 % 8 == 0 and C0 <= 48 and cfg.in_chans <= 12)      # (= the conditions of the fused stem kernel below)
+        if not prep_late:
+            self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max,
+                     **(dict(lane=1, signal="prep_done") if prep_side else {}))
         # the pixel-activity map and its poolings also only read the inputs (and the mask tables): with `front_side` they follow the weight
         # staging on the side lane, so the main lane goes mask -> im2col directly and the stem GEMM waits for ONE side-lane event
         front_side = prep_side and bool(self.opt["front_side"]) and self.track_activity
@@ -1028,6 +1034,8 @@ class Engine:
                 self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2, **fl)
             if front_side:
                 f[-1][3]["signal"] = "front_done"
+        if prep_late:
+            self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max, lane=1, signal="prep_done")
         wt = self.w["stem.Wt"]
         self.stem_im2col = bool(self.opt["stem_im2col"])
         self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
@@ -1102,6 +1110,8 @@ class Engine:
         x = self.x0
         bi = 0
         self._front_rest = (stem_at, rest_key) if (prep_side and self.stem_front) else None
+        self._prep_late = prep_late and self._front_rest is not None
+        assert not prep_late or self._front_rest is not None
         for i in range(4):
             if i > 0:
                 dn = self.down[i - 1]
@@ -1284,8 +1294,11 @@ class Engine:
                 self._fwd_join_keys = ["img_side_done"]
         if self._front_rest is not None:          # the first main-lane op behind the fused stem kernel waits for the rest of the side-lane front
             at, key = self._front_rest
-            nxt = next(op for op in f[at + 1:] if op[3]["lane"] == 0)
-            nxt[3]["wait"] = tuple(nxt[3]["wait"]) + (key,)
+            mains = [op for op in f[at + 1:] if op[3]["lane"] == 0]
+            mains[0][3]["wait"] = tuple(mains[0][3]["wait"]) + (key,)
+            if self._prep_late:           # the depthwise kernel reads fp32 taps; the first STAGED weight belongs to the op behind it
+                assert mains[0][0].endswith(":dw"), mains[0][0]
+                mains[1][3]["wait"] = tuple(mains[1][3]["wait"]) + ("prep_done",)
         self.loss_scale = 1.0
         lv = P.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
         glv = self.grads.get("loss_fn.log_vars") if cfg.loss_aggr == "uncertainty" else None
