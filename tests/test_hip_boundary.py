@@ -284,6 +284,31 @@ def test_rccl_exchange_runs_at_world_size_one():
         assert m and float(m.group(1)) < 1e-5, r.stdout
 
 
+def test_lanes_and_outside_streams_are_probed_for_shared_hardware_queues():
+    """ROCm serialises HIP streams that share a hardware queue. The launch program probes its side lanes against the main stream at the
+    first replay (and replaces a colliding lane); mpmae_program_stream_overlaps answers the same question for a stream outside the program.
+    Whatever the runtime's queue assignment in this process: a stream never 'overlaps' with itself, the stream picked for the gradient
+    exchange does overlap with the main stream and the lanes, and the program still steps after the probes."""
+    import ctypes as C
+    from mmearth_train_amd import dist as mdist
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], "bf16", sd, inputs, noise)
+    run = mdist.StepRunner(eng, world_size=1, lr=1e-4, mode="program")
+    run.step()
+    torch.cuda.synchronize()
+    main = torch.cuda.current_stream()
+    ms = C.c_void_p(main.cuda_stream)
+    assert eng.lib.mpmae_program_stream_overlaps(run.prog, ms, ms) == 0
+    s = mdist.pick_concurrent_stream(eng, run.prog)
+    assert eng.lib.mpmae_program_stream_overlaps(run.prog, ms, C.c_void_p(s.cuda_stream)) == 1
+    assert eng.lib.mpmae_program_stream_overlaps(None, ms, C.c_void_p(s.cuda_stream)) == 1
+    run.step()                      # the program still runs after the probes (which synchronise and launch on its lanes)
+    torch.cuda.synchronize()
+    assert torch.isfinite(eng.total).all()
+
+
 def test_bench_gpus_flag_starts_ranks_or_fails_loudly():
     """`python bench.py --gpus N` outside a launcher spawns N ranks itself; on a node with fewer GPUs it must refuse (exit code 2 and
     a message), not run one rank and print n_gpus: 1."""
