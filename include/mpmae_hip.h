@@ -321,6 +321,13 @@ int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream
 /* weight + bias gradients of the same layers (autograd of the reference ops). */
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits,
                 mpmae_stream_t stream);
+/* The same gradients for `count` layers of IDENTICAL shape in one launch + one fold: all pwconv1 / pwconv2 weight gradients of
+ * an encoder stage (autograd of MinkowskiLinear, models/convnextv2_sparse.py:41-43,51-53), whose operands persist until the stage's
+ * data-gradient chain is done. probs[i] as for mpmae_wgrad with no prologues (its ws / ws_floats are ignored); ws: fp32 scratch
+ * for the per-split partial slabs of ALL problems. bf16, widths that are multiples of 80 (C = 80: 4C % 320 == 0; else C % 160 == 0),
+ * contiguous dW: the grouped DMA-ring kernel (gemm_tng.cuh); anything else: count calls of mpmae_wgrad (same results). */
+int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws, size_t ws_floats,
+                      mpmae_stream_t stream);
 
 /* ---- MX-fp8 pointwise path (BASELINE configs[4]: "fp8 MFMA pointwise path") ------------------
  * The nn.Linear / 1x1-conv layers with K % 128 == 0 (decoder Block pwconv1/2 forward and data gradient,
@@ -365,6 +372,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80: 0 = two row tiles per wave, otherwise one */
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
   MPMAE_OPT_TN3_BLOCKS,   /* default 256: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2) */
+  MPMAE_OPT_TNG_BLOCKS,   /* default 512: target workgroup count of the GROUPED weight-gradient kernel (gemm_tng.cuh; 0 = one mpmae_wgrad per problem) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

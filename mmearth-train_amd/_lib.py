@@ -106,6 +106,7 @@ class RsArgs(C.Structure):
 
 
 PS_MAXBLK = 9          # MPMAE_PS_MAXBLK
+TNG_MAXP = 20          # problems per mpmae_wgrad_group launch (csrc/gemm_tng.cuh)
 
 
 class PsBlock(C.Structure):
@@ -159,7 +160,7 @@ class StemFrontArgs(C.Structure):
                 ("track_activity", c_int)]
 
 
-OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS".split())}      # enum MpmaeOption (include/mpmae_hip.h)
+OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 
@@ -176,6 +177,7 @@ SYMBOLS = {
     "mpmae_prep_weights": [c_int, c_void_p, c_int, c_int, c_void_p],
     "mpmae_gemm": [c_int, c_int, c_int, P(GemmArgs), c_void_p],
     "mpmae_wgrad": [c_int, c_int, c_int, P(WgradArgs), c_int, c_void_p],
+    "mpmae_wgrad_group": [c_int, P(WgradArgs), c_int, c_void_p, c_size_t, c_void_p],
     "mpmae_ln_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                      c_int, c_int, c_void_p, c_void_p],
     "mpmae_ln_bwd": [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

@@ -18,6 +18,7 @@
 #include "dwband.cuh"
 #include "ps.cuh"
 #include "gemm_tn3.cuh"
+#include "gemm_tng.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -123,6 +124,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC_N80 */ 1,
     /* MPMAE_OPT_STB_BLOCKS */ 512,
     /* MPMAE_OPT_TN3_BLOCKS */ 256,
+    /* MPMAE_OPT_TNG_BLOCKS */ 512,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -246,6 +248,96 @@ int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int spli
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, S_(s));
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, S_(s));
   return launch_status();
+}
+
+// Grouped weight gradients (gemm_tng.cuh): count problems of one shape, one launch + one fold.
+template <int RX, int RY, int NST>
+static int launch_tng(const TngP& g, int blocks, hipStream_t st) {
+  using Cf = TngCfg<RX, RY, NST>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_tng_kernel<RX, RY, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
+      return (int)hipGetLastError();
+    attr = true;
+  }
+  LAUNCH((gemm_tng_kernel<RX, RY, NST>), dim3(blocks), dim3(256), Cf::LDS, st, g);
+  return 0;
+}
+
+static bool tng_ok(int dt, const WgradP* pr, int count, int* WX_, int* WY_) {
+  if (dt != 1 || count < 1 || count > TNG_MAXP || g_opt[MPMAE_OPT_TNG_BLOCKS] <= 0) return false;
+  const int WX = pr[0].Nn < pr[0].Kk ? pr[0].Nn : pr[0].Kk, WY = pr[0].Nn < pr[0].Kk ? pr[0].Kk : pr[0].Nn;
+  if (!((WX == 80 && WY % 320 == 0) || (WX % 160 == 0 && WY % 160 == 0))) return false;
+  if (((size_t)WX * WY + WY) % 4 || ((size_t)WX * WY + WX) % 4) return false;
+  for (int i = 0; i < count; ++i) {
+    const WgradP& a = pr[i];
+    const int wx = a.Nn < a.Kk ? a.Nn : a.Kk, wy = a.Nn < a.Kk ? a.Kk : a.Nn;
+    if (wx != WX || wy != WY || a.M != pr[0].M || a.M < 1) return false;
+    if (a.P2 || a.pp0 || a.pp1 || a.qp0 || a.qp1 || !a.P || !a.Q || !a.dW) return false;
+    if (a.sn != a.Kk || a.sk != 1) return false;
+    if ((a.ldp | a.ldq) & 7) return false;
+    if (((uintptr_t)a.P | (uintptr_t)a.Q) & 15) return false;
+    if (a.ldp < a.Nn || a.ldq < a.Kk) return false;
+  }
+  *WX_ = WX; *WY_ = WY;
+  return true;
+}
+
+int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws, size_t ws_floats, mpmae_stream_t s) {
+  if (!probs || count < 1 || !ws) return (int)hipErrorInvalidValue;
+  int WX = 0, WY = 0;
+  if (!tng_ok(dt, probs, count, &WX, &WY)) {            // one call per problem (each with the scratch given here)
+    for (int i = 0; i < count; ++i) {
+      MpmaeWgradArgs a = probs[i];
+      a.ws = ws; a.ws_floats = ws_floats;
+      const int tiles = cdiv(a.Nn, 64) * cdiv(a.Kk, 64);
+      int splits = cdiv(768, tiles);
+      if (splits > cdiv(a.M, 256)) splits = cdiv(a.M, 256);
+      const int err = mpmae_wgrad(dt, PRO_NONE, PRO_NONE, &a, splits < 1 ? 1 : splits, s);
+      if (err) return err;
+    }
+    return 0;
+  }
+  const int M = probs[0].M;
+  const bool narrow = WX == 80;                         // (1, 4) regions: 80 x 320 tile; else (2, 2): 160 x 160
+  const int xt = narrow ? 1 : WX / 160, yt = narrow ? WY / 320 : WY / 160;
+  const size_t per_max = (size_t)WX * WY + WY;          // slab stride: the larger of the two bias lengths
+  int splits = g_opt[MPMAE_OPT_TNG_BLOCKS] / (count * xt * yt);
+  const int maxs = M / (8 * TNG_SL);                    // >= 8 k-steps per split
+  if (splits > maxs) splits = maxs;
+  if (splits >= 8) splits -= splits % 8;                // one row range per XCD
+  if ((size_t)splits * count * per_max > ws_floats) splits = (int)(ws_floats / ((size_t)count * per_max));
+  if (splits < 1) splits = 1;
+  if ((size_t)count * per_max > ws_floats) return (int)hipErrorInvalidValue;
+  const int rps = cdiv(cdiv(M, splits), TNG_SL) * TNG_SL;
+  splits = cdiv(M, rps);
+  TngP g;
+  TngFoldP f;
+  g.nprob = count; g.M = M; g.WX = WX; g.WY = WY; g.rps = rps; g.splits = splits; g.xt = xt; g.yt = yt;
+  f.nprob = count; f.splits = splits;
+  size_t maxper = 0;
+  for (int i = 0; i < count; ++i) {
+    const WgradP& a = probs[i];
+    const bool swap = a.Kk < a.Nn;                      // X = Q (pwconv1: P = dh is the wide operand)
+    TngProb& p = g.p[i];
+    p.X = reinterpret_cast<const bf16_t*>(swap ? a.Q : a.P);
+    p.Y = reinterpret_cast<const bf16_t*>(swap ? a.P : a.Q);
+    p.ldx = swap ? a.ldq : a.ldp; p.ldy = swap ? a.ldp : a.ldq;
+    p.slab = ws + (size_t)i * splits * per_max;
+    p.swap = swap ? 1 : 0; p.want_db = a.db ? 1 : 0;
+    const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
+    f.p[i].slab = p.slab; f.p[i].dW = a.dW; f.p[i].db = a.db; f.p[i].nk = a.Nn * a.Kk; f.p[i].per = (int)per;
+    if (per > maxper) maxper = per;
+  }
+  const int blocks = count * xt * yt * splits;
+  int err;
+  if (narrow) err = launch_tng<1, 4, 3>(g, blocks, S_(s));
+  else err = launch_tng<2, 2, 3>(g, blocks, S_(s));
+  if (err) return err;
+  int fb = cdiv((long long)(maxper / 4), 256);
+  if (fb > 256) fb = 256;
+  LAUNCH(wgrad_group_fold_kernel, dim3(fb, count), dim3(256), 0, S_(s), f);
+  RET();
 }
 
 // ------------------------------------------------------------------------------------------

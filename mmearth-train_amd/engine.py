@@ -67,6 +67,7 @@ ENGINE_OPTIONS = dict(
     grn_fold_minc=0,        # smallest C with folded GRN finalisation
     hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
     dzr_maxc=80,            # largest C recomputing dz
+    wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
 )
 
 
@@ -499,6 +500,44 @@ class Engine:
         self._wgrad(lst, name, ppro, qpro, lane=1, wait=(k,) if k else (), signal=key, **kw)
         self._side_read(key, *reads)
 
+    # -- grouped weight gradients (mpmae_wgrad_group): the pointwise weight gradients of a stage's blocks are collected while the
+    # stage's data-gradient chain is built and issued as ONE side-lane op behind it (their operands persist: one ring slot per block)
+    def _group_ok(self, blk, qpro):
+        return (self.lanes and bool(self.opt["wgrad_group"]) and self.dt == BF16 and blk["sparse"] and qpro == "NONE"
+                and blk["C"] in (80, 160, 320) and blk["H"] == 4 * blk["C"])
+
+    def _group_add(self, lst, name, reads, **kw):
+        if not hasattr(self, "_group_pending"):
+            self._group_pending = []
+        self._group_pending.append((name, list(reads), kw))
+        # a ring slot is reused every len(ring) blocks: flush before a later block of the same stage could overwrite an operand
+        if len(self._group_pending) >= 2 * min(_lib.TNG_MAXP // 2, max(1, min(len(self.scr_dz2), len(self.scr_dx)) - 2)):
+            self._group_flush(lst)
+
+    def _group_flush(self, lst):
+        pend = getattr(self, "_group_pending", [])
+        if not pend:
+            return
+        self._group_pending = []
+        arr = (_lib.WgradArgs * len(pend))()
+        nbytes = flops = 0
+        for i, (_, _, kw) in enumerate(pend):
+            a = arr[i]
+            for k, v in kw.items():
+                setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+            a.rpg = max(int(a.M), 1)
+            nbytes += int(a.M) * (int(a.Nn) + int(a.Kk)) * 2 + int(a.Nn) * int(a.Kk) * 4
+            flops += 2 * int(a.M) * int(a.Nn) * int(a.Kk)
+        self._keepalive.append(arr)
+        stage = pend[0][0].split(":")[0].rsplit(".", 1)[0]          # "encoder.stages.2"
+        k = self._after(lst)
+        self._evseq += 1
+        key = f"s{self._evseq}"
+        self._op(lst, f"{stage}:pw.wgrad[{len(pend)}]", self.lib.mpmae_wgrad_group, self.dt, arr, len(pend), _p(self.ws2), self.ws_floats,
+                 kind="wgrad_group", nbytes=nbytes, flops=flops, lane=1, wait=(k,) if k else (), signal=key)
+        for _, reads, _ in pend:
+            self._side_read(key, *reads)
+
     def _write_waits(self, *tensors):
         """Event keys a main-lane op must wait for before overwriting these scratch tensors."""
         keys = []
@@ -899,7 +938,10 @@ class Engine:
         if blk.get("z_free"):
             w2_args.update(Q=blk["h"], qp0=blk["scale"], qp1=P[nm["gb"]])
             w2_qpro = "GRN"
-        if not late_w2 and not late_all:
+        grouped = self._group_ok(blk, w2_qpro)
+        if grouped:
+            self._group_add(lst, tag + ":pw2.wgrad", [dout], **w2_args)
+        elif not late_w2 and not late_all:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
         if not blk["sparse"] and not self.grouped_epi:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
@@ -934,17 +976,19 @@ class Engine:
             self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
                        ldb=w1t["ld"], ldc=Cc)
         self._guard(lst, dd)
-        if late_w2:
+        if late_w2 and not grouped:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
         w1_args = dict(P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        if not late_all:
+        if grouped:
+            self._group_add(lst, tag + ":pw1.wgrad", [dz], **w1_args)
+        elif not late_all:
             self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         if rs_n is None:
             self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
             self._guard(lst, dd)
-        if late_all:
+        if late_all and not grouped:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
             self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         self._dw_bwd(lst, blk, dd, dout, dx)
@@ -1459,6 +1503,7 @@ class Engine:
                 other = ring[ri]
                 cur = nxt
                 bi -= 1
+            self._group_flush(b)          # the stage's grouped pointwise weight gradients: side lane, behind its data-gradient chain
             if i > 0:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"

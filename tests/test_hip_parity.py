@@ -323,6 +323,42 @@ def test_weight_gradient_kernel_matches_fp32_matmul(M, N, K):
     assert _rel(db, Pm.float().sum(0)) < 2e-5
 
 
+@pytest.mark.parametrize("M,C_,count", [(19456, 160, 12), (4864, 320, 4), (9728, 80, 4), (152, 160, 12), (38, 320, 3), (1203, 80, 2),
+                                        (777, 160, 20), (640, 96, 4), (4864, 160, 1)])
+def test_grouped_weight_gradients_match_fp32_matmul(M, C_, count):
+    """mpmae_wgrad_group (gemm_tng.cuh: all pwconv1 / pwconv2 weight gradients of a stage in one DMA-ring launch + one fold): problems
+    alternate between the two operand orders (pwconv2: [C] x [4C], pwconv1: [4C] x [C]); dW += P^T Q and db += column sums of P against
+    torch fp32 on the same bf16 values, on top of a non-zero gradient buffer (the entry point accumulates). Covers the stage shapes at
+    bs 256 / 64, ragged row counts (not a multiple of the 32-row k-step, fewer rows than one k-step per split), the problem-count limit
+    and a width the grouped kernel does not take (96: one mpmae_wgrad per problem, same results)."""
+    import ctypes as C
+    from mmearth_train_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + C_ + count)
+    H = 4 * C_
+    arr = (_lib.WgradArgs * count)()
+    keep, want = [], []
+    for i in range(count):
+        Nn, Kk = (C_, H) if i % 2 == 0 else (H, C_)
+        Pm = torch.randn(M, Nn, device="cuda").to(torch.bfloat16)
+        Qm = torch.randn(M, Kk, device="cuda").to(torch.bfloat16)
+        dW = torch.randn(Nn, Kk, device="cuda")
+        db = torch.randn(Nn, device="cuda")
+        want.append((dW + Pm.float().t() @ Qm.float(), db + Pm.float().sum(0)))
+        a = arr[i]
+        a.P, a.Q, a.M, a.Nn, a.Kk, a.ldp, a.ldq = Pm.data_ptr(), Qm.data_ptr(), M, Nn, Kk, Nn, Kk
+        a.dW, a.sn, a.sk, a.db = dW.data_ptr(), Kk, 1, (db.data_ptr() if i % 3 != 2 else 0)
+        keep.append((Pm, Qm, dW, db))
+    ws = torch.empty(32 << 20, dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.mpmae_wgrad_group(1, arr, count, C.c_void_p(ws.data_ptr()), ws.numel(), st) == 0
+    torch.cuda.synchronize()
+    for i, ((_, _, dW, db), (wW, wb)) in enumerate(zip(keep, want)):
+        assert _rel(dW, wW) < 2e-5, (i, _rel(dW, wW))
+        if i % 3 != 2:
+            assert _rel(db, wb) < 2e-5, (i, _rel(db, wb))
+
+
 @pytest.mark.parametrize("M,N,K", [(4864, 40, 160), (3001, 80, 320), (2048, 160, 640), (1000, 96, 384)])
 def test_weight_gradient_with_grn_prologue_matches_fp32(M, N, K):
     """pwconv2's weight gradient from h instead of a stored z (mpmae_wgrad, Q prologue MPMAE_PRO_GRN on the transpose-read kernel):
