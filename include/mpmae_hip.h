@@ -325,7 +325,7 @@ int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int spli
  * an encoder stage (autograd of MinkowskiLinear, models/convnextv2_sparse.py:41-43,51-53), whose operands persist until the stage's
  * data-gradient chain is done. probs[i] as for mpmae_wgrad with no prologues (its ws / ws_floats are ignored); ws: fp32 scratch
  * for the per-split partial slabs of ALL problems. bf16, widths that are multiples of 80 (C = 80: 4C % 320 == 0; else C % 160 == 0),
- * contiguous dW: the grouped DMA-ring kernel (gemm_tng.cuh); anything else: count calls of mpmae_wgrad (same results). */
+ * any dW strides: the grouped DMA-ring kernel (gemm_tng.cuh); anything else: count calls of mpmae_wgrad (same results). */
 int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws, size_t ws_floats,
                       mpmae_stream_t stream);
 
@@ -421,6 +421,10 @@ int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, f
  * weight + bias gradient. `args` are HOST pointers. */
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* args, mpmae_stream_t stream);
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* args, int nblocks, mpmae_stream_t stream);
+/* The same gradients for `count` depthwise layers of identical geometry in one launch + one fold (all blocks of an encoder stage: their
+ * x / dd operands persist until the stage's data-gradient chain is done). probs[i].ws / ws_floats are ignored; ws: scratch for all slabs. */
+int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, float* ws, size_t ws_floats,
+                              mpmae_stream_t stream);
 /* depthwise stem, kernel = stride = patch/8 (convnextv2_sparse.py:121-127). */
 int mpmae_dwstride_fwd(int dt, const void* in, void* out, const float* w, const float* b, int Mout,
                        int C, int S, int k, const uint8_t* act_in, const uint8_t* act_out,

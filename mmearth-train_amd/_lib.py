@@ -106,6 +106,7 @@ class RsArgs(C.Structure):
 
 
 PS_MAXBLK = 9          # MPMAE_PS_MAXBLK
+DWG_MAX = 12           # problems per mpmae_dwconv7_wgrad_group launch (csrc/dwconv.cuh)
 TNG_MAXP = 20          # problems per mpmae_wgrad_group launch (csrc/gemm_tng.cuh)
 
 
@@ -198,6 +199,7 @@ SYMBOLS = {
     "mpmae_get_option": [c_int],
     "mpmae_dwconv7_fwd": [c_int, P(DwArgs), c_void_p],
     "mpmae_dwconv7_wgrad": [c_int, P(DwWgArgs), c_int, c_void_p],
+    "mpmae_dwconv7_wgrad_group": [c_int, P(DwWgArgs), c_int, c_void_p, c_size_t, c_void_p],
     "mpmae_dwstride_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                            c_void_p, c_void_p, c_void_p],
     "mpmae_dwstride_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,

@@ -274,7 +274,7 @@ static bool tng_ok(int dt, const WgradP* pr, int count, int* WX_, int* WY_) {
     const int wx = a.Nn < a.Kk ? a.Nn : a.Kk, wy = a.Nn < a.Kk ? a.Kk : a.Nn;
     if (wx != WX || wy != WY || a.M != pr[0].M || a.M < 1) return false;
     if (a.P2 || a.pp0 || a.pp1 || a.qp0 || a.qp1 || !a.P || !a.Q || !a.dW) return false;
-    if (a.sn != a.Kk || a.sk != 1) return false;
+    if (a.sn < 1 || a.sk < 1) return false;
     if ((a.ldp | a.ldq) & 7) return false;
     if (((uintptr_t)a.P | (uintptr_t)a.Q) & 15) return false;
     if (a.ldp < a.Nn || a.ldq < a.Kk) return false;
@@ -326,7 +326,7 @@ int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws,
     p.slab = ws + (size_t)i * splits * per_max;
     p.swap = swap ? 1 : 0; p.want_db = a.db ? 1 : 0;
     const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
-    f.p[i].slab = p.slab; f.p[i].dW = a.dW; f.p[i].db = a.db; f.p[i].nk = a.Nn * a.Kk; f.p[i].per = (int)per;
+    f.p[i].slab = p.slab; f.p[i].dW = a.dW; f.p[i].db = a.db; f.p[i].nk = a.Nn * a.Kk; f.p[i].per = (int)per; f.p[i].Kk = a.Kk; f.p[i].sn = a.sn; f.p[i].sk = a.sk;
     if (per > maxper) maxper = per;
   }
   const int blocks = count * xt * yt * splits;
@@ -520,7 +520,7 @@ static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
 }
 
 template <typename T, int S>
-static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
+static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st, const DwWgGroupP* grp = nullptr) {
   constexpr int CW = 64 / S;
   size_t lds = dw5_map_bytes<T, S>(a.g.grid);
   int nt8;
@@ -538,9 +538,11 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) 
     }
     cur = lds;
   }
-  dim3 g(nblocks, a.C / CW);
-  if (a.g.grid == 7) LAUNCH((dwconv7_wgrad_v5_kernel<T, S, 7>), g, dim3(nthreads), lds, st, a);
-  else LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(nthreads), lds, st, a);
+  DwWgGroupP gr;
+  if (grp) gr = *grp; else gr.count = 0;
+  dim3 g(nblocks, a.C / CW, gr.count > 0 ? gr.count : 1);
+  if (a.g.grid == 7) LAUNCH((dwconv7_wgrad_v5_kernel<T, S, 7>), g, dim3(nthreads), lds, st, a, gr);
+  else LAUNCH((dwconv7_wgrad_v5_kernel<T, S>), g, dim3(nthreads), lds, st, a, gr);
   return true;
 }
 
@@ -679,7 +681,9 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     int nb = a->g.N < want ? a->g.N : want;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     dim3 g(nb, cdiv(a->C, 64));
-    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a);
+    DwWgGroupP gr;
+    gr.count = 0;
+    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a, gr);
     launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }
@@ -754,6 +758,62 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
     LAUNCH(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
   }
+  RET();
+}
+
+// All depthwise weight gradients of a stage in one launch (grid.z = problem) + one fold: identical geometry / width / tap strides,
+// bf16, the per-sample LDS-map kernels (v5: S >= 2, v6s1: S = 1 on the 7 x 7 grid). Anything else: one mpmae_dwconv7_wgrad each.
+int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, float* ws, size_t ws_floats, mpmae_stream_t s) {
+  if (!probs || count < 1 || !ws) return (int)hipErrorInvalidValue;
+  const MpmaeDwWgArgs& a0 = probs[0];
+  bool ok = dt == 1 && count <= DWG_MAX && dw_variant() >= 6 && g_opt[MPMAE_OPT_DWW] < 6 && a0.CC >= 1 && a0.TP * a0.g.S <= 8;
+  for (int i = 0; ok && i < count; ++i) {
+    const MpmaeDwWgArgs& a = probs[i];
+    ok = a.C == a0.C && a.g.N == a0.g.N && a.g.keep == a0.g.keep && a.g.grid == a0.g.grid && a.g.S == a0.g.S && a.g.vis == a0.g.vis &&
+         a.g.inv == a0.g.inv && a.s_kh == a0.s_kh && a.s_kw == a0.s_kw && a.s_c == a0.s_c && a.act == a0.act && a.x && a.dd && a.dw &&
+         (((uintptr_t)a.x) & 15) == 0 && (((uintptr_t)a.dd) & 3) == 0;
+  }
+  const bool s1 = ok && a0.g.S == 1 && a0.g.grid == 7 && (a0.C & 15) == 0;
+  const bool v5 = ok && !s1 && a0.g.S >= 2 && dw_v4_ok(a0.C, a0.g.S);
+  const size_t per = (size_t)50 * a0.C;
+  int nb = 0;
+  if (s1) {
+    const int want = g_opt[MPMAE_OPT_DWW_S1_NB] > 0 ? g_opt[MPMAE_OPT_DWW_S1_NB] : (cdiv(a0.C, 64) <= 5 ? 128 : 64);
+    nb = a0.g.N < want ? a0.g.N : want;
+  } else if (v5) {
+    nb = a0.g.N < g_opt[MPMAE_OPT_DWW_NB] ? a0.g.N : g_opt[MPMAE_OPT_DWW_NB];
+  }
+  if (nb > 0 && (size_t)nb * per * count > ws_floats) nb = (int)(ws_floats / (per * count));
+  if (nb < 1 || count == 1) {                    // one by one, each on the scratch given here
+    for (int i = 0; i < count; ++i) {
+      MpmaeDwWgArgs a = probs[i];
+      a.ws = ws; a.ws_floats = ws_floats;
+      const int err = mpmae_dwconv7_wgrad(dt, &a, 2048, s);
+      if (err) return err;
+    }
+    return 0;
+  }
+  DwWgGroupP gr;
+  ReduceGroupP rg;
+  gr.count = rg.count = count;
+  for (int i = 0; i < count; ++i) {
+    gr.x[i] = probs[i].x; gr.dd[i] = probs[i].dd; gr.ws[i] = ws + (size_t)i * nb * per;
+    rg.part[i] = gr.ws[i]; rg.out[i] = probs[i].dw; rg.out2[i] = probs[i].db;
+  }
+  if (s1) {
+    dim3 g(nb, cdiv(a0.C, 64), count);
+    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), a0, gr);
+  } else {
+    bool done;
+    switch (a0.g.S) { case 8: done = launch_dwwg_v5<bf16_t, 8>(a0, nb, S_(s), &gr); break; case 4: done = launch_dwwg_v5<bf16_t, 4>(a0, nb, S_(s), &gr); break;
+                      default: done = launch_dwwg_v5<bf16_t, 2>(a0, nb, S_(s), &gr); }
+    if (!done) return (int)hipErrorInvalidValue;
+  }
+  const int W = 50 * a0.C;
+  int R = nb / 16;
+  if (R < 1) R = 1;
+  if (R > 32) R = 32;
+  LAUNCH(reduce_partials_group2_kernel, dim3(cdiv(W, 64), R, count), dim3(256), 0, S_(s), rg, nb, W, a0.C, a0.s_kh, a0.s_kw, a0.s_c);
   RET();
 }
 

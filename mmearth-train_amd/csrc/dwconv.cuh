@@ -91,6 +91,22 @@ __global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const DwP p) {
 
 // weight / bias gradient: dw[kh,kw,c] += sum_p dd[p,c] * x[p + (kh-3, kw-3), c] ; db[c] += sum_p dd[p,c]
 typedef MpmaeDwWgArgs DwWgP;
+// Grouped depthwise weight gradients (mpmae_dwconv7_wgrad_group): problem blockIdx.z of a launch replaces the operand / slab pointers of
+// the shared argument record by its own (count == 0: a plain launch). Read from the kernel-argument segment (scalar loads with a dynamic
+// offset; indexing a by-value copy at run time goes to scratch, see ps.cuh).
+constexpr int DWG_MAX = 12;
+struct DwWgGroupP { int count, pad; const void* x[DWG_MAX]; const void* dd[DWG_MAX]; float* ws[DWG_MAX]; };
+__device__ __forceinline__ void dwwg_select(const DwWgP& q, const DwWgGroupP& grp, const void*& x, const void*& dd, float*& ws) {
+  x = q.x; dd = q.dd; ws = q.ws;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (grp.count > 0) {
+    typedef __attribute__((address_space(4))) const char* kchar_p;
+    typedef __attribute__((address_space(4))) const DwWgGroupP* kgrp_p;
+    const kgrp_p g = (kgrp_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DwWgP) + 7) / 8) * 8);
+    x = g->x[blockIdx.z]; dd = g->dd[blockIdx.z]; ws = g->ws[blockIdx.z];
+  }
+#endif
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv7_wgrad_kernel(const DwWgP q) {

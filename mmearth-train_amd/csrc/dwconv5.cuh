@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) void dwconv7_v5_kernel(const DwP p) {
 // base + immediate; with a runtime pitch hipcc hoisted the 98 loop-invariant offsets into VGPRs (220 VGPRs, one
 // workgroup per CU)
 template <typename T, int S, int GC = 0>
-__global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
+__global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q, const DwWgGroupP grp) {
   using D = Dw5<T, S>;
   constexpr int CW = D::CW;
   extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
@@ -137,8 +137,11 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
   const int C = q.C, c0 = blockIdx.y * CW;
   const int ox = lane / CW, cw = lane - ox * CW;
   const int c = c0 + cw;
-  const T* dd = reinterpret_cast<const T*>(q.dd);
-  const T* x = reinterpret_cast<const T*>(q.x);
+  const void *xv, *ddv;
+  float* wsv;
+  dwwg_select(q, grp, xv, ddv, wsv);
+  const T* dd = reinterpret_cast<const T*>(ddv);
+  const T* x = reinterpret_cast<const T*>(xv);
 
   {
     uint4* m4 = reinterpret_cast<uint4*>(dw5_smem);
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q) {
   for (int o = CW; o < 64; o <<= 1) adb += __shfl_xor(adb, o, 64);
   if (ox == 0) red[(wave * 50 + 49) * CW + cw] = adb;
   __syncthreads();
-  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
+  float* slab = wsv + (size_t)blockIdx.x * 50 * C;
   for (int i = tid; i < 50 * CW; i += blockDim.x) {
     float v = 0.f;
     for (int w = 0; w < NW; ++w) v += red[w * 50 * CW + i];

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
 // lanes of a channel pair folded through LDS at the end -> slab ws[blockIdx.x][50][C].
 // grid = (nblocks, C/64), block = 256 (4 independent channel chunks).
 template <int G>
-__global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q) {
+__global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q, const DwWgGroupP grp) {
   using T = bf16_t;
   constexpr int CW = 16, MS = G + 6, MAPB = ((MS * MS * CW * 2 + 15) / 16) * 16;
   constexpr int REDB = 8 * 10 * CW * 4;             // fold buffer per wave: [8 ox lanes][10 taps][16] floats, 5 passes
@@ -345,8 +345,11 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q) 
   const int cp = lane & 7, ox = lane >> 3;
   const bool col_ok = ox < G;
   const int c = cc0 + 2 * cp;
-  const T* x = reinterpret_cast<const T*>(q.x);
-  const T* dd = reinterpret_cast<const T*>(q.dd);
+  const void *xv, *ddv;
+  float* wsv;
+  dwwg_select(q, grp, xv, ddv, wsv);
+  const T* x = reinterpret_cast<const T*>(xv);
+  const T* dd = reinterpret_cast<const T*>(ddv);
   {
     uint4* m4 = reinterpret_cast<uint4*>(map);
     const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q) 
   __builtin_amdgcn_s_waitcnt(0);
   __builtin_amdgcn_wave_barrier();
   float* red = reinterpret_cast<float*>(wbase);           // [8][10][16]
-  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
+  float* slab = wsv + (size_t)blockIdx.x * 50 * C;
 #pragma unroll
   for (int kb = 0; kb < 5; ++kb) {
 #pragma unroll

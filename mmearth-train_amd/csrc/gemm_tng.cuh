@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tng_kernel(const TngP g) {
   else tng_body<RX, RY, NST, false>(g, pr, tile, split, tng_smem);
 }
 
-// Fold of a group: dW_p[e] += sum_s slab_p[s][e] (e < Nn Kk), db_p[e - Nn Kk] += ... ; fixed summation order.
-struct TngFoldProb { const float* slab; float* dW; float* db; int nk, per; };
+// Fold of a group: dW_p[n sn + k sk] += sum_s slab_p[s][n Kk + k], db_p[n] += sum_s slab_p[s][Nn Kk + n]; fixed summation order.
+struct TngFoldProb { const float* slab; float* dW; float* db; int nk, per, Kk, sn, sk, pad; };
 struct TngFoldP { int nprob, splits; TngFoldProb p[TNG_MAXP]; };
 
 __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(const TngFoldP f) {
@@ -236,7 +236,13 @@ __global__ __launch_bounds__(256) void wgrad_group_fold_kernel(const TngFoldP f)
       s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
     }
     const int e = v * 4;
-    float* dst = e < pr.nk ? pr.dW + e : (pr.db ? pr.db + (e - pr.nk) : nullptr);
-    if (dst) { dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w; }      // (the flat gradient buffer is only 4-byte aligned per tensor)
+    if (e < pr.nk) {                         // dW[n * sn + k * sk] (Kk % 4 == 0: the four elements share a row n)
+      const int n = e / pr.Kk, k = e - n * pr.Kk;
+      float* dst = pr.dW + (size_t)n * pr.sn + (size_t)k * pr.sk;
+      dst[0] += s.x; dst[pr.sk] += s.y; dst[2 * pr.sk] += s.z; dst[3 * pr.sk] += s.w;
+    } else if (pr.db) {
+      float* dst = pr.db + (e - pr.nk);
+      dst[0] += s.x; dst[1] += s.y; dst[2] += s.z; dst[3] += s.w;
+    }
   }
 }

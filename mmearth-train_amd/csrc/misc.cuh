@@ -321,6 +321,40 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   else atomicAdd(dst, s);
 }
 
+// Mode-2 second stage (depthwise taps + bias) for a GROUP of problems of one shape: blockIdx.z = problem, pointers from the table.
+struct ReduceGroupP { int count, pad; const float* part[12]; float* out[12]; float* out2[12]; };
+__global__ __launch_bounds__(256) void reduce_partials_group2_kernel(const ReduceGroupP r, int P, int W, int a, int b, int c, int d) {
+  __shared__ float red[4][64];
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const ReduceGroupP* kgrp_p;
+  const kgrp_p g = (kgrp_p)__builtin_amdgcn_kernarg_segment_ptr();
+  const float* part = g->part[blockIdx.z];
+  float* out = g->out[blockIdx.z];
+  float* out2 = g->out2[blockIdx.z];
+#else
+  const float* part = r.part[0]; float* out = r.out[0]; float* out2 = r.out2[0];
+#endif
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  const int chunk = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+  float s = 0.f;
+  if (e < W) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || e >= W) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  float* dst;
+  const int tap = e / a, ch = e - tap * a;
+  if (tap < 49) { const int kh = tap / 7, kw = tap - kh * 7; dst = out + kh * b + kw * c + ch * d; }
+  else { if (!out2) return; dst = out2 + ch; }
+  if (gridDim.y == 1) *dst += s;
+  else atomicAdd(dst, s);
+}
+
 // ---------------------------------------------------------------------------------
 // Aligned random crop of the input stage (kornia RandomCrop in FCMAE.forward, models/fcmae.py:419-434): every pixel-wise
 // modality of sample n is cut at the SAME window (ty[n], tx[n]) - fp32 bands and int64 class maps alike (the reference

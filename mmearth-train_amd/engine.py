@@ -67,6 +67,7 @@ ENGINE_OPTIONS = dict(
     grn_fold_minc=0,        # smallest C with folded GRN finalisation
     hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
     dzr_maxc=80,            # largest C recomputing dz
+    dw_group=1,             # ... and ONE launch for its depthwise weight gradients (mpmae_dwconv7_wgrad_group), from this stage index on (stage 0 stays per block: its weight gradients are the tail of the backward; 9 = never)
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
 )
 
@@ -514,7 +515,7 @@ class Engine:
         if len(self._group_pending) >= 2 * min(_lib.TNG_MAXP // 2, max(1, min(len(self.scr_dz2), len(self.scr_dx)) - 2)):
             self._group_flush(lst)
 
-    def _group_flush(self, lst):
+    def _group_flush(self, lst, name=None):
         pend = getattr(self, "_group_pending", [])
         if not pend:
             return
@@ -533,7 +534,7 @@ class Engine:
         k = self._after(lst)
         self._evseq += 1
         key = f"s{self._evseq}"
-        self._op(lst, f"{stage}:pw.wgrad[{len(pend)}]", self.lib.mpmae_wgrad_group, self.dt, arr, len(pend), _p(self.ws2), self.ws_floats,
+        self._op(lst, name or f"{stage}:pw.wgrad[{len(pend)}]", self.lib.mpmae_wgrad_group, self.dt, arr, len(pend), _p(self.ws2), self.ws_floats,
                  kind="wgrad_group", nbytes=nbytes, flops=flops, lane=1, wait=(k,) if k else (), signal=key)
         for _, reads, _ in pend:
             self._side_read(key, *reads)
@@ -1015,6 +1016,13 @@ class Engine:
         a.act = act.data_ptr() if act is not None else 0
         a.ws, a.ws_floats = (self.ws3 if self.lanes else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
+        if (self.lanes and dt == BF16 and blk["sparse"] and blk["stage"] >= int(self.opt["dw_group"]) and self.cfg.depths[blk["stage"]] > 1):
+            if not hasattr(self, "_dwg_pending"):
+                self._dwg_pending = []
+            self._dwg_pending.append((tag, a, dd, 2 * M * Cc * 2, 2 * 49 * M * Cc))
+            if len(self._dwg_pending) >= min(_lib.DWG_MAX, max(1, len(self.scr_dd2) - 2)):
+                self._dwg_flush(lst)
+            return
         if self.lanes:
             k = self._after(lst)
             self._evseq += 1
@@ -1025,6 +1033,22 @@ class Engine:
         else:
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
                      nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
+
+    def _dwg_flush(self, lst):
+        pend = getattr(self, "_dwg_pending", [])
+        if not pend:
+            return
+        self._dwg_pending = []
+        arr = (_lib.DwWgArgs * len(pend))(*[p_[1] for p_ in pend])
+        self._keepalive.append(arr)
+        stage = pend[0][0].rsplit(".", 1)[0]
+        k = self._after(lst)
+        self._evseq += 1
+        key = f"s{self._evseq}"
+        self._op(lst, f"{stage}:dw.wgrad[{len(pend)}]", self.lib.mpmae_dwconv7_wgrad_group, self.dt, arr, len(pend), _p(self.ws3), self.ws_floats,
+                 kind="dwconv7_wgrad_group", nbytes=sum(p_[3] for p_ in pend), flops=sum(p_[4] for p_ in pend), lane=self.dw_lane,
+                 wait=(k,) if k else (), signal=key)
+        self._side_read(key, *[p_[2] for p_ in pend])
 
     def _block_fwd_fused(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
@@ -1503,7 +1527,8 @@ class Engine:
                 other = ring[ri]
                 cur = nxt
                 bi -= 1
-            self._group_flush(b)          # the stage's grouped pointwise weight gradients: side lane, behind its data-gradient chain
+            self._dwg_flush(b)            # the stage's grouped depthwise / pointwise weight gradients: side lane, behind its data-gradient chain
+            self._group_flush(b)
             if i > 0:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
@@ -1511,7 +1536,15 @@ class Engine:
                 wd = self.w[f"down{i - 1}.W"]
                 nxt = other[:self.M[i - 1] * Ci]
                 if dn["grouped"]:
-                    self._side_wgrad(b, pre + ":wgrad", "NONE", "NONE", [cur], P=cur, Q=dn["yg"], M=self.M[i], Nn=Co, Kk=4 * Ci,
+                    wx, wy = min(Co, 4 * Ci), max(Co, 4 * Ci)
+                    if (self.lanes and bool(self.opt["wgrad_group"]) and dt == BF16
+                            and ((wx == 80 and wy % 320 == 0) or (wx % 160 == 0 and wy % 160 == 0))):
+                        # a group of one: the DMA-ring kernel with few row splits instead of the transpose-read kernel's 76 slabs
+                        self._group_add(b, pre + ":wgrad", [cur], P=cur, Q=dn["yg"], M=self.M[i], Nn=Co, Kk=4 * Ci,
+                                        ldp=Co, ldq=4 * Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"])
+                        self._group_flush(b, name=pre + ":wgrad")
+                    else:
+                      self._side_wgrad(b, pre + ":wgrad", "NONE", "NONE", [cur], P=cur, Q=dn["yg"], M=self.M[i], Nn=Co, Kk=4 * Ci,
                                      ldp=Co, ldq=4 * Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"])
                     dyg = self.scr_dxn[:self.M[i] * 4 * Ci]
                     self._gemm(b, pre + ":dgrad", "NONE", "STORE", A=cur, B=wd["t"], C=dyg, M=self.M[i], N=4 * Ci, K=Co,

@@ -50,7 +50,7 @@ def eng():
     from mmearth_train_amd.synth import make_inputs, make_state_dict
     cfg = make_cfg()
     N = 6
-    e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=0))      # per-block kernels (the persistent stage kernels have their own test below)
+    e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=0, dw_group=9, wgrad_group=0))      # per-block kernels / launches (the persistent stage kernels and the grouped weight gradients have their own tests)
     e.load_state_dict(make_state_dict(cfg, seed=21))
     inputs, noise = make_inputs(cfg, N, seed=22)
     z = torch.rand(N, 1, 56, 56, generator=torch.Generator().manual_seed(23)) < 0.06
@@ -173,6 +173,41 @@ def test_depthwise7_weight_gradient_every_stage(eng):
         # accumulation semantics: a second launch adds
         assert lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], _st()) == 0
         assert _rel(got, 2 * ref) < 2e-4, name
+
+
+@pytest.mark.parametrize("count", [2, 5])
+def test_depthwise7_weight_gradient_group_matches_single_launches(eng, count):
+    """mpmae_dwconv7_wgrad_group (all depthwise weight gradients of a stage: one launch with grid.z = problem + one fold) against one
+    mpmae_dwconv7_wgrad per problem on the same operands, for every sparse stage geometry (S = 8 / 4 / 2 on the v5 kernel, S = 1 on
+    v6s1) and the dense decoder record (not groupable: the entry point issues the single launches itself)."""
+    e, lib = eng, eng.lib
+    ops = {o[0]: o for o in e.bwd_ops}
+    for blk in _blocks(e):
+        tag, M, Cc = blk["prefix"], blk["M"], blk["C"]
+        act = e.act[blk["stage"]] if blk["sparse"] else None
+        live = act.bool()[:, None] if act is not None else torch.ones(M, 1, dtype=torch.bool, device=DEV)
+        name, fn, args, _ = ops[tag + ":dw.wgrad"]
+        wshape = (49, Cc) if blk["sparse"] else (Cc, 1, 7, 7)
+        arr = (type(args[1]._obj) * count)()
+        keep, want = [], []
+        ws = torch.empty(32 << 20, device=DEV)
+        torch.manual_seed(7 * M + Cc + count)
+        for i in range(count):
+            a = type(args[1]._obj).from_buffer_copy(args[1]._obj)
+            x = torch.randn(M, Cc, device=DEV).to(bf) * live
+            dd = (torch.randn(M, Cc, device=DEV) * 0.2).to(bf) * live
+            dw0, db0 = torch.randn(wshape, device=DEV), torch.randn(Cc, device=DEV)
+            dw, db = dw0.clone(), db0.clone()
+            a.x, a.dd, a.dw, a.db, a.ws, a.ws_floats = x.data_ptr(), dd.data_ptr(), dw0.data_ptr(), db0.data_ptr(), ws.data_ptr(), ws.numel()
+            assert lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], _st()) == 0       # reference: the single launch (pinned against torch above)
+            a.dw, a.db = dw.data_ptr(), db.data_ptr()
+            arr[i] = a
+            keep.append((x, dd, dw, db))
+            want.append((dw0, db0))
+        assert lib.mpmae_dwconv7_wgrad_group(1, arr, count, C.c_void_p(ws.data_ptr()), ws.numel(), _st()) == 0
+        torch.cuda.synchronize()
+        for (x, dd, dw, db), (dw0, db0) in zip(keep, want):
+            assert _rel(dw, dw0) < 1e-5 and _rel(db, db0) < 1e-5, (name, _rel(dw, dw0), _rel(db, db0))
 
 
 def test_loss_kernels_forward_and_backward_match_oracle_autograd(eng):
