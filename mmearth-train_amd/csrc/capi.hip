@@ -19,6 +19,7 @@
 #include "ps.cuh"
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
+#include "gemm_nt4.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -125,6 +126,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_STB_BLOCKS */ 512,
     /* MPMAE_OPT_TN3_BLOCKS */ 256,
     /* MPMAE_OPT_TNG_BLOCKS */ 512,
+    /* MPMAE_OPT_NT4 */ 1,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -449,7 +451,8 @@ int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G
 
 int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv, const float* gamma,
                            int G, int H, float* coef, float* dgamma, float* dbeta, mpmae_stream_t s) {
-  LAUNCH(grn_bwd_finalize_kernel, dim3(G), dim3(256), 0, S_(s), S0, S1, Gx, Ainv, gamma, H, coef, dgamma, dbeta);
+  const int gpb = (H <= 4096 && G >= 64) ? 8 : 1;       // groups per workgroup (dense decoder: one group per sample)
+  LAUNCH(grn_bwd_finalize_kernel, dim3(cdiv(G, gpb)), dim3(256), 0, S_(s), S0, S1, Gx, Ainv, gamma, H, coef, dgamma, dbeta, G, gpb);
   RET();
 }
 
@@ -1092,8 +1095,31 @@ static int launch_nt3_k(const GemmP& a, const Nt3Scales& sc, hipStream_t st) {
   return launch_status();
 }
 
+// 256-row tiles, 8 waves, 32 x 32 x 16 MFMA, DMA double buffer (gemm_nt4.cuh): the decoder / head shapes
+template <int BN>
+static int launch_nt4(const GemmP& a, hipStream_t st) {
+  using Cf = Nt4Cfg<BN>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt4_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
+      return (int)hipGetLastError();
+    attr = true;
+  }
+  const int tm = cdiv(a.M, NT4_BM), tn = cdiv(a.N, BN);
+  LAUNCH((gemm_nt4_kernel<BN>), dim3(cdiv(tm, 8) * 8 * tn), dim3(512), Cf::LDS, st, a, tm, tn);
+  return launch_status();
+}
+
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   if (epi == EPI_STORE) a.R = nullptr;
+  // measured (tools/gemm_probe.py, profiles/r04/gemm_probe.txt): the 256 x 256 tile wins where its tile count fills the 256 CUs in
+  // at most two even rounds (decoder pw1 / pw2.dgrad, N = 2048: 49.5 vs 55.3 us) and loses on 539 tiles (pixel heads, N = 2816:
+  // 73 vs 65 us); the 256 x 128 variant ties with the 128 x 128 kernels (N = 512). NT4 = 2 takes it for every eligible shape.
+  const int nt4 = g_opt[MPMAE_OPT_NT4];
+  if (nt4 && (epi == EPI_STORE || epi == EPI_RESID) && a.K % NT4_BK == 0 && a.M >= 8192 && a.N >= 256 &&
+      !(((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.R) & 15) &&
+      (nt4 >= 2 || (a.N % 256 == 0 && a.N >= 1024 && a.N <= 2048)))
+    return a.N >= 1024 ? launch_nt4<256>(a, st) : launch_nt4<128>(a, st);
   const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
   int err = (w64 < w128) ? launch_gemm_fast_bn<64>(epi, a, st) : launch_gemm_fast_bn<128>(epi, a, st);
   if (err) return err;

@@ -169,50 +169,67 @@ __global__ __launch_bounds__(256) void grn_bwd_finalize_kernel(const float* __re
                                                                const float* __restrict__ Gx, const float* __restrict__ Ainv,
                                                                const float* __restrict__ gamma, int H,
                                                                float* __restrict__ coef, float* __restrict__ dgamma,
-                                                               float* __restrict__ dbeta) {
-  __shared__ float red[4];
+                                                               float* __restrict__ dbeta, int G, int gpb) {
+  __shared__ float red[2][4];
   constexpr int MAXC = 16;                       // columns per thread in registers: H <= 4096
-  const int g = blockIdx.x;
-  const float ainv = Ainv[g];
   if (H <= 256 * MAXC) {
-    float v0[MAXC], v1[MAXC], vx[MAXC], vg[MAXC];
-#pragma unroll
-    for (int u = 0; u < MAXC; ++u) {
-      const int j = threadIdx.x + 256 * u, jc = j < H ? j : 0;
-      const size_t i = (size_t)g * H + jc;
-      v0[u] = S0[i]; v1[u] = S1[i]; vx[u] = Gx[i]; vg[u] = gamma[jc];
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int u = 0; u < MAXC; ++u) s += (threadIdx.x + 256 * u < H) ? vg[u] * v1[u] * vx[u] : 0.f;
-    s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    const float T2 = (red[0] + red[1] + red[2] + red[3]) * ainv * ainv / H;
+    // A workgroup walks `gpb` groups (the dense decoder has one group per SAMPLE: 256 of them) and keeps the gamma / beta gradient
+    // partials of its columns in registers: one atomic per column and WORKGROUP instead of one per column and group - with a
+    // workgroup per group the 256-way same-address atomics were most of the kernel (21 us stand-alone, 44 us in the step).
+    float vg[MAXC], dg[MAXC], db[MAXC];
 #pragma unroll
     for (int u = 0; u < MAXC; ++u) {
       const int j = threadIdx.x + 256 * u;
-      if (j < H) {
-        const float dGx = vg[u] * v1[u] * ainv - T2;
-        coef[(size_t)g * H + j] = (vx[u] > 0.f) ? dGx / vx[u] : 0.f;
+      vg[u] = gamma[j < H ? j : 0];
+      dg[u] = 0.f; db[u] = 0.f;
+    }
+    const int g0 = blockIdx.x * gpb, g1 = min(G, g0 + gpb);
+    for (int g = g0; g < g1; ++g) {
+      const float ainv = Ainv[g];
+      float v0[MAXC], v1[MAXC], vx[MAXC];
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        const int j = threadIdx.x + 256 * u, jc = j < H ? j : 0;
+        const size_t i = (size_t)g * H + jc;
+        v0[u] = S0[i]; v1[u] = S1[i]; vx[u] = Gx[i];
+      }
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) s += (threadIdx.x + 256 * u < H) ? vg[u] * v1[u] * vx[u] : 0.f;
+      s = wave_sum(s);
+      float* rd = red[(g - g0) & 1];               // two buffers: one barrier per group
+      if ((threadIdx.x & 63) == 0) rd[threadIdx.x >> 6] = s;
+      __syncthreads();
+      const float T2 = (rd[0] + rd[1] + rd[2] + rd[3]) * ainv * ainv / H;
+#pragma unroll
+      for (int u = 0; u < MAXC; ++u) {
+        const int j = threadIdx.x + 256 * u;
+        if (j < H) {
+          const float dGx = vg[u] * v1[u] * ainv - T2;
+          coef[(size_t)g * H + j] = (vx[u] > 0.f) ? dGx / vx[u] : 0.f;
+          dg[u] += vx[u] * ainv * v1[u];
+          db[u] += v0[u];
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < MAXC; ++u) {
       const int j = threadIdx.x + 256 * u;
-      if (j < H) { atomicAdd(dgamma + j, vx[u] * ainv * v1[u]); atomicAdd(dbeta + j, v0[u]); }
+      if (j < H) { atomicAdd(dgamma + j, dg[u]); atomicAdd(dbeta + j, db[u]); }
     }
     return;
   }
+  const int g = blockIdx.x;
+  const float ainv = Ainv[g];
   float s = 0.f;
   for (int j = threadIdx.x; j < H; j += 256) {
     const size_t i = (size_t)g * H + j;
     s += gamma[j] * S1[i] * Gx[i];
   }
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
   __syncthreads();
-  const float T2 = (red[0] + red[1] + red[2] + red[3]) * ainv * ainv / H;
+  const float T2 = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) * ainv * ainv / H;
   for (int j = threadIdx.x; j < H; j += 256) {
     const size_t i = (size_t)g * H + j;
     const float gx = Gx[i];

@@ -336,6 +336,53 @@ def test_direct_to_lds_gemm_matches_torch(M, N, K, resid):
     assert _rel(c, ref) < 6e-3
 
 
+@pytest.mark.parametrize("M,N,K,resid,bias_on,act_on", [(12544, 2048, 512, False, True, False), (12544, 512, 2048, True, True, True),
+                                                        (8300, 2816, 512, False, True, True), (9000, 520, 2816, True, False, False),
+                                                        (8192, 264, 64, False, False, True), (10000, 1032, 128, True, True, False)])
+def test_256_row_tile_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
+    """mpmae_gemm bf16 NT with M >= 8192, N >= 256, K % 64 == 0 takes the 256-row-tile kernel (gemm_nt4.cuh: 8 waves of 32 x 32 x 16
+    MFMA, DMA double buffer, transposed issue with permuted B rows, XCD-aware tile order): both tile widths, ragged last row / column
+    tiles (N % 16 == 8 cuts a lane's 16-column group in half), optional bias / residual / row mask; against an fp32 matmul of the
+    same bf16 operands, and bit-for-bit against the 128 x 128 kernels' rounding contract (one bf16 rounding of the fp32 sum)."""
+    L, lib = _lib()
+    dev = "cuda"
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev).to(bf)
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
+    bias = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev).to(bf)
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    c = torch.full((M, N), 7.0, device=dev, dtype=bf)
+    g = L.GemmArgs()
+    g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), c.data_ptr()
+    g.bias = bias.data_ptr() if bias_on else 0
+    g.act = act.data_ptr() if act_on else 0
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
+    if resid:
+        g.R, g.ldr = r.data_ptr(), N
+    assert lib.mpmae_set_option(L.OPT["NT4"], 2) == 0          # every eligible shape (default 1: only the shapes where it measured faster)
+    try:
+        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+    finally:
+        lib.mpmae_set_option(L.OPT["NT4"], 1)
+    ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
+    if act_on:
+        ref = ref * act.bool()[:, None]
+    assert _rel(c, ref) < 6e-3
+    if act_on:
+        assert (c[~act.bool()] == 0).all()
+    c2 = torch.empty_like(c)
+    g.C = c2.data_ptr()
+    assert lib.mpmae_set_option(L.OPT["NT4"], 0) == 0
+    try:
+        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+    finally:
+        lib.mpmae_set_option(L.OPT["NT4"], 1)
+    torch.cuda.synchronize()
+    d = (c.float() - c2.float()).abs()
+    assert (d <= 2.0 ** -7 * c2.float().abs() + 1e-6).all(), float(d.max())      # same operands, fp32 accumulation order differs: <= 1 bf16 ulp
+
+
 @pytest.mark.parametrize("M,Cc", [(1000, 40), (333, 80)])
 def test_dz_recomputation_matches_the_materialised_path(M, Cc):
     """mpmae_rs which = 1 with out == NULL (statistics only) and which = 5 with dz_dout / dz_w2t (dz = dout W2 recomputed

@@ -45,8 +45,13 @@ for M, N, K, name in shapes:
     assert lib.mpmae_gemm(1, 0, 0, C.byref(g), st) == 0
     err0 = rel(c.float(), ref)
     us = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
+    lib.mpmae_set_option(_lib.OPT["NT4"], 0)
+    us0 = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
+    lib.mpmae_set_option(_lib.OPT["NT4"], 1)
     usv = t(lambda: torch.nn.functional.linear(a, w))
-    print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}")
+    print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF (128-row tiles {us0:6.1f} us) | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}", flush=True)
+    if os.environ.get("BRIEF"):
+        continue
     # epilogues: residual + row mask, GELU^2 sums, dz statistics
     g.R, g.ldr, g.act = r.data_ptr(), N, act.data_ptr()
     assert lib.mpmae_gemm(1, 0, 2, C.byref(g), st) == 0
