@@ -102,6 +102,50 @@ def test_fp32_step_matches_oracle_and_golden(name):
             assert np.abs(g2[sl].numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, k
 
 
+@pytest.mark.parametrize("model,img,patch", [("convnextv2_femto", 56, 8), ("convnextv2_pico", 56, 8), ("convnextv2_nano", 56, 8),
+                                             ("convnextv2_base", 56, 8), ("convnextv2_nano", 112, 16)])
+def test_other_size_factories_run_on_the_hip_path(model, img, patch):
+    """The size factories the reference exports besides atto / tiny (models/fcmae.py:459-496: femto 48..384, pico 64..512, nano 80..640
+    with depth 8 at stage 2, base 128..1024 with 27 blocks at stage 2 - more than the persistent stage kernel's block table and deeper
+    than the backward scratch rings) as one full step at N = 2 against the oracle: fp32 mode to the fp32 bounds (loss 1e-4, every
+    parameter gradient 2e-4), bf16 mode to the stated bf16 bounds (losses 2e-2, total 1e-2, gradient cosine >= 0.99 / 0.999 flat)."""
+    from mmearth_train_amd import MODALITIES as M
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg(model, img, patch, out_modalities=M.subset("all_mod"))
+    N = 2
+    sd = make_state_dict(cfg, seed=71)
+    inputs, _ = make_inputs(cfg, N, seed=72)
+    noise = torch.randn(N, cfg.num_patches, generator=torch.Generator().manual_seed(73))
+    (loss, pred, mask, loss_dict, _, _), taps, grads = _oracle(cfg, sd, inputs, noise)
+    ref = np.array([v.item() for v in loss_dict.values()])
+    for dtype in ("f32", "bf16"):
+        eng = _engine(cfg, N, dtype, sd, inputs, noise)
+        eng.forward()
+        eng.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(eng.mask.cpu(), mask)
+        got = np.array(eng.losses.tolist())
+        tol_l, tol_t = (1e-4, 1e-4) if dtype == "f32" else (2e-2, 1e-2)
+        assert np.all(np.abs(got - ref) <= tol_l * np.abs(ref)), (dtype, got, ref)
+        assert abs(eng.total.item() - loss.item()) <= tol_t * abs(loss.item()), dtype
+        if dtype == "f32":
+            for k in sd:
+                ge, go = eng.grads[k].cpu(), grads[k]
+                assert (ge - go).abs().max().item() <= 2e-4 * go.abs().max().item() + 1e-9, k
+        else:
+            flat_e = torch.cat([eng.grads[k].cpu().reshape(-1) for k in sd])
+            flat_o = torch.cat([grads[k].reshape(-1) for k in sd])
+            assert torch.nn.functional.cosine_similarity(flat_e, flat_o, dim=0).item() >= 0.999
+            for k in sd:
+                go = grads[k].reshape(-1)
+                if go.numel() >= 8 and go.norm() > 0:
+                    cs = torch.nn.functional.cosine_similarity(eng.grads[k].cpu().reshape(-1), go, dim=0).item()
+                    assert cs >= 0.99, (k, cs)
+        del eng
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", ["allmod_atto_56", "allmod_tiny_112", "allmod_atto_56_zeropix"])
 def test_bf16_step_within_stated_tolerance(name):
     c = CASES[name]
