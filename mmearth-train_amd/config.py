@@ -114,7 +114,7 @@ def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=
     mods = OrderedDict(inp_modalities)
     mods.update(out_modalities)
     assert patch_size % 8 == 0 and img_size % patch_size == 0
-    assert decoder_depth == 1, "reference recipes use decoder_depth 1 (main_pretrain.py:82)"
+    assert decoder_depth >= 1
     in_chans = out_channels("sentinel2", mods, modalities_full)
     oms = []
     for name in out_modalities:

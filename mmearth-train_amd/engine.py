@@ -83,8 +83,6 @@ def _rup(x, m):
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
                  track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None, lanes=None, options=None):
-        if cfg.decoder_depth != 1:
-            raise NotImplementedError("decoder_depth != 1")
         self.lib = _lib.load()
         self.opt = dict(ENGINE_OPTIONS)
         for kv in filter(None, os.environ.get("MPMAE_ENGINE_OPTS", "").split(",")):
@@ -209,8 +207,6 @@ class Engine:
         first = self.cfg.out_mods[0].name
         for key, t in self.params.items():
             src = sd[key] if key in sd else None
-            if src is None and key.startswith(f"decoder_dict.{first}.0."):
-                raise KeyError(key)
             if src is None:
                 raise KeyError(key)
             t.copy_(src.to(torch.float32).reshape(t.shape))
@@ -218,7 +214,7 @@ class Engine:
     def state_dict(self):
         """Reference-layout state dict (shared decoder block replicated under every modality)."""
         first = self.cfg.out_mods[0].name
-        pre = f"decoder_dict.{first}.0."
+        pre = f"decoder_dict.{first}."
         out = OrderedDict()
         for k, v in self.params.items():
             if not k.startswith(pre):
@@ -226,7 +222,7 @@ class Engine:
         for m in self.cfg.out_mods:
             for k, v in self.params.items():
                 if k.startswith(pre):
-                    out[f"decoder_dict.{m.name}.0." + k[len(pre):]] = v
+                    out[f"decoder_dict.{m.name}." + k[len(pre):]] = v
         return out
 
     # ------------------------------------------------------------------ buffers
@@ -281,7 +277,11 @@ class Engine:
         for i in range(4):
             for j in range(cfg.depths[i]):
                 self.blocks.append(self._alloc_block(f"encoder.stages.{i}.{j}", self.M[i], dims[i], 1, i, sparse=True))
-        self.dec = self._alloc_block(f"decoder_dict.{cfg.out_mods[0].name}.0", N * L, D, N, None, sparse=False)
+        # the decoder: nn.Sequential of decoder_depth dense Blocks shared by every modality (fcmae.py:119-121,137,145)
+        self.decs = [self._alloc_block(f"decoder_dict.{cfg.out_mods[0].name}.{j}", N * L, D, N, None, sparse=False)
+                     for j in range(cfg.decoder_depth)]
+        self.dec = self.decs[0]
+        self.dec_dx = [self._t(N * L * D) for _ in range(cfg.decoder_depth - 1)]      # data gradients between the decoder blocks
         self.down = []
         for i in range(3):
             self.down.append(dict(xhat=self._t(self.M[i], dims[i]), rstd=self._t(self.M[i], dtype=f32),
@@ -307,7 +307,7 @@ class Engine:
         ps_blocks = [blk for blk in self.blocks if self._ps_ok(blk["stage"])]
         self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks), dtype=f32, device=dev)
         off = 0
-        for blk in self.blocks + [self.dec]:
+        for blk in self.blocks + self.decs:
             G, H = blk["G"], blk["H"]
             for nm in ("G2", "S0", "S1"):
                 blk[nm] = self.stats[off:off + G * H]
@@ -324,8 +324,8 @@ class Engine:
         npc = max(1, len([m for m in cfg.out_mods if m.kind == "pix_cont"]))
         self.patch_buf = torch.zeros(npc, 4, N * L, dtype=f32, device=dev)
         # backward scratch
-        maxMH = max(b["M"] * b["H"] for b in self.blocks + [self.dec])
-        maxMC = max(max(b["M"] * b["C"] for b in self.blocks + [self.dec]), self.Mfull * C0)
+        maxMH = max(b["M"] * b["H"] for b in self.blocks + self.decs)
+        maxMC = max(max(b["M"] * b["C"] for b in self.blocks + self.decs), self.Mfull * C0)
         self.scr_dz2 = [self._t(maxMH) for _ in range(int(self.opt["dz_ring"]))]   # dz / dh, one per block in turn (side lane reads dh)
         self.scr_dz = self.scr_dz2[0]
         self.scr_dxn = self._t(maxMC)
@@ -394,7 +394,8 @@ class Engine:
             add(f"down{i}.W", kk, 4 * Ci, Co, Co, 1)             # [4C][C']
         add("proj.W", P["proj.weight"], D, dims[3], dims[3], 1)
         add("proj.WT", P["proj.weight"], dims[3], D, 1, dims[3])
-        block_weights(self.dec["prefix"], D, False)
+        for d_ in self.decs:
+            block_weights(d_["prefix"], D, False)
         pixT = imgT = None
         coff_p = coff_i = 0
         for om in cfg.out_mods:
@@ -1228,7 +1229,9 @@ class Engine:
                        N=D, K=dims[3], lda=dims[3], ldb=wp["ld"], ldc=D, vis=self.vis, keep=self.keep, L=L)
             self._op(f, "mask_token", lib.mpmae_fill_mask_token, dt, _p(self.xdec), _p(P["mask_token"]), _p(self.inv), N * L, D,
                      None, 0, 0)
-        y = self._block_fwd(f, self.dec, self.xdec)
+        y = self.xdec
+        for d_ in self.decs:
+            y = self._block_fwd(f, d_, y)
         self.dec_out = y
         # heads
         coff = 0
@@ -1488,7 +1491,11 @@ class Engine:
                      _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
         # decoder block
         dxdec = self.scr_dxA[:N * L * D]
-        self._block_bwd(b, self.dec, self.dy, dxdec)
+        cur_d = self.dy
+        for j in range(len(self.decs) - 1, -1, -1):
+            out_d = dxdec if j == 0 else self.dec_dx[j - 1]
+            self._block_bwd(b, self.decs[j], cur_d, out_d)
+            cur_d = out_d
         wpt = self.w["proj.WT"]
         cur = self.scr_dxB[:self.M[3] * dims[3]]
         if self.proj_compact:

@@ -54,17 +54,18 @@ def state_dict_spec(cfg: ModelCfg):
     add(("proj.bias", (D,), "b"))
     add(("mask_token", (1, D, 1, 1), "b"))
     first = cfg.out_mods[0].name
-    p = f"decoder_dict.{first}.0"
-    add((p + ".dwconv.weight", (D, 1, 7, 7), "w"))
-    add((p + ".dwconv.bias", (D,), "b"))
-    add((p + ".norm.weight", (D,), "g"))
-    add((p + ".norm.bias", (D,), "b"))
-    add((p + ".pwconv1.weight", (4 * D, D), "w"))
-    add((p + ".pwconv1.bias", (4 * D,), "b"))
-    add((p + ".grn.gamma", (1, 1, 1, 4 * D), "gb"))
-    add((p + ".grn.beta", (1, 1, 1, 4 * D), "gb"))
-    add((p + ".pwconv2.weight", (D, 4 * D), "w"))
-    add((p + ".pwconv2.bias", (D,), "b"))
+    for j in range(cfg.decoder_depth):      # nn.Sequential of decoder_depth Blocks (fcmae.py:119-121)
+        p = f"decoder_dict.{first}.{j}"
+        add((p + ".dwconv.weight", (D, 1, 7, 7), "w"))
+        add((p + ".dwconv.bias", (D,), "b"))
+        add((p + ".norm.weight", (D,), "g"))
+        add((p + ".norm.bias", (D,), "b"))
+        add((p + ".pwconv1.weight", (4 * D, D), "w"))
+        add((p + ".pwconv1.bias", (4 * D,), "b"))
+        add((p + ".grn.gamma", (1, 1, 1, 4 * D), "gb"))
+        add((p + ".grn.beta", (1, 1, 1, 4 * D), "gb"))
+        add((p + ".pwconv2.weight", (D, 4 * D), "w"))
+        add((p + ".pwconv2.bias", (D,), "b"))
     for m in cfg.out_mods:
         if m.kind.startswith("pix"):
             add((f"pred_dict.{m.name}.weight", (m.head_out, D, 1, 1), "w"))
@@ -115,7 +116,7 @@ def expand_aliases(cfg: ModelCfg, sd):
     modality (aliases of the same tensors, fcmae.py:137,145)."""
     first = cfg.out_mods[0].name
     out = OrderedDict()
-    pre = f"decoder_dict.{first}.0."
+    pre = f"decoder_dict.{first}."
     for k, v in sd.items():
         if k.startswith(pre):
             continue
@@ -124,7 +125,7 @@ def expand_aliases(cfg: ModelCfg, sd):
     for m in cfg.out_mods:
         for k, v in sd.items():
             if k.startswith(pre):
-                out[f"decoder_dict.{m.name}.0." + k[len(pre):]] = v
+                out[f"decoder_dict.{m.name}." + k[len(pre):]] = v
     return out
 
 

@@ -161,7 +161,9 @@ def decoder(sd, x, mask, cfg, taps=None):
     if taps is not None:
         taps["dec_in"] = x
     first = cfg.out_mods[0].name
-    y = dense_block(sd, f"decoder_dict.{first}.0", x)
+    y = x
+    for j in range(getattr(cfg, "decoder_depth", 1)):      # nn.Sequential of decoder_depth Blocks (fcmae.py:119-121)
+        y = dense_block(sd, f"decoder_dict.{first}.{j}", y)
     if taps is not None:
         taps["dec_out"] = y
     pred = OrderedDict()

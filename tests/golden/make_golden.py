@@ -40,7 +40,7 @@ def run_reference(c, cfg, sd, inputs, noise_seed):
     loss_fn = (ref.custom_loss.UncertaintyWeightingStrategy(len(cfg.out_mods))
                if c["aggr"] == "uncertainty" else None)
     model = ref.fcmae.__dict__[c["model"]](
-        mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=c["norm_pix"],
+        mask_ratio=0.6, decoder_depth=c.get("decoder_depth", 1), decoder_embed_dim=512, norm_pix_loss=c["norm_pix"],
         patch_size=c["patch"], img_size=c["img"], args=args, loss_fn=loss_fn, sparse=True)
     full = expand_aliases(cfg, sd)
     missing = model.load_state_dict(full, strict=True)

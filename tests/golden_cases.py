@@ -28,6 +28,9 @@ CASES = OrderedDict(
     allmod_atto_56_zeropix=dict(model="convnextv2_atto", img=56, patch=8, subset="all_mod", N=2,
                                 norm_pix=True, aggr="uncertainty", wseed=16, iseed=26, nseed=36,
                                 zero_pix=True),
+    # decoder_depth = 2 (fcmae.py:119-121: an nn.Sequential of decoder_depth Blocks shared by every modality)
+    allmod_atto_56_dec2=dict(model="convnextv2_atto", img=56, patch=8, subset="all_mod", N=2,
+                             norm_pix=True, aggr="uncertainty", wseed=17, iseed=27, nseed=37, decoder_depth=2),
 )
 
 GRAD_SLICES = {
@@ -45,7 +48,7 @@ GRAD_SLICES = {
 
 def case_cfg(c):
     return make_cfg(c["model"], c["img"], c["patch"], out_modalities=M.subset(c["subset"]),
-                    norm_pix_loss=c["norm_pix"], loss_aggr=c["aggr"])
+                    norm_pix_loss=c["norm_pix"], loss_aggr=c["aggr"], decoder_depth=c.get("decoder_depth", 1))
 
 
 def case_data(c, cfg):
