@@ -496,6 +496,10 @@ int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
 typedef struct MpmaeMeters {
   const float* losses; const float* weighted; int T;
   float* ring; int window; float* sums; float* gnorm2;
+  /* error words of the persistent stage kernels' grid barriers (mpmae_ps_fwd / _bwd: args->sync[2] != 0 after a spin timeout, i.e. a
+   * workgroup that never became resident): n_err rows of err_stride unsigneds, word 2 of each. Any non-zero word makes hp_fetch skip
+   * this update like a non-finite loss (hp[4] = 1, hp[5] += 1) and counts it in hp[6]; NULL / 0: not checked. */
+  const unsigned* err_words; int n_err; int err_stride;
 } MpmaeMeters;
 int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total,
                    const MpmaeMeters* meters, mpmae_stream_t stream);

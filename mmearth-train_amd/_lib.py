@@ -141,7 +141,7 @@ class PsBwdArgs(C.Structure):
 
 class Meters(C.Structure):
     _fields_ = [("losses", c_void_p), ("weighted", c_void_p), ("T", c_int), ("ring", c_void_p), ("window", c_int),
-                ("sums", c_void_p), ("gnorm2", c_void_p)]
+                ("sums", c_void_p), ("gnorm2", c_void_p), ("err_words", c_void_p), ("n_err", c_int), ("err_stride", c_int)]
 
 
 class StemTailArgs(C.Structure):

@@ -1935,10 +1935,11 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
 int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total, const MpmaeMeters* meters,
                    mpmae_stream_t s) {
   if (!ring_pinned || slots < 1 || !counter || !hp) return (int)hipErrorInvalidValue;
-  MeterP mt{nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr};
+  MeterP mt{nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, 0, 0};
   if (meters && meters->ring) {
     if (!meters->losses || !meters->sums || !meters->gnorm2 || meters->T < 1 || meters->window < 1) return (int)hipErrorInvalidValue;
-    mt = MeterP{meters->losses, meters->weighted, meters->T, meters->ring, meters->window, meters->sums, meters->gnorm2};
+    mt = MeterP{meters->losses, meters->weighted, meters->T, meters->ring, meters->window, meters->sums, meters->gnorm2,
+                meters->err_words, meters->err_words ? meters->n_err : 0, meters->err_stride};
   }
   LAUNCH(hp_fetch_kernel, dim3(1), dim3(1024), 0, S_(s), ring_pinned, slots, counter, hp, total, mt);
   RET();

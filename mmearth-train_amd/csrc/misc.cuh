@@ -215,7 +215,8 @@ __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ ds
 // losses, total loss, gradient norm} plus running sums [2T + 2] and a count, written here at no extra launch; the gradient norm of a
 // step is accumulated by adamw_kernel (sum g^2 of the exchanged gradients) and lands in ITS record at the next fetch. The host reads
 // ring + sums with one copy per print, ranks fold their sums with one all-reduce per epoch.
-struct MeterP { const float* losses; const float* weighted; int T; float* ring; int window; float* sums; float* gnorm2; };
+struct MeterP { const float* losses; const float* weighted; int T; float* ring; int window; float* sums; float* gnorm2;
+                const unsigned* err_words; int n_err; int err_stride; };
 __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
                                                        const float* __restrict__ total, const MeterP mt) {
   // 1024 threads, every global read issued up front from a clamped address (a runtime-length loop of dependent loads was 64 serial
@@ -224,6 +225,10 @@ __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict_
   const int c = *counter;
   const float gs_prev = hp[3];
   const float tot = total ? *total : 0.f;
+  // `total` is the guard loss: in a data-parallel run the all-reduced SUM of the ranks' losses (every rank takes the same skip
+  // decision). The meter records the MEAN over ranks like the reference's all_reduce_mean (engine_pretrain.py:104): this step's
+  // grad_scale (= 1 / world, 1 on a single rank) is the averaging factor of the same exchange.
+  const float gs_new = ring[(size_t)(c % R) * 4 + 3];
   if (mt.ring) {
     const int W = 2 * mt.T + 2;
     const float cntf = mt.sums[W], nbf = mt.gnorm2[0];
@@ -231,7 +236,7 @@ __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict_
 #pragma unroll
     for (int j = 0; j < 4; ++j) g[j] = mt.gnorm2[1 + threadIdx.x + j * 1024];           // capacity 4096 partials (engine.gnorm2)
     const int i = min((int)threadIdx.x, W - 2);
-    const float lv = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : tot;
+    const float lv = i < mt.T ? mt.losses[i] : i < 2 * mt.T ? (mt.weighted ? mt.weighted[i - mt.T] : 0.f) : tot * gs_new;
     const float sv = mt.sums[i], sg = mt.sums[W - 1];
     const int cnt = (int)cntf, nb = (int)nbf;
     float t = 0.f;
@@ -262,9 +267,14 @@ __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict_
     *counter = c + 1;
     // engine_pretrain.py:83-85 stops on a non-finite loss BEFORE the optimizer step; here the check stays on the
     // device: hp[4] makes this step's AdamW a no-op, hp[5] counts skipped steps (the host polls it lazily)
-    const bool bad = !(fabsf(tot) <= 3.0e38f);
+    // ... and a persistent stage kernel whose grid barrier timed out trained this step on partial GRN statistics (ps.cuh
+    // grid_barrier): same treatment, counted separately in hp[6] so that the host can tell the two apart
+    unsigned perr = 0;
+    for (int i = 0; i < mt.n_err; ++i) perr |= mt.err_words[(size_t)i * mt.err_stride + 2];
+    const bool bad = !(fabsf(tot) <= 3.0e38f) || perr != 0;
     hp[4] = bad ? 1.f : 0.f;
     if (bad) hp[5] += 1.f;
+    if (perr) hp[6] += 1.f;
   }
 }
 

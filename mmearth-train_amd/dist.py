@@ -446,6 +446,11 @@ class StepRunner:
         """Updates skipped because the loss was non-finite (device-side guard in mpmae_hp_fetch); host sync."""
         return int(self.eng.hp[5].item())
 
+    def barrier_timeouts(self) -> int:
+        """Steps in which a persistent stage kernel's grid barrier timed out (a workgroup never became resident, e.g. another process
+        holds CUs): the update was skipped on the device (counted in skipped_steps() too); the activations of that step are invalid."""
+        return int(self.eng.hp[6].item())
+
     def mean_loss(self) -> float:
         if not self.exchange:
             return float(self.eng.total.item())

@@ -1630,6 +1630,11 @@ class Engine:
                         Kk=9 * cfg.in_chans, ldp=C0, ldq=0, dW=Gd["encoder.initial_conv.0.kernel"], sn=1, sk=C0,
                         db=Gd["encoder.initial_conv.0.bias"], vis=self.vis, inv=self.inv, keep=self.keep, L=L, S=self.p,
                         Cseg=cfg.in_chans, grid=self.grid, H=cfg.img_size)
+            # this weight gradient gathers its taps from the INPUT IMAGE (and the mask tables): it, not the last loss-gradient op, is the
+            # last reader of the static input buffers - the asynchronous input stage of the next batch must wait for it
+            if b[-1][3]["signal"] is None:
+                b[-1][3]["signal"] = "inputs_free_stem"
+            self._inputs_free_key = b[-1][3]["signal"]
 
     # ------------------------------------------------------------------ execution
     def _stream(self):
@@ -1830,6 +1835,8 @@ class Engine:
             m.losses, m.T = self.losses.data_ptr(), len(self.cfg.out_mods)
             m.weighted = self.weighted.data_ptr() if self.cfg.loss_aggr == "uncertainty" else 0
             m.ring, m.window, m.sums, m.gnorm2 = self.meter_ring.data_ptr(), self.METER_WINDOW, self.meter_sums.data_ptr(), self.gnorm2.data_ptr()
+            if hasattr(self, "ps_sync"):       # grid-barrier error words of the persistent stage kernels: a timeout skips the update and is counted in hp[6]
+                m.err_words, m.n_err, m.err_stride = self.ps_sync.data_ptr(), int(self._ps_launches), int(self.ps_sync.shape[1])
             self._meters_rec = m
         return C.byref(self._meters_rec)
 
@@ -1894,7 +1901,14 @@ class Engine:
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
         # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane
         # event - the stem GEMM waiting for the weight staging - covers the statistics; the gradient finalisation waits for "grads_zero")
-        fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), zl)]
+        fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), dict(zl, signal="stats_zero") if zs else zl)]
+        if zs:      # the first statistics producer of the main lane waits for the fill explicitly (program_run drops the wait when an earlier
+            # main-lane wait for a later side-lane event already implies it; without prep_side / in fp8 mode nothing else orders them: ADVICE r3)
+            for op in self.fwd_ops:
+                if op[3]["lane"] == 0 and (op[0].endswith((":ln+pw1", ":pw1")) or ":ps.fwd" in op[0]):
+                    if "stats_zero" not in op[3]["wait"]:
+                        op[3]["wait"] = tuple(op[3]["wait"]) + ("stats_zero",)
+                    break
         # ... and the forward's own finalisation is dropped: the one in front of the backward computes the same losses / total plus
         # d total / d log_vars (a caller that replays ONLY the forward piece reads its losses through Engine.forward instead)
         fwd += list(self.fwd_ops) + ([] if zs else [fin(False)])

@@ -83,6 +83,9 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, args, runner=N
             m = runner.eng.read_meters()
             if "loss" in m:
                 loss_value = m["loss"]["value"]
+                if runner.barrier_timeouts() > 0:
+                    raise RuntimeError("a persistent stage kernel timed out at its grid barrier (a workgroup never became resident - is another "
+                                       "process using this GPU?); the update was skipped. Re-run with Engine option ps=0 to use the per-block kernels")
                 if not math.isfinite(loss_value) or runner.skipped_steps() > 0:
                     print("Loss is {}, stopping training".format(loss_value))
                     sys.exit(1)

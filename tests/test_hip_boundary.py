@@ -481,3 +481,34 @@ def test_device_meters_match_host_recomputation(mode):
         assert abs(got["global_avg"] - series[:n].mean().item()) <= 1e-4 * abs(series[:n].mean().item()), name
     g = eng.meter_global_averages()           # per-epoch form: includes the last update's norm, one (here trivial) cross-rank fold
     assert abs(g["grad_norm"] - gn.mean().item()) <= 1e-4 * gn.mean().item() and abs(g["loss"] - tot.mean().item()) <= 1e-4 * tot.mean().item()
+
+
+def test_meter_records_the_rank_mean_loss_and_a_barrier_timeout_skips_the_update():
+    """(a) with the data-parallel exchange on, mpmae_hp_fetch receives the all-reduced SUM of the rank losses as its guard
+    value; the meter's `loss` column must hold the MEAN over ranks (the reference logs all_reduce_mean(loss), engine_pretrain.py:104):
+    emulated here at "world 4" by handing the kernel 4 x loss with grad_scale 1/4. (b) A non-zero grid-barrier error word of a
+    persistent stage kernel makes the optimizer launch a no-op (parameters unchanged) and is counted in hp[5] / hp[6]."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], "bf16", sd, inputs, noise)
+    eng.forward(); eng.backward()
+    eng.reset_meters()
+    L = eng.total.item()
+    guard = (eng.total * 4.0).clone()
+    eng.step_count += 1
+    eng.set_hyper(1e-3, eng.step_count, grad_scale=0.25)
+    eng.launch_adamw(guard_loss=guard)
+    torch.cuda.synchronize()
+    m = eng.read_meters()
+    assert abs(m["loss"]["value"] - L) <= 1e-6 * abs(L), (m["loss"]["value"], L)
+    assert eng.hp[5].item() == 0 and eng.hp[6].item() == 0
+    assert hasattr(eng, "ps_sync"), "the default bf16 engine runs the persistent stage kernels"
+    before = eng.pflat.clone()
+    eng.ps_sync[0, 2] = 1                       # a timed-out barrier in the first persistent launch
+    eng.step_count += 1
+    eng.set_hyper(1e-3, eng.step_count)
+    eng.launch_adamw()
+    torch.cuda.synchronize()
+    assert torch.equal(eng.pflat, before), "the update must be skipped"
+    assert eng.hp[5].item() == 1 and eng.hp[6].item() == 1
