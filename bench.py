@@ -31,6 +31,7 @@ from mmearth_train_amd.synth import make_inputs, make_state_dict  # noqa: E402
 from mmearth_train_amd import dist as mdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_PEAK_TFS = 2500.0         # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 STEP_ROOFLINE_US = {            # sum over layers of max(t_MFMA, t_HBM) at bs256
     ("convnextv2_atto", 56, "all_mod"): 764.0,
     ("convnextv2_atto", 56, "pix_mod"): 759.0,
@@ -96,20 +97,36 @@ def per_kernel_times(eng, reps=3, by_name=False, split_lanes=False):
     return acc
 
 
-# bench "kind" -> HIP kernel symbol (as rocprofv3 prints it) of the launch that moves the data
-KIND_TO_KERNEL = {
-    "wgrad<NONE,NONE>": "gemm_tn2_kernel",
-    "dwconv7": "dwconv7_v6",
-    "dwconv7_wgrad": "dwconv7_wgrad_v5_kernel",
-    "grn_apply": "grn_apply_kernel",
-    "grn_bwd_apply": "grn_bwd_apply_kernel",
-    "rs<0>": "rsc_wide_kernel",
-    "rs<1>": "rsc_wide_kernel",
-    "rs<4>": "rsc_narrow_kernel",
-    "rs<5>": "rsc_narrow_kernel",
-    "gemm<NONE,STORE>": "gemm_nt_bf16_kernel",
-    "gemm_mx<STORE>": "gemm_nt3_kernel",
-    "gemm_mx<RESID>": "gemm_nt3_kernel",
+# bench op "kind" -> kernel FAMILY, and the HIP kernel symbols (as rocprofv3 prints them) that move a family's data. The second-stage
+# folds an entry point launches are part of its op (HIP events around the C-ABI call) and of its family (tools/families.py).
+def family_of(kind):
+    if kind.startswith("rs<"):
+        return "rs"
+    if kind.startswith("wgrad"):
+        return "wgrad"
+    if kind.startswith("dwconv7_wgrad"):
+        return "dwconv7_wgrad"
+    if kind.startswith("gemm"):
+        return "gemm_nt"
+    return kind
+
+
+FAMILY_SYMBOLS = {
+    "rs": ("rsc_wide_kernel", "rsc_narrow_kernel"),
+    "wgrad": ("gemm_tn2_kernel", "gemm_tn3_kernel", "gemm_tng_kernel", "gemm_tn_bf16_kernel"),
+    "dwconv7": ("dwconv7_band_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
+    "dwconv7_wgrad": ("dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
+    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt4_kernel", "gemm_nt3_kernel"),
+    "ps_fwd": ("ps_fwd_kernel",),
+}
+FAMILY_TEXT = {
+    "rs": "fused pointwise row-streaming kernels (LN + pwconv1 + GELU^2 sums, GRN + pwconv2 + residual, pwconv2 data gradient + GRN statistics, "
+          "GRN backward + pwconv1 data gradient + LN backward) with their statistic / LayerNorm-gradient folds",
+    "wgrad": "weight-gradient GEMMs dW = P^T Q (transpose-read, DMA-ring and grouped kernels) with their slab folds",
+    "dwconv7": "depthwise 7x7 forward / data gradient",
+    "dwconv7_wgrad": "depthwise 7x7 weight gradient with its folds",
+    "gemm_nt": "dense NT GEMMs (decoder block, heads, downsample, stage-3 pointwise)",
+    "ps_fwd": "persistent per-sample stage kernels (all blocks of stage 2 / 3 forward)",
 }
 
 
@@ -137,17 +154,30 @@ def _pmc_matches(a):
 PMC_PATH, PMC_SOURCE = _latest_pmc()
 
 
-def pmc_traffic(kind, path=None):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE x2 + WRITE_SIZE, see tools/pmc_traffic.py); None when that kernel was not sampled."""
+def _latest_families(a):
+    """Newest committed in-step family table (profiles/rNN/kernel_families.json, tools/families.py) sampled on THIS workload, or None."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    for d in sorted((x for x in (os.listdir(root) if os.path.isdir(root) else [])), reverse=True):
+        path = os.path.join(root, d, "kernel_families.json")
+        if os.path.isfile(path):
+            doc = json.load(open(path))
+            ref, _ = build_parser().parse_known_args(doc.get("meta", {}).get("bench_args", "").split())
+            if all(getattr(ref, k) == getattr(a, k) for k in ("model", "img", "patch", "subset", "batch", "dtype")):
+                return doc, f"profiles/{d}/kernel_families.json (rocprofv3 --kernel-trace of bench.py, commit {doc['meta'].get('commit', 'n/a')})"
+    return None, None
+
+
+def pmc_traffic(family, path=None):
+    """HBM bytes per launch of a family's main kernels from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    tools/pmc_traffic.py), averaged over the sampled launches of every symbol of the family; None when it was not sampled."""
     path = path or PMC_PATH
-    sym = KIND_TO_KERNEL.get(kind)
-    if sym is None or not path or not os.path.exists(path):
+    syms = FAMILY_SYMBOLS.get(family)
+    if not syms or not path or not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
     tot = n = 0
     for name, d in ks.items():
-        if sym in name:
+        if any(sym in name for sym in syms):
             tot += d["traffic_bytes"] * d["launches_sampled"]
             n += d["launches_sampled"]
     return int(tot / n) if n else None
@@ -157,7 +187,7 @@ def cpu_baseline(cfg, batches, steps, warm=3):
     """Oracle (CPU restatement, kind 'port') forward+backward+AdamW on the host cores: `warm` warm-up + `steps` timed fp32 steps
     per batch size (bs 4 and bs 32, 3 + 5). `value` is the best batch size's images/sec."""
     from oracle import mpmae_ref as O
-    ncores = min(os.cpu_count(), 16)       # more threads only add contention on these small ops
+    ncores = os.cpu_count()                # SURVEY 8d: every host core (stated in the line)
     torch.set_num_threads(ncores)
     sd = make_state_dict(cfg, seed=0)
     runs = []
@@ -279,13 +309,26 @@ def main():
 
     out = None
     if rank == 0:
-        # --- roofline of the dominant kernel: live per-launch HIP-event timing ---
+        # --- roofline of the dominant kernel FAMILY ---
+        # live: HIP events (on the launch stream) around every C-ABI call of an eager pass, an op's second-stage folds included;
+        # in-step: the committed rocprofv3 kernel trace of this workload (both lanes live), which also CHOOSES the family when present
         acc = per_kernel_times(eng)
         tot = sum(d["ms"] for d in acc.values())
-        dom_kind, dom = max(acc.items(), key=lambda kv: kv[1]["ms"])
+        fams = {}
+        for kind, d in acc.items():
+            f = fams.setdefault(family_of(kind), dict(ms=0.0, n=0, bytes=0, flops=0))
+            for k in f:
+                f[k] += d[k]
+        fam_doc, fam_src = _latest_families(a)
+        in_step = fam_doc["families"] if fam_doc else {}
+        cands = [k for k in fams if k in in_step and in_step[k]["us_per_step"] > 0]
+        dom_kind = max(cands, key=lambda k: in_step[k]["us_per_step"]) if cands else max(fams, key=lambda k: fams[k]["ms"])
+        dom = fams[dom_kind]
         avg_ms = dom["ms"] / dom["n"]
         avg_bytes = dom["bytes"] / dom["n"]
-        achieved = avg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        avg_flops = dom["flops"] / dom["n"]
+        mfma_bound = avg_flops / MFMA_PEAK_TFS / 1e12 > avg_bytes / HBM_PEAK_GBS / 1e9
+        achieved = (avg_flops / (avg_ms * 1e-3) / 1e12 if mfma_bound else avg_bytes / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0
         if a.profile_ops:
             acc2 = per_kernel_times(eng, split_lanes=True)
             tot2 = sum(d["ms"] for d in acc2.values())
@@ -305,16 +348,48 @@ def main():
         key = (a.model, a.img, a.subset)
         step_roof = STEP_ROOFLINE_US.get(key)
         traffic = pmc_traffic(dom_kind) if _pmc_matches(a) else None      # counters are per workload
-        roof = dict(bound="hbm", kernel=dom_kind, achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
-                    algorithmic_bytes=int(avg_bytes),
-                    kernel_avg_us=round(avg_ms * 1e3, 2), kernel_launches_per_step=dom["n"] // 3,
-                    kernel_share_of_step=round(dom["ms"] / tot, 3))
+        peak = MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS
+        ops_per_step = dom["n"] // 3
+        roof = dict(bound="mfma" if mfma_bound else "hbm", kernel=dom_kind, kernel_family=FAMILY_TEXT.get(dom_kind, dom_kind),
+                    kernel_symbols=list(FAMILY_SYMBOLS.get(dom_kind, ())),
+                    achieved=round(achieved, 1), peak=peak, unit="TFLOP/s" if mfma_bound else "GB/s",
+                    frac=round(achieved / peak, 4), traffic=traffic,
+                    algorithmic_bytes=int(avg_bytes), algorithmic_flops=int(avg_flops),
+                    kernel_avg_us=round(avg_ms * 1e3, 2), kernel_launches_per_step=ops_per_step,
+                    kernel_share_of_step=round(dom["ms"] / tot, 3),
+                    timing="live: HIP events around every C-ABI call of the family in an eager pass (an op = its kernel + the folds it launches)")
+        if dom_kind in in_step:
+            # the same family inside the real step (both lanes live): what the step pays; `frac` is the smaller of the two
+            us_step = in_step[dom_kind]["us_per_step"]
+            per_op = us_step / max(ops_per_step, 1)
+            ach_step = (avg_flops / (per_op * 1e-6) / 1e12 if mfma_bound else avg_bytes / (per_op * 1e-6) / 1e9) if per_op > 0 else 0.0
+            roof.update(in_step=dict(us_per_step=us_step, avg_us_per_op=round(per_op, 2), achieved=round(ach_step, 1),
+                                     frac=round(ach_step / peak, 4), share_of_kernel_time=in_step[dom_kind]["share_of_kernel_time"],
+                                     source=fam_src))
+            roof["frac"] = round(min(achieved, ach_step) / peak, 4)
         if traffic is not None:
             roof["traffic_source"] = PMC_SOURCE
         if step_roof and a.batch == 256:
             roof["step_roofline_us"] = step_roof
             roof["step_frac"] = round(step_roof / (ms_per_step * 1e3), 4)
+        pieces = None
+        if world == 1 and getattr(trainer, "prog", None) is not None and hasattr(trainer, "_span"):
+            # forward / backward / optimizer split of the recorded step (HIP events around replays of program ranges, unprofiled)
+            nseg = len(trainer.segments)
+
+            def timed(span, reps=20):
+                for _ in range(3):
+                    eng.run_program(trainer.prog, span)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    eng.run_program(trainer.prog, span)
+                e1.record()
+                torch.cuda.synchronize()
+                return round(e0.elapsed_time(e1) / reps * 1e3, 1)
+            pieces = dict(forward_us=timed(trainer._span(0, 0)), backward_us=timed(trainer._span(1, 1 + nseg)),
+                          forward_backward_us=timed(trainer._span(0, 1 + nseg)))
         out = dict(metric="pretrain images/sec (12x56x56 S2, bs256/GPU)" if a.img == 56 else "pretrain images/sec",
                    value=round(value, 1), unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=round(ms_per_step, 4), ms_per_step_median_hip_events=round(median_ms, 4),
@@ -328,6 +403,8 @@ def main():
                                            "ms_per_step_with_input_stage includes the D2D batch copy and device randn of every step, issued on an input stream "
                                            "behind the previous step's last reader of the input buffers (Engine.set_inputs_async)"),
                    roofline=roof)
+        if pieces:
+            out["piece_times"] = pieces
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_batch, a.cpu_steps)
         print(json.dumps(out), flush=True)

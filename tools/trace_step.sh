@@ -7,6 +7,7 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o st --output-format c
 python tools/kstats.py $O/stats/st_kernel_trace.csv 80 > $O/kernel_time_per_step.txt
 python tools/timeline.py $O/stats/st_kernel_trace.csv ${BACK:-12} > $O/timeline.txt
 python tools/lane_dump.py $O/stats/st_kernel_trace.csv ${BACK:-12} > $O/lanes_one_step.txt
+python tools/families.py $O/stats/st_kernel_trace.csv $O/kernel_families.json "$@" > $O/kernel_families.txt
 cp $O/stats/st_kernel_stats.csv $O/rocprofv3_kernel_stats.csv 2>/dev/null || true
 rm -rf $O/stats
 head -3 $O/kernel_time_per_step.txt; cat $O/timeline.txt
