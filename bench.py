@@ -54,6 +54,7 @@ def build_parser():
     ap.add_argument("--mode", default="program", choices=["program", "hipgraph", "eager"],
                     help="step driver: native launch program (default), HIP graph replay, or the Python loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)      # child process of cpu_baseline_all: N threads, JSON out
     ap.add_argument("--cpu-batch", type=int, nargs="+", default=[4, 32],
                     help="batch sizes of the CPU-oracle baseline (SURVEY 8d: 4 = BASELINE configs[0], and 32)")
     ap.add_argument("--profile-names", action="store_true", help="per-launch (by op name) time table to stderr")
@@ -183,11 +184,11 @@ def pmc_traffic(family, path=None):
     return int(tot / n) if n else None
 
 
-def cpu_baseline(cfg, batches, steps, warm=3):
+def cpu_baseline(cfg, batches, steps, warm=3, threads=None):
     """Oracle (CPU restatement, kind 'port') forward+backward+AdamW on the host cores: `warm` warm-up + `steps` timed fp32 steps
     per batch size (bs 4 and bs 32, 3 + 5). `value` is the best batch size's images/sec."""
     from oracle import mpmae_ref as O
-    ncores = os.cpu_count()                # SURVEY 8d: every host core (stated in the line)
+    ncores = threads or min(os.cpu_count(), 16)      # (every host core is tried too, in a time-boxed child process: cpu_baseline_all)
     torch.set_num_threads(ncores)
     sd = make_state_dict(cfg, seed=0)
     runs = []
@@ -223,6 +224,30 @@ def cpu_baseline(cfg, batches, steps, warm=3):
                        f"oracle/mpmae_ref.py (fwd+bwd+AdamW); value = batch {best['batch']}")
 
 
+def cpu_baseline_all(a, cfg):
+    """SURVEY 8d asks for the CPU port on EVERY host core. On the 256-core GPU host that is slower than 16 threads by orders of magnitude
+    (thread oversubscription on small ops: round 4's first attempt ran 40 minutes without finishing), so: the 16-thread leg in-process, the
+    all-core leg in a child process with a 90 s wall-clock box; both are reported, `value` is the faster one, `cores` its thread count."""
+    import subprocess
+    base = cpu_baseline(cfg, a.cpu_batch, a.cpu_steps)
+    n_all = os.cpu_count()
+    if n_all <= base["cores"]:
+        return base
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(n_all), "--model", a.model, "--img", str(a.img),
+           "--patch", str(a.patch), "--subset", a.subset, "--cpu-steps", str(a.cpu_steps), "--cpu-batch"] + [str(b) for b in a.cpu_batch]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=90)
+        allc = json.loads(r.stdout.strip().splitlines()[-1])
+        base["all_cores"] = dict(cores=n_all, value=allc["value"], runs=allc["runs"])
+        if allc["value"] > base["value"]:
+            base.update(value=allc["value"], cores=n_all, runs=allc["runs"], sample=allc["sample"])
+    except subprocess.TimeoutExpired:
+        base["all_cores"] = dict(cores=n_all, value=None, note="did not finish 3 + 5 steps at batch 4 and 32 within the 90 s box")
+    except Exception as e:          # noqa: BLE001 - the baseline must never take the bench line down
+        base["all_cores"] = dict(cores=n_all, value=None, note=f"failed: {type(e).__name__}")
+    return base
+
+
 def _free_port():
     import socket
     with socket.socket() as sk:
@@ -247,6 +272,10 @@ def _spawn_ranks(a):
 
 def main():
     a = parse()
+    if a.cpu_baseline_only:
+        cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
+        print(json.dumps(cpu_baseline(cfg, a.cpu_batch, a.cpu_steps, threads=a.cpu_baseline_only)), flush=True)
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         _spawn_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -406,7 +435,7 @@ def main():
         if pieces:
             out["piece_times"] = pieces
         if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, a.cpu_batch, a.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline_all(a, cfg)
         print(json.dumps(out), flush=True)
     if world > 1:
         mdist.barrier()

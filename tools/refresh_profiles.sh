@@ -20,7 +20,7 @@ if [ -z "$SKIP_PREFIX" ]; then
 fi
 # the bench line LAST: it reads the family table / PMC file the driver will find committed under profiles/
 mkdir -p profiles/r99_tmp && cp $O/kernel_families.json $O/pmc_traffic.json profiles/r99_tmp/ 2>/dev/null
-python bench.py ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err
+timeout 400 python bench.py ${BENCH_ARGS:-} > $O/bench.json 2> $O/bench.err
 rm -rf profiles/r99_tmp
 tail -1 $O/bench.json | cut -c1-1500
 head -5 $O/kernel_families.txt; cat $O/timeline.txt | head -4
