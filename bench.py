@@ -227,7 +227,7 @@ def cpu_baseline(cfg, batches, steps, warm=3, threads=None):
 def cpu_baseline_all(a, cfg):
     """SURVEY 8d asks for the CPU port on EVERY host core. On the 256-core GPU host that is slower than 16 threads by orders of magnitude
     (thread oversubscription on small ops: round 4's first attempt ran 40 minutes without finishing), so: the 16-thread leg in-process, the
-    all-core leg in a child process with a 90 s wall-clock box; both are reported, `value` is the faster one, `cores` its thread count."""
+    all-core leg in a child process with a 60 s wall-clock box; both are reported, `value` is the faster one, `cores` its thread count."""
     import subprocess
     base = cpu_baseline(cfg, a.cpu_batch, a.cpu_steps)
     n_all = os.cpu_count()
@@ -236,13 +236,13 @@ def cpu_baseline_all(a, cfg):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(n_all), "--model", a.model, "--img", str(a.img),
            "--patch", str(a.patch), "--subset", a.subset, "--cpu-steps", str(a.cpu_steps), "--cpu-batch"] + [str(b) for b in a.cpu_batch]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=90)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
         allc = json.loads(r.stdout.strip().splitlines()[-1])
         base["all_cores"] = dict(cores=n_all, value=allc["value"], runs=allc["runs"])
         if allc["value"] > base["value"]:
             base.update(value=allc["value"], cores=n_all, runs=allc["runs"], sample=allc["sample"])
     except subprocess.TimeoutExpired:
-        base["all_cores"] = dict(cores=n_all, value=None, note="did not finish 3 + 5 steps at batch 4 and 32 within the 90 s box")
+        base["all_cores"] = dict(cores=n_all, value=None, note="did not finish 3 + 5 steps at batch 4 and 32 within the 60 s box")
     except Exception as e:          # noqa: BLE001 - the baseline must never take the bench line down
         base["all_cores"] = dict(cores=n_all, value=None, note=f"failed: {type(e).__name__}")
     return base
