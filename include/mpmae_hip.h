@@ -141,6 +141,9 @@ typedef struct MpmaeImgArgs {
  * scale / coef are [M / rpg][H] (rpg = rows per GRN group; 0 = one group).
  * Field use per kernel is documented in those files. Replaces convnextv2_sparse.py:40-43,55 and
  * their autograd. */
+/* out[(e / a) * b + (e % a) * c] += sum_{p < P} part[p * W + e], e < W  (second stage of a two-stage reduction) */
+typedef struct MpmaeFoldDesc { const float* part; int P, W; float* out; int a, b, c; } MpmaeFoldDesc;
+
 typedef struct MpmaeRsArgs {
   const void* A; const void* A2; const void* W; int ldw;
   const float* bias; const float* v0; const float* v1;
@@ -165,8 +168,14 @@ typedef struct MpmaeRsArgs {
    * dz_w2t = staged W2^T [H][dz_ldw2]. which = 4 with the same fields recomputes h = xn W1^T + b1 instead of reading A:
    * dz_dout = xn [M,C], dz_w2t = staged W1 [H][dz_ldw2], dz_bias = b1 [H]. */
   const void* dz_dout; const void* dz_w2t; int dz_ldw2; const float* dz_bias;
+  /* Optional (which = 5): the fold of the LayerNorm gamma / beta gradient partials (one slab row per workgroup in `ws`) is NOT
+   * launched; its description is written to *defer_fold (HOST memory) instead, for a later mpmae_fold_group call - nothing on the
+   * data-gradient chain reads those gradients, so a training step folds the slabs of a whole stage on its weight-gradient lane.
+   * `ws` must then stay untouched until that call has run. */
+  MpmaeFoldDesc* defer_fold;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
+int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t stream);
 
 /* ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------------
  * ONE launch runs every Block of a sparse stage (convnextv2_sparse.py:47-56 x depth, with MinkowskiLayerNorm and the
@@ -400,6 +409,16 @@ int mpmae_ln_fwd_down(int dt, const void* x, void* xhat, float* rstd, void* y_gr
 int mpmae_ln_bwd_down(int dt, const void* dy_grouped, const void* xhat, const float* rstd,
                       const float* gamma, void* dx, float* dgamma, float* dbeta, int M, int C, int S,
                       const uint8_t* rowmask, float* ws, size_t ws_floats, mpmae_stream_t stream);
+/* The same backward with the fold of the gamma / beta gradient partials left to a later mpmae_fold_group call (see
+ * MpmaeRsArgs.defer_fold): *defer_fold (host memory) receives its description, `ws` must stay untouched until then. */
+int mpmae_ln_bwd_defer(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat,
+                       const float* rstd, const float* gamma, const float* beta, int act, void* dx,
+                       int accumulate, float* dgamma, float* dbeta, int M, int C, const uint8_t* rowmask,
+                       float* ws, size_t ws_floats, MpmaeFoldDesc* defer_fold, mpmae_stream_t stream);
+int mpmae_ln_bwd_down_defer(int dt, const void* dy_grouped, const void* xhat, const float* rstd,
+                            const float* gamma, void* dx, float* dgamma, float* dbeta, int M, int C, int S,
+                            const uint8_t* rowmask, float* ws, size_t ws_floats, MpmaeFoldDesc* defer_fold,
+                            mpmae_stream_t stream);
 /* MinkowskiGRN (batch-global, eps 1e-6; sparse_norm_layers.py:24-33) and GRN (per-sample,
  * eps 1e-4; norm_layers.py:41-44): statistics finalisation for G groups of H channels. */
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx,

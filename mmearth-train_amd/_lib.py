@@ -102,7 +102,12 @@ class RsArgs(C.Structure):
                 ("rpg", c_int),
                 ("fin_sum", c_void_p), ("fin_sum0", c_void_p), ("fin_gamma", c_void_p), ("fin_gx", c_void_p),
                 ("fin_ainv", c_void_p), ("fin_out", c_void_p), ("fin_dgamma", c_void_p), ("fin_dbeta", c_void_p),
-                ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p)]
+                ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p),
+                ("defer_fold", c_void_p)]
+
+
+class FoldDesc(C.Structure):
+    _fields_ = [("part", c_void_p), ("P", c_int), ("W", c_int), ("out", c_void_p), ("a", c_int), ("b", c_int), ("c", c_int)]
 
 
 PS_MAXBLK = 9          # MPMAE_PS_MAXBLK
@@ -178,11 +183,16 @@ SYMBOLS = {
     "mpmae_prep_weights": [c_int, c_void_p, c_int, c_int, c_void_p],
     "mpmae_gemm": [c_int, c_int, c_int, P(GemmArgs), c_void_p],
     "mpmae_wgrad": [c_int, c_int, c_int, P(WgradArgs), c_int, c_void_p],
+    "mpmae_fold_group": [P(FoldDesc), c_int, c_void_p],
     "mpmae_wgrad_group": [c_int, P(WgradArgs), c_int, c_void_p, c_size_t, c_void_p],
     "mpmae_ln_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float,
                      c_int, c_int, c_void_p, c_void_p],
     "mpmae_ln_bwd": [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                      c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
+    "mpmae_ln_bwd_defer": [c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                           c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
+    "mpmae_ln_bwd_down_defer": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p],
     "mpmae_grn_fwd_finalize": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_grn_bwd_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p],

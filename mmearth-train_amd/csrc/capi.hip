@@ -386,7 +386,8 @@ int mpmae_ln_fwd_down(int dt, const void* x, void* xhat, float* rstd, void* y_gr
 
 static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
                        const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
-                       int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, int down_S, mpmae_stream_t s) {
+                       int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, int down_S, mpmae_stream_t s,
+                       MpmaeFoldDesc* defer = nullptr) {
   if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
   if (down_S && ((C & 7) || C > 1024 || (down_S & 1))) return (int)hipErrorInvalidValue;
   int blocks = grid1d((long long)M * 64, 256, 1024);
@@ -421,7 +422,8 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
   if (dgamma && dbeta) {
     const long long delta = dbeta - dgamma;
     if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
-    launch_reduce(1, ws, blocks, 2 * C, dgamma, nullptr, C, (int)delta, 1, 0, S_(s));
+    if (defer) *defer = MpmaeFoldDesc{ws, blocks, 2 * C, dgamma, C, (int)delta, 1};
+    else launch_reduce(1, ws, blocks, 2 * C, dgamma, nullptr, C, (int)delta, 1, 0, S_(s));
   } else if (dgamma || dbeta) {
     return (int)hipErrorInvalidValue;     // both or neither
   }
@@ -441,6 +443,22 @@ int mpmae_ln_bwd_down(int dt, const void* dy_grouped, const void* xhat, const fl
   if (S < 2 || !dy_grouped) return (int)hipErrorInvalidValue;
   return ln_bwd_impl(dt, dy_grouped, 1, 1.0f, xhat, rstd, gamma, nullptr, 0, dx, 0, dgamma, dbeta, M, C, rowmask, ws,
                      ws_floats, S, s);
+}
+
+int mpmae_ln_bwd_defer(int dt, const void* dy, int dy_div, float dy_scale, const void* xhat, const float* rstd,
+                       const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
+                       int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, MpmaeFoldDesc* defer_fold, mpmae_stream_t s) {
+  if (!defer_fold || !dgamma || !dbeta) return (int)hipErrorInvalidValue;
+  return ln_bwd_impl(dt, dy, dy_div, dy_scale, xhat, rstd, gamma, beta, act, dx, accumulate, dgamma, dbeta, M, C, rowmask,
+                     ws, ws_floats, 0, s, defer_fold);
+}
+
+int mpmae_ln_bwd_down_defer(int dt, const void* dy_grouped, const void* xhat, const float* rstd, const float* gamma, void* dx,
+                            float* dgamma, float* dbeta, int M, int C, int S, const uint8_t* rowmask, float* ws, size_t ws_floats,
+                            MpmaeFoldDesc* defer_fold, mpmae_stream_t s) {
+  if (S < 2 || !dy_grouped || !defer_fold || !dgamma || !dbeta) return (int)hipErrorInvalidValue;
+  return ln_bwd_impl(dt, dy_grouped, 1, 1.0f, xhat, rstd, gamma, nullptr, 0, dx, 0, dgamma, dbeta, M, C, rowmask, ws,
+                     ws_floats, S, s, defer_fold);
 }
 
 int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G, int H, float* Gx, float* Ainv,
@@ -1470,7 +1488,8 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       // gridDim.x colliding updates per address land together at the kernel's tail)
       const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
       if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
-      launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+      if (a.defer_fold) *a.defer_fold = MpmaeFoldDesc{a.ws, rowblocks, 2 * KC, a.s0, KC, (int)delta, 1};
+      else launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
     }
 #undef RSC_NARROW
   } else {
@@ -1942,6 +1961,16 @@ int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp,
                 meters->err_words, meters->err_words ? meters->n_err : 0, meters->err_stride};
   }
   LAUNCH(hp_fetch_kernel, dim3(1), dim3(1024), 0, S_(s), ring_pinned, slots, counter, hp, total, mt);
+  RET();
+}
+
+int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t s) {
+  if (!descs || count < 0) return (int)hipErrorInvalidValue;
+  for (int i = 0; i < count; ++i) {
+    const MpmaeFoldDesc& d = descs[i];
+    if (!d.part || !d.out || d.P < 1 || d.W < 1 || d.a < 1) return (int)hipErrorInvalidValue;
+    launch_reduce(1, d.part, d.P, d.W, d.out, nullptr, d.a, d.b, d.c, 0, S_(s));
+  }
   RET();
 }
 

@@ -68,6 +68,7 @@ ENGINE_OPTIONS = dict(
     hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
     dzr_maxc=80,            # largest C recomputing dz
     dw_group=1,             # ... and ONE launch for its depthwise weight gradients (mpmae_dwconv7_wgrad_group), from this stage index on (stage 0 stays per block: its weight gradients are the tail of the backward; 9 = never)
+    ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
 )
 
@@ -454,6 +455,25 @@ class Engine:
         *a, stream = args
         return self.lib.mpmae_ln_bwd_down(*a, _p(self.ws), self.ws_floats, stream)
 
+    def _ln_bwd_callable(self, Cc, down=False):
+        """The LayerNorm-backward entry point of one op. With `ln_fold_defer` (bf16, two lanes) the op gets a slab of its own and a
+        host-side fold record: the gamma / beta gradient fold is launched later by the segment's mpmae_fold_group on the side lane."""
+        if not (self.lanes and self.dt == BF16 and bool(self.opt["ln_fold_defer"])):
+            return self._ln_bwd_down_fn if down else self._ln_bwd_fn
+        slab = torch.empty(1024 * 2 * Cc, dtype=torch.float32, device=self.device)      # <= 1024 workgroups (one slab row each)
+        fd = _lib.FoldDesc()
+        self._keepalive += [slab, fd]
+        if not hasattr(self, "_fold_pending"):
+            self._fold_pending = []
+        self._fold_pending.append(fd)
+        fn = self.lib.mpmae_ln_bwd_down_defer if down else self.lib.mpmae_ln_bwd_defer
+
+        def call(*args, _slab=slab, _fd=fd, _fn=fn):
+            *a, stream = args
+            return _fn(*a, _p(_slab), _slab.numel(), C.addressof(_fd), stream)
+        call.__name__ = "mpmae_ln_bwd_down" if down else "mpmae_ln_bwd"
+        return call
+
     def _colstats_fn(self, *args):
         *a, stream = args
         return self.lib.mpmae_colstats(*a, _p(self.ws), self.ws_floats, stream)
@@ -539,6 +559,22 @@ class Engine:
                  kind="wgrad_group", nbytes=nbytes, flops=flops, lane=1, wait=(k,) if k else (), signal=key)
         for _, reads, _ in pend:
             self._side_read(key, *reads)
+
+    def _fold_flush(self, lst, stage):
+        pend = getattr(self, "_fold_pending", [])
+        if not pend:
+            return
+        self._fold_pending = []
+        arr = (_lib.FoldDesc * len(pend))()
+        self._keepalive.append(arr)
+        srcs = list(pend)
+
+        def fold(stream, _arr=arr, _srcs=srcs):      # the records are filled by the mpmae_rs calls of the stage (recorded / issued before this op)
+            for i_, fd in enumerate(_srcs):
+                _arr[i_] = fd
+            return self.lib.mpmae_fold_group(_arr, len(_srcs), stream)
+        k = self._after(lst)
+        self._op(lst, f"{stage}:ln.fold[{len(pend)}]", fold, kind="ln_fold_group", lane=1, wait=(k,) if k else ())
 
     def _write_waits(self, *tensors):
         """Event keys a main-lane op must wait for before overwriting these scratch tensors."""
@@ -649,7 +685,8 @@ class Engine:
         for k, v in kw.items():
             setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
         a.M, a.C, a.H = blk["M"], blk["C"], blk["H"]
-        a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+        if "ws" not in kw:
+            a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
         self._keepalive.append(a)
         self._op(lst, name, self.lib.mpmae_rs, which, C.byref(a), kind=f"rs<{which}>", nbytes=nbytes, flops=flops)
 
@@ -958,6 +995,16 @@ class Engine:
                      _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
         if rsc:  # dh (written over dz) in the operand prologue, pwconv1 data gradient, LayerNorm backward
             dzkw = dict(dz_dout=dout, dz_w2t=w2t["t"], dz_ldw2=w2t["ld"]) if dzr else {}
+            if self.lanes and bool(self.opt["ln_fold_defer"]) and blk["sparse"]:
+                # its own slab (nothing else may touch it until the stage's fold op has run) + a host-side fold record
+                if "ln_slab" not in blk:
+                    blk["ln_slab"] = torch.empty(((M + 63) // 64 + 1) * 2 * Cc, dtype=torch.float32, device=self.device)
+                if not hasattr(self, "_fold_pending"):
+                    self._fold_pending = []
+                fd = _lib.FoldDesc()
+                self._keepalive.append(fd)
+                self._fold_pending.append(fd)
+                dzkw = dict(dzkw, ws=blk["ln_slab"], ws_floats=blk["ln_slab"].numel(), defer_fold=C.addressof(fd))
             self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, ((2 if dzr else 3) * M * H + (3 if dzr else 2) * M * Cc) * esz,
                      (4 if dzr else 2) * M * Cc * H,
                      A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
@@ -986,7 +1033,7 @@ class Engine:
         elif not late_all:
             self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         if rs_n is None:
-            self._op(lst, tag + ":ln.bwd", self._ln_bwd_fn, dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
+            self._op(lst, tag + ":ln.bwd", self._ln_bwd_callable(Cc), dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
             self._guard(lst, dd)
@@ -1486,9 +1533,10 @@ class Engine:
             # keeps this tiny GEMM on the fast kernel
             self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
                        K=self.ldimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
-            self._op(b, "head:ln.bwd", self._ln_bwd_fn, dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
+            self._op(b, "head:ln.bwd", self._ln_bwd_callable(D), dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
                      _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, _p(self.dy), 1 if have_pix else 0,
                      _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
+        self._fold_flush(b, "head")              # (inside the heads' gradient bucket: the exchange of a bucket must see its folds)
         # decoder block
         dxdec = self.scr_dxA[:N * L * D]
         cur_d = self.dy
@@ -1516,6 +1564,7 @@ class Engine:
             self._gemm(b, "proj.dgrad", "ROW_GATHER", "STORE", A=dxdec, B=wpt["t"], C=cur, M=self.M[3], N=dims[3], K=D, lda=D,
                        ldb=wpt["ld"], ldc=dims[3], vis=self.vis, keep=self.keep, L=L, act=self.act[3])
         self._guard(b, cur)
+        self._fold_flush(b, f"decoder_dict.{cfg.out_mods[0].name}")
         ring, ri = self.scr_dx, 2 % len(self.scr_dx)      # dxdec = ring[0], cur = ring[1]
         other = ring[ri]
         bi = len(self.blocks) - 1
@@ -1536,6 +1585,7 @@ class Engine:
                 bi -= 1
             self._dwg_flush(b)            # the stage's grouped depthwise / pointwise weight gradients: side lane, behind its data-gradient chain
             self._group_flush(b)
+            self._fold_flush(b, f"encoder.stages.{i}")
             if i > 0:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
@@ -1556,7 +1606,7 @@ class Engine:
                     dyg = self.scr_dxn[:self.M[i] * 4 * Ci]
                     self._gemm(b, pre + ":dgrad", "NONE", "STORE", A=cur, B=wd["t"], C=dyg, M=self.M[i], N=4 * Ci, K=Co,
                                lda=Co, ldb=wd["ld"], ldc=4 * Ci)
-                    self._op(b, pre + ":ln.bwd", self._ln_bwd_down_fn, dt, _p(dyg), _p(dn["xhat"]), _p(dn["rstd"]),
+                    self._op(b, pre + ":ln.bwd", self._ln_bwd_callable(Ci, down=True), dt, _p(dyg), _p(dn["xhat"]), _p(dn["rstd"]),
                              _p(P[pre + ".0.ln.weight"]), _p(nxt), _p(Gd[pre + ".0.ln.weight"]), _p(Gd[pre + ".0.ln.bias"]),
                              self.M[i - 1], Ci, self.S[i - 1], _p(self.act[i - 1]), kind="ln_bwd_down",
                              nbytes=3 * self.M[i - 1] * Ci * (4 if dt == F32 else 2))
