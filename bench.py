@@ -131,47 +131,38 @@ FAMILY_TEXT = {
 }
 
 
-def _latest_pmc():
-    """Newest committed PMC traffic file (profiles/rNN/pmc_traffic.json) and a provenance stamp for the JSON line."""
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = sorted(d for d in (os.listdir(root) if os.path.isdir(root) else []) if os.path.isfile(os.path.join(root, d, "pmc_traffic.json")))
-    if not cands:
-        return None, None
-    path = os.path.join(root, cands[-1], "pmc_traffic.json")
-    meta = json.load(open(path)).get("meta", {})
-    return path, (f"profiles/{cands[-1]}/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; commit {meta.get('commit', 'n/a')}; "
-                  f"bench args '{meta.get('bench_args', '')}')")
-
-
-def _pmc_matches(a):
-    """The committed counters were sampled on ONE workload: only quote them for a run of the same model / size / subset / batch / dtype."""
-    if not PMC_PATH:
-        return False
-    args = json.load(open(PMC_PATH)).get("meta", {}).get("bench_args", "")
-    ref, _ = build_parser().parse_known_args(args.split())
+def _args_match(a, bench_args):
+    ref, _ = build_parser().parse_known_args(bench_args.split())
     return all(getattr(ref, k) == getattr(a, k) for k in ("model", "img", "patch", "subset", "batch", "dtype"))
 
 
-PMC_PATH, PMC_SOURCE = _latest_pmc()
-
-
-def _latest_families(a):
-    """Newest committed in-step family table (profiles/rNN/kernel_families.json, tools/families.py) sampled on THIS workload, or None."""
+def _latest_profile(a, stem):
+    """Newest committed profiles/rNN/<stem>*.json whose meta.bench_args name THIS workload (model / size / subset / batch / dtype):
+    counters and traces are per workload and only quoted for a run of the same one. Returns (path, document) or (None, None)."""
+    import glob
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     for d in sorted((x for x in (os.listdir(root) if os.path.isdir(root) else [])), reverse=True):
-        path = os.path.join(root, d, "kernel_families.json")
-        if os.path.isfile(path):
-            doc = json.load(open(path))
-            ref, _ = build_parser().parse_known_args(doc.get("meta", {}).get("bench_args", "").split())
-            if all(getattr(ref, k) == getattr(a, k) for k in ("model", "img", "patch", "subset", "batch", "dtype")):
-                return doc, f"profiles/{d}/kernel_families.json (rocprofv3 --kernel-trace of bench.py, commit {doc['meta'].get('commit', 'n/a')})"
+        for path in sorted(glob.glob(os.path.join(root, d, stem + "*.json"))):
+            try:
+                doc = json.load(open(path))
+            except Exception:      # noqa: BLE001
+                continue
+            if _args_match(a, doc.get("meta", {}).get("bench_args", "")):
+                return path, doc
     return None, None
 
 
-def pmc_traffic(family, path=None):
+def _latest_families(a):
+    """In-step family table (tools/families.py) of this workload, or (None, None)."""
+    path, doc = _latest_profile(a, "kernel_families")
+    if not path:
+        return None, None
+    return doc, f"{os.path.relpath(path, os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 --kernel-trace of bench.py, commit {doc['meta'].get('commit', 'n/a')})"
+
+
+def pmc_traffic(family, path):
     """HBM bytes per launch of a family's main kernels from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE, see
     tools/pmc_traffic.py), averaged over the sampled launches of every symbol of the family; None when it was not sampled."""
-    path = path or PMC_PATH
     syms = FAMILY_SYMBOLS.get(family)
     if not syms or not path or not os.path.exists(path):
         return None
@@ -331,6 +322,13 @@ def main():
         trainer.step()
     torch.cuda.synchronize()
     ms_with_inputs = (time.perf_counter() - t1) / n_in * 1e3
+    per_rank = [elapsed]
+    if world > 1:          # every rank's own wall time of the timed region (the line's value uses the slowest)
+        import torch.distributed as tdist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        tdist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
     elapsed = mdist.max_over_ranks(elapsed) if world > 1 else elapsed
     loss = float(eng.total.item())
     ms_per_step = elapsed / a.steps * 1e3
@@ -376,7 +374,8 @@ def main():
                 print(f"{k:58s} {d['ms'] / 3 * 1e3:9.1f} us {gbs:8.0f} GB/s {tfs:8.1f} TF/s", file=sys.stderr)
         key = (a.model, a.img, a.subset)
         step_roof = STEP_ROOFLINE_US.get(key)
-        traffic = pmc_traffic(dom_kind) if _pmc_matches(a) else None      # counters are per workload
+        pmc_path, pmc_doc = _latest_profile(a, "pmc_traffic")      # counters are per workload
+        traffic = pmc_traffic(dom_kind, pmc_path) if pmc_path else None
         peak = MFMA_PEAK_TFS if mfma_bound else HBM_PEAK_GBS
         ops_per_step = dom["n"] // 3
         roof = dict(bound="mfma" if mfma_bound else "hbm", kernel=dom_kind, kernel_family=FAMILY_TEXT.get(dom_kind, dom_kind),
@@ -397,7 +396,8 @@ def main():
                                      source=fam_src))
             roof["frac"] = round(min(achieved, ach_step) / peak, 4)
         if traffic is not None:
-            roof["traffic_source"] = PMC_SOURCE
+            roof["traffic_source"] = (f"{os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                      f"passes; commit {pmc_doc.get('meta', {}).get('commit', 'n/a')})")
         if step_roof and a.batch == 256:
             roof["step_roofline_us"] = step_roof
             roof["step_frac"] = round(step_roof / (ms_per_step * 1e3), 4)
@@ -434,6 +434,8 @@ def main():
                    roofline=roof)
         if pieces:
             out["piece_times"] = pieces
+        if world > 1:
+            out["per_rank_ms_per_step"] = [round(t / a.steps * 1e3, 4) for t in per_rank]
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_all(a, cfg)
         print(json.dumps(out), flush=True)

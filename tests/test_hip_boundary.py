@@ -512,3 +512,26 @@ def test_meter_records_the_rank_mean_loss_and_a_barrier_timeout_skips_the_update
     torch.cuda.synchronize()
     assert torch.equal(eng.pflat, before), "the update must be skipped"
     assert eng.hp[5].item() == 1 and eng.hp[6].item() == 1
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs (one rank per GPU over RCCL)")
+def test_rccl_two_gpus_ranks_agree_and_bench_runs(tmp_path):
+    """The first N > 1 run over the real backend (skipped on the 1-GPU test box): two ranks, one per GPU, nccl
+    (= RCCL): (a) tools/ddp_probe.py - after two optimizer steps both ranks hold identical parameters and the all-reduced gradients
+    equal the hand average of the two ranks' gradients, for the program / segments / eager step drivers; (b) `bench.py --gpus 2`
+    starts its two ranks and prints one line with n_gpus 2 and a per-rank time for each rank."""
+    import json
+    env = dict(os.environ, DDP_PROBE_BACKEND="nccl", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_probe.py"), str(tmp_path)], capture_output=True, text=True,
+                       env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for mode in ("program", "program+segments", "eager"):
+        m = re.search(mode.replace("+", r"\+") + r" ranks equal: (\w+)\s+max rel diff vs hand-averaged reference: ([0-9.e+-]+)", r.stdout)
+        assert m and m.group(1) == "True" and float(m.group(2)) < 2e-3, r.stdout
+        g = re.search(mode.replace("+", r"\+") + r" step-1 averaged gradient vs reference: max rel ([0-9.e+-]+)", r.stdout)
+        assert g and float(g.group(1)) < 1e-4, r.stdout
+    b = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
+    line = json.loads(b.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and len(line["per_rank_ms_per_step"]) == 2

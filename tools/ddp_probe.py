@@ -10,12 +10,15 @@ import torch.multiprocessing as mp
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def build(rank, N=8):
+BACKEND = os.environ.get("DDP_PROBE_BACKEND", "gloo")       # "nccl": one rank per GPU over RCCL (needs >= 2 visible GPUs)
+
+
+def build(rank, N=8, dev=None):
     from mmearth_train_amd.config import make_cfg
     from mmearth_train_amd.engine import Engine
     from mmearth_train_amd.synth import make_inputs, make_state_dict
     cfg = make_cfg()
-    eng = Engine(cfg, N, dtype="f32", device="cuda:0", block_mode="mat")
+    eng = Engine(cfg, N, dtype="f32", device=dev or "cuda:0", block_mode="mat")
     eng.load_state_dict(make_state_dict(cfg, seed=0))
     eng.set_inputs(*make_inputs(cfg, N, seed=100 + rank))
     return eng
@@ -26,10 +29,14 @@ UF = int(os.environ.get("DDP_PROBE_UPDATE_FREQ", "1"))      # > 1: gradient accu
 
 def worker(rank, world, mode, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = "29533"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    dev = f"cuda:{rank}" if BACKEND == "nccl" else "cuda:0"
+    torch.cuda.set_device(dev)
+    if BACKEND == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from mmearth_train_amd import dist as mdist
-    eng = build(rank)
+    eng = build(rank, dev=dev)
     drv, _, ov = mode.partition("+")              # "program" (bucket events), "program+segments" (one replay call per bucket), "eager"
     run = mdist.StepRunner(eng, world_size=world, lr=1e-3, mode=drv, update_freq=UF, overlap=ov or "events")
     assert drv != "program" or bool(run.bucket_signals) == (ov != "segments")
