@@ -1136,8 +1136,9 @@ static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   const int nt4 = g_opt[MPMAE_OPT_NT4];
   if (nt4 && (epi == EPI_STORE || epi == EPI_RESID) && a.K % NT4_BK == 0 && a.M >= 8192 && a.N >= 256 &&
       !(((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.R) & 15) &&
-      (nt4 >= 2 || (a.N % 256 == 0 && a.N >= 1024 && a.N <= 2048)))
+      (nt4 >= 2 || (a.N % 256 == 0 && a.N >= 1024 && a.N <= 2048))) {
     return a.N >= 1024 ? launch_nt4<256>(a, st) : launch_nt4<128>(a, st);
+  }
   const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
   int err = (w64 < w128) ? launch_gemm_fast_bn<64>(epi, a, st) : launch_gemm_fast_bn<128>(epi, a, st);
   if (err) return err;

@@ -31,6 +31,51 @@ template <int BN> struct Nt4Cfg {
   static constexpr int NI = (NT4_BM + BN) / 8, PER = NI / 8;          // DMA wave-instructions (8 rows each) per stage / per wave
 };
 
+template <int MI, int NJ>
+__device__ __forceinline__ void nt4_epilogue(const GemmP& p, const f32x16_t (&acc)[MI][NJ], int m0, int n0, int wm, int wn, int l32, int hb) {
+  // epilogue: lane = row m0 + wm * 32 MI + mi * 32 + l % 32, columns n0 + wn * 64 + nj * 32 + 16 (l / 32) + r, r = 0..15.
+  // Every optional operand (row mask, bias, residual) is REQUESTED first - clamped addresses, pointer selects, opaque masks - and
+  // consumed afterwards: a load under a per-lane branch is a serial round trip each (DESIGN.md, "a per-lane conditional load").
+  bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+  const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
+  const unsigned act_m = opaque_mask(p.act != nullptr) & 0xffu, r_m = opaque_mask(Rg != nullptr), b_m = opaque_mask(p.bias != nullptr);
+  int rowc[MI];
+  uint8_t lv[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    rowc[i] = min(m0 + wm * 32 * MI + i * 32 + l32, p.M - 1);
+    lv[i] = *(p.act ? p.act + rowc[i] : reinterpret_cast<const uint8_t*>(p.B));
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int col = n0 + wn * 64 + j * 32 + 16 * hb + 8 * h, colc = min(col, p.N - 8);
+      const float* bp = p.bias ? p.bias + colc : reinterpret_cast<const float*>(p.B);
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      uint4 rraw[MI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        rraw[i] = *reinterpret_cast<const uint4*>(Rg ? Rg + (size_t)rowc[i] * p.ldr + colc : reinterpret_cast<const bf16_t*>(p.B));
+      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = m0 + wm * 32 * MI + i * 32 + l32;
+        const bool live = ((lv[i] & act_m) | (~act_m & 1u)) != 0;
+        const uint4 rm = make_uint4(rraw[i].x & r_m, rraw[i].y & r_m, rraw[i].z & r_m, rraw[i].w & r_m);
+        float v[8], rr[8];
+        rr[0] = __uint_as_float(rm.x << 16); rr[1] = __uint_as_float(rm.x & 0xffff0000u);
+        rr[2] = __uint_as_float(rm.y << 16); rr[3] = __uint_as_float(rm.y & 0xffff0000u);
+        rr[4] = __uint_as_float(rm.z << 16); rr[5] = __uint_as_float(rm.z & 0xffff0000u);
+        rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][j][8 * h + e] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
+        if (row < p.M && col < p.N) st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+      }
+    }
+  }
+}
+
 template <int BN>
 __global__ __launch_bounds__(512) void gemm_nt4_kernel(const GemmP p, int tm, int tn) {
   using Cf = Nt4Cfg<BN>;
@@ -138,45 +183,12 @@ __global__ __launch_bounds__(512) void gemm_nt4_kernel(const GemmP p, int tm, in
   if (kt < nk) stage(std::integral_constant<int, 0>{}, false);
 #undef NT4_RD
 
-  // epilogue: lane = row m0 + wm * 32 MI + mi * 32 + l % 32, columns n0 + wn * 64 + nj * 32 + 16 (l / 32) + r, r = 0..15.
-  // Every optional operand (row mask, bias, residual) is REQUESTED first - clamped addresses, pointer selects, opaque masks - and
-  // consumed afterwards: a load under a per-lane branch is a serial round trip each (DESIGN.md, "a per-lane conditional load").
-  bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
-  const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
-  const unsigned act_m = opaque_mask(p.act != nullptr) & 0xffu, r_m = opaque_mask(Rg != nullptr), b_m = opaque_mask(p.bias != nullptr);
-  int rowc[MI];
-  uint8_t lv[MI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    rowc[i] = min(m0 + wm * 32 * MI + i * 32 + l32, p.M - 1);
-    lv[i] = *(p.act ? p.act + rowc[i] : reinterpret_cast<const uint8_t*>(p.B));
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int col = n0 + wn * 64 + j * 32 + 16 * hb + 8 * h, colc = min(col, p.N - 8);
-      const float* bp = p.bias ? p.bias + colc : reinterpret_cast<const float*>(p.B);
-      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-      uint4 rraw[MI];
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-        rraw[i] = *reinterpret_cast<const uint4*>(Rg ? Rg + (size_t)rowc[i] * p.ldr + colc : reinterpret_cast<const bf16_t*>(p.B));
-      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int row = m0 + wm * 32 * MI + i * 32 + l32;
-        const bool live = ((lv[i] & act_m) | (~act_m & 1u)) != 0;
-        const uint4 rm = make_uint4(rraw[i].x & r_m, rraw[i].y & r_m, rraw[i].z & r_m, rraw[i].w & r_m);
-        float v[8], rr[8];
-        rr[0] = __uint_as_float(rm.x << 16); rr[1] = __uint_as_float(rm.x & 0xffff0000u);
-        rr[2] = __uint_as_float(rm.y << 16); rr[3] = __uint_as_float(rm.y & 0xffff0000u);
-        rr[4] = __uint_as_float(rm.z << 16); rr[5] = __uint_as_float(rm.z & 0xffff0000u);
-        rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][j][8 * h + e] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
-        if (row < p.M && col < p.N) st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
-      }
-    }
-  }
+  nt4_epilogue<MI, NJ>(p, acc, m0, n0, wm, wn, l32, hb);
 }
+
+// A third variant was measured and removed (round 4, profiles/r04/gemm_and_wgrad_group_probes.txt, "NT4=3"): 256 x 128 tile, 4 waves, two
+// workgroups per CU, 32-deep K steps through a ring of three 24 KB stages with counted vmcnt (so that one workgroup's prologue / epilogue
+// runs under the other's main loop): 54.1 us at N = 2048, K = 512 (this kernel 53.5, the 128 x 128 kernels 58.0), 45.7 vs 40.8 vs 41.1 at
+// N = 512, K = 2048. Three tilings landing on the same time says the bound is none of tile shape, pipeline depth or occupancy: every variant
+// fills LDS at ~10-12 bytes per cycle and CU (205-411 MB of operand slabs per GEMM in ~40 us of main loop), the rate the microarchitecture
+// guide quotes for global_load(_lds)_dwordx4 streams, i.e. 64-128 flop per byte x ~12 B/cycle = 20-38 % of the MFMA peak.
