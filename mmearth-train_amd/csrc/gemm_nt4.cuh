@@ -70,7 +70,18 @@ __device__ __forceinline__ void nt4_epilogue(const GemmP& p, const f32x16_t (&ac
         rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][j][8 * h + e] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
-        if (row < p.M && col < p.N) st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+        if (row < p.M && col < p.N) {
+#ifdef NT4_SC1_STORES
+          // write-through store that does not keep the line in this XCD's L2 (MI355X_MICROARCH.md, "stores of each flavour"): the output
+          // streams out once and is next read by another kernel; kept lines would evict the operand slabs the tiles of this XCD share
+          typedef __attribute__((ext_vector_type(4))) unsigned u32x4s_t;
+          const u32x4s_t pk = {f2bf2(v[0], v[1]), f2bf2(v[2], v[3]), f2bf2(v[4], v[5]), f2bf2(v[6], v[7])};
+          bf16_t* dst = Cg + (size_t)row * p.ldc + col;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(pk) : "memory");
+#else
+          st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+#endif
+        }
       }
     }
   }
