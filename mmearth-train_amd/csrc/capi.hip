@@ -266,10 +266,25 @@ static int launch_tng(const TngP& g, int blocks, hipStream_t st) {
   return 0;
 }
 
+template <int RX, int RY, int NST>
+static int launch_tng48(const TngP& g, int blocks, hipStream_t st) {
+  using Cf = Tng48Cfg<RX, RY, NST>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_tng48_kernel<RX, RY, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
+      return (int)hipGetLastError();
+    attr = true;
+  }
+  LAUNCH((gemm_tng48_kernel<RX, RY, NST>), dim3(blocks), dim3(256), Cf::LDS, st, g);
+  return 0;
+}
+
 static bool tng_ok(int dt, const WgradP* pr, int count, int* WX_, int* WY_) {
   if (dt != 1 || count < 1 || count > TNG_MAXP || g_opt[MPMAE_OPT_TNG_BLOCKS] <= 0) return false;
   const int WX = pr[0].Nn < pr[0].Kk ? pr[0].Nn : pr[0].Kk, WY = pr[0].Nn < pr[0].Kk ? pr[0].Kk : pr[0].Nn;
-  if (!((WX == 80 && WY % 320 == 0) || (WX % 160 == 0 && WY % 160 == 0))) return false;
+  // 80-column regions (atto / nano widths) or 48-column regions (tiny / large widths, femto from stage 1)
+  if (!((WX == 80 && WY % 320 == 0) || (WX % 160 == 0 && WY % 160 == 0) || (WX == 96 && WY % 384 == 0) || (WX % 192 == 0 && WY % 192 == 0)))
+    return false;
   if (((size_t)WX * WY + WY) % 4 || ((size_t)WX * WY + WX) % 4) return false;
   for (int i = 0; i < count; ++i) {
     const WgradP& a = pr[i];
@@ -301,8 +316,10 @@ int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws,
     return 0;
   }
   const int M = probs[0].M;
-  const bool narrow = WX == 80;                         // (1, 4) regions: 80 x 320 tile; else (2, 2): 160 x 160
-  const int xt = narrow ? 1 : WX / 160, yt = narrow ? WY / 320 : WY / 160;
+  const bool r48 = WX % 80 != 0;                        // 48-column regions, a wave owns 2 x 2 of them (gemm_tng48_kernel)
+  const bool narrow = WX == 80 || WX == 96;             // (1, 4) waves: 80 x 320 / 96 x 384 tile; else (2, 2): 160 x 160 / 192 x 192
+  const int tx = r48 ? (narrow ? 96 : 192) : (narrow ? 80 : 160), ty = r48 ? (narrow ? 384 : 192) : (narrow ? 320 : 160);
+  const int xt = WX / tx, yt = WY / ty;
   const size_t per_max = (size_t)WX * WY + WY;          // slab stride: the larger of the two bias lengths
   int splits = g_opt[MPMAE_OPT_TNG_BLOCKS] / (count * xt * yt);
   const int maxs = M / (8 * TNG_SL);                    // >= 8 k-steps per split
@@ -333,7 +350,8 @@ int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws,
   }
   const int blocks = count * xt * yt * splits;
   int err;
-  if (narrow) err = launch_tng<1, 4, 3>(g, blocks, S_(s));
+  if (r48) err = narrow ? launch_tng48<1, 4, 3>(g, blocks, S_(s)) : launch_tng48<2, 2, 3>(g, blocks, S_(s));
+  else if (narrow) err = launch_tng<1, 4, 3>(g, blocks, S_(s));
   else err = launch_tng<2, 2, 3>(g, blocks, S_(s));
   if (err) return err;
   int fb = cdiv((long long)(maxper / 4), 256);

@@ -214,6 +214,175 @@ __global__ __launch_bounds__(256, 2) void gemm_tng_kernel(const TngP g) {
   else tng_body<RX, RY, NST, false>(g, pr, tile, split, tng_smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same kernel for the widths that are multiples of 96 (tiny / large: 96 .. 768, femto from stage 1): 48-COLUMN regions (a region row
+// is 96 bytes = THREE 32-byte bank groups, odd again), a wave owns 2 x 2 regions = a 96 x 96 output block (6 x 6 MFMA tiles, 36 MFMAs per
+// k-step, 144 accumulator VGPRs); workgroup = (2, 2) waves = 192 x 192 at C >= 192, (1, 4) waves = 96 x 384 at C = 96.
+// ---------------------------------------------------------------------------------------------------------------------------------
+constexpr int TNG48_RW = 48, TNG48_RB = TNG_SL * TNG48_RW * 2;      // 3072 bytes per region stage = 3 DMA wave-instructions
+template <int RX, int RY, int NST>
+struct Tng48Cfg {
+  static constexpr int NREG = 2 * (RX + RY), NI = NREG * 3, PER = (NI + 3) / 4;
+  static constexpr int STAGE_B = NREG * TNG48_RB, DUMMY_B = (4 * PER - NI) * 1024, LDS = NST * STAGE_B + DUMMY_B;
+};
+
+template <int RX, int RY, int NST, bool SWAP>
+__device__ __forceinline__ void tng48_body(const TngP& g, const TngProb& pr, int tile, int split, unsigned char* smem) {
+  using Cf = Tng48Cfg<RX, RY, NST>;
+  constexpr int PER = Cf::PER, STAGE_B = Cf::STAGE_B, RW = TNG48_RW, RB = TNG48_RB, NT = 6;      // 6 MFMA tiles per wave and side
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lg = lane >> 4;
+  const int wx = wave % RX, wy = wave / RX;
+  const int xtile = tile % g.xt, ytile = tile / g.xt;
+  const int x0 = xtile * (2 * RX * RW), y0 = ytile * (2 * RY * RW);
+  const int mbeg = split * g.rps, mend = min(g.M, mbeg + g.rps);
+  const int nsl = (mend - mbeg + TNG_SL - 1) / TNG_SL;
+
+  f32x4_t acc[NT][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t accb[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) accb[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const bool do_db = pr.want_db && (SWAP ? (xtile == 0 && wx == 0) : (ytile == 0 && wy == 0));
+  typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+
+  // DMA plan: instruction I = wave + 4 k moves chunks (I % 3) * 64 + lane of region q = I / 3 (a region stage is 32 rows x 6 chunks)
+  const bf16_t* dsrc[PER];
+  int drow[PER], dld[PER];
+  unsigned ddst[PER];
+  bool dreal[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int I = wave + 4 * k;
+    const bool real = I < Cf::NI;
+    const int q = real ? I / 3 : 0, ii = real ? I % 3 : 0;
+    const int chunk = ii * 64 + lane, row = chunk / 6, cc = chunk - row * 6;
+    const bool isx = q < 2 * RX;
+    dsrc[k] = (isx ? pr.X + x0 + q * RW : pr.Y + y0 + (q - 2 * RX) * RW) + cc * 8;
+    dld[k] = isx ? pr.ldx : pr.ldy;
+    drow[k] = row;
+    dreal[k] = real;
+    ddst[k] = real ? (unsigned)(q * RB + ii * 1024) : (unsigned)(NST * STAGE_B + (I - Cf::NI) * 1024);
+  }
+  auto dma = [&](int s) {
+    const int mb = mbeg + s * TNG_SL;
+    const unsigned so = (unsigned)(s % NST) * STAGE_B;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int r = min(mb + drow[k], g.M - 1);
+      const bf16_t* src = dsrc[k] + (size_t)r * dld[k];
+      unsigned char* dst = smem + (dreal[k] ? so : 0u) + ddst[k];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    }
+  };
+
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  const int rl = lg * 4 + (lr >> 2);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned xlane = lds0 + (2 * wx) * RB + rl * (RW * 2) + (lr & 3) * 8;
+  const unsigned ylane = lds0 + (2 * RX + 2 * wy) * RB + rl * (RW * 2) + (lr & 3) * 8;
+#define TNG_TR(dst, addr, imm) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+  auto mk = [](const u32x2_t& lo, const u32x2_t& hi) { return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y)); };
+
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nsl) dma(s);
+
+  for (int s = 0; s < nsl; ++s) {
+    static_assert(NST == 3, "ring depth");
+    if (s + 1 < nsl) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const unsigned so = (unsigned)(s % NST) * STAGE_B;
+    const int valid = mend - (mbeg + s * TNG_SL);
+    if (valid < TNG_SL) {
+      const int nz = (TNG_SL - valid) * (RW * 2 / 16);
+      for (int q = 0; q < Cf::NREG; ++q)
+        for (int c = tid; c < nz; c += 256)
+          *reinterpret_cast<uint4*>(smem + so + q * RB + valid * (RW * 2) + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
+    if (s + NST - 1 < nsl) dma(s + NST - 1);
+    // tile i of a side: region i / 3 (+ RB), MFMA tile i % 3 of it (+ 32 bytes); second half of the k-step: + 16 rows
+    u32x2_t xl[NT], xh[NT], yl[NT], yh[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { TNG_TR(xl[i], xlane + so, (i / 3) * RB + (i % 3) * 32); TNG_TR(xh[i], xlane + so, (i / 3) * RB + (i % 3) * 32 + 16 * RW * 2); }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { TNG_TR(yl[j], ylane + so, (j / 3) * RB + (j % 3) * 32); TNG_TR(yh[j], ylane + so, (j / 3) * RB + (j % 3) * 32 + 16 * RW * 2); }
+    asm volatile("s_waitcnt lgkmcnt(10)"
+                 : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[3]), "+v"(xl[4]), "+v"(xl[5]), "+v"(xh[0]), "+v"(xh[1]), "+v"(xh[2]), "+v"(xh[3]),
+                   "+v"(xh[4]), "+v"(xh[5]), "+v"(yl[0]), "+v"(yh[0]));
+    bf16x8_t xf[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) xf[i] = mk(xl[i], xh[i]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j == 1) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(yl[1]), "+v"(yh[1]));
+      if (j == 2) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(yl[2]), "+v"(yh[2]));
+      if (j == 3) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(yl[3]), "+v"(yh[3]));
+      if (j == 4) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(yl[4]), "+v"(yh[4]));
+      if (j == 5) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(yl[5]), "+v"(yh[5]));
+      const bf16x8_t yf = mk(yl[j], yh[j]);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, xf[i], acc[i][j], 0, 0, 0)
+                         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf, acc[i][j], 0, 0, 0);
+      if (SWAP && do_db) accb[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(yf, ones, accb[j], 0, 0, 0);
+    }
+    if (!SWAP && do_db) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, accb[i], 0, 0, 0);
+    }
+  }
+#undef TNG_TR
+
+  const int Nn = SWAP ? g.WY : g.WX, Kk = SWAP ? g.WX : g.WY;
+  float* slab = pr.slab + (size_t)split * ((size_t)Nn * Kk + Nn);
+  const int xb = x0 + wx * 2 * RW, yb = y0 + wy * 2 * RW;      // tile i covers columns xb + 16 i .. (the two regions of a wave are adjacent)
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = SWAP ? yb + j * 16 + lg * 4 + r : xb + i * 16 + lg * 4 + r;
+        const int k = SWAP ? xb + i * 16 + lr : yb + j * 16 + lr;
+        slab[(size_t)n * Kk + k] = acc[i][j][r];
+      }
+  if (do_db && lr == 0) {
+    float* dslab = slab + (size_t)Nn * Kk;
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dslab[(SWAP ? yb : xb) + i * 16 + lg * 4 + r] = accb[i][r];
+  }
+}
+
+template <int RX, int RY, int NST>
+__global__ __launch_bounds__(256) void gemm_tng48_kernel(const TngP g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tng_smem[];
+  const int b = blockIdx.x;
+  const int split = b % g.splits, t = b / g.splits;
+  const int ntiles = g.xt * g.yt;
+  const int tile = t % ntiles, prob = t / ntiles;
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const char* kchar_p;
+  typedef __attribute__((address_space(4))) const TngProb* kprob_p;
+  const TngProb pr = ((kprob_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TngP, p)))[prob];
+#else
+  const TngProb pr = g.p[prob];
+#endif
+  if (pr.swap) tng48_body<RX, RY, NST, true>(g, pr, tile, split, tng_smem);
+  else tng48_body<RX, RY, NST, false>(g, pr, tile, split, tng_smem);
+}
+
 // Fold of a group: dW_p[n sn + k sk] += sum_s slab_p[s][n Kk + k], db_p[n] += sum_s slab_p[s][Nn Kk + n]; fixed summation order.
 struct TngFoldProb { const float* slab; float* dW; float* db; int nk, per, Kk, sn, sk, pad; };
 struct TngFoldP { int nprob, splits; TngFoldProb p[TNG_MAXP]; };

@@ -526,7 +526,7 @@ class Engine:
     # stage's data-gradient chain is built and issued as ONE side-lane op behind it (their operands persist: one ring slot per block)
     def _group_ok(self, blk, qpro):
         return (self.lanes and bool(self.opt["wgrad_group"]) and self.dt == BF16 and blk["sparse"] and qpro == "NONE"
-                and blk["C"] in (80, 160, 320) and blk["H"] == 4 * blk["C"])
+                and (blk["C"] % 80 == 0 or blk["C"] % 96 == 0) and blk["H"] == 4 * blk["C"])
 
     def _group_add(self, lst, name, reads, **kw):
         if not hasattr(self, "_group_pending"):
@@ -1595,7 +1595,8 @@ class Engine:
                 if dn["grouped"]:
                     wx, wy = min(Co, 4 * Ci), max(Co, 4 * Ci)
                     if (self.lanes and bool(self.opt["wgrad_group"]) and dt == BF16
-                            and ((wx == 80 and wy % 320 == 0) or (wx % 160 == 0 and wy % 160 == 0))):
+                            and ((wx == 80 and wy % 320 == 0) or (wx % 160 == 0 and wy % 160 == 0)
+                                 or (wx == 96 and wy % 384 == 0) or (wx % 192 == 0 and wy % 192 == 0))):
                         # a group of one: the DMA-ring kernel with few row splits instead of the transpose-read kernel's 76 slabs
                         self._group_add(b, pre + ":wgrad", [cur], P=cur, Q=dn["yg"], M=self.M[i], Nn=Co, Kk=4 * Ci,
                                         ldp=Co, ldq=4 * Ci, dW=Gd[pre + ".1.kernel"], sn=1, sk=Co, db=Gd[pre + ".1.bias"])

@@ -369,13 +369,15 @@ def test_weight_gradient_kernel_matches_fp32_matmul(M, N, K):
 
 
 @pytest.mark.parametrize("M,C_,count", [(19456, 160, 12), (4864, 320, 4), (9728, 80, 4), (152, 160, 12), (38, 320, 3), (1203, 80, 2),
-                                        (777, 160, 20), (640, 96, 4), (4864, 160, 1)])
+                                        (777, 160, 20), (4864, 160, 1), (640, 64, 4),
+                                        # 48-column regions (tiny / large widths): both wave grids, ragged rows
+                                        (9728, 96, 6), (4864, 192, 6), (1203, 384, 4), (304, 768, 2), (77, 96, 3)])
 def test_grouped_weight_gradients_match_fp32_matmul(M, C_, count):
     """mpmae_wgrad_group (gemm_tng.cuh: all pwconv1 / pwconv2 weight gradients of a stage in one DMA-ring launch + one fold): problems
     alternate between the two operand orders (pwconv2: [C] x [4C], pwconv1: [4C] x [C]); dW += P^T Q and db += column sums of P against
     torch fp32 on the same bf16 values, on top of a non-zero gradient buffer (the entry point accumulates). Covers the stage shapes at
     bs 256 / 64, ragged row counts (not a multiple of the 32-row k-step, fewer rows than one k-step per split), the problem-count limit
-    and a width the grouped kernel does not take (96: one mpmae_wgrad per problem, same results)."""
+    and a width the grouped kernel does not take (64: one mpmae_wgrad per problem, same results); widths that are multiples of 96 run on the 48-column-region variant."""
     import ctypes as C
     from mmearth_train_amd import _lib
     lib = _lib.load()
