@@ -135,9 +135,15 @@ __global__ __launch_bounds__(512) void dwconv7_band_kernel(const DwP p) {
       f32x2_t w7[7];
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * C + 2 * cp);
+      // the whole input column of this kx FIRST (S + 6 independent LDS reads in flight), then the multiply-adds: written as one loop
+      // hipcc reuses ONE destination register for the reads and parks an s_waitcnt lgkmcnt(0) behind every one of them - the column
+      // became S + 6 serial LDS round trips per kx (round 4, found in the ISA; the same shape in every depthwise kernel)
+      uint32_t raw[S + 6];
+#pragma unroll
+      for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + (size_t)(y * MW + kx) * C);
 #pragma unroll
       for (int y = 0; y < S + 6; ++y) {
-        const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + (size_t)(y * MW + kx) * C));
+        const f32x2_t v = bf2x2_to_f2(raw[y]);
 #pragma unroll
         for (int o = 0; o < S; ++o) {
           const int ky = y - o;

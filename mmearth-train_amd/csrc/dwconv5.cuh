@@ -106,9 +106,12 @@ __global__ __launch_bounds__(512) void dwconv7_v5_kernel(const DwP p) {
       float w7[7];
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) w7[ky] = wl[(ky * 7 + kx) * CW + cw];
+      float col[S + 6];      // the whole input column first: independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+      for (int y = 0; y < S + 6; ++y) col[y] = ldf<T>(tile + (y * MS + ox + kx) * CW + cw);
 #pragma unroll
       for (int y = 0; y < S + 6; ++y) {
-        const float v = ldf<T>(tile + (y * MS + ox + kx) * CW + cw);
+        const float v = col[y];
 #pragma unroll
         for (int o = 0; o < S; ++o) {
           const int ky = y - o;
@@ -175,9 +178,12 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q, co
         if (kx > 0)
           asm volatile("" : "+v"(toff) : "v"(adw[kx - 1]), "v"(adw[7 + kx - 1]), "v"(adw[14 + kx - 1]),
                        "v"(adw[21 + kx - 1]), "v"(adw[28 + kx - 1]), "v"(adw[35 + kx - 1]), "v"(adw[42 + kx - 1]) : "memory");
+        float col[S + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+        for (int y = 0; y < S + 6; ++y) col[y] = ldf<T>(tile + toff + (y * MS + ox + kx) * CW + cw);
 #pragma unroll
         for (int y = 0; y < S + 6; ++y) {
-          const float v = ldf<T>(tile + toff + (y * MS + ox + kx) * CW + cw);
+          const float v = col[y];
 #pragma unroll
           for (int o = 0; o < S; ++o) {
             const int ky = y - o;

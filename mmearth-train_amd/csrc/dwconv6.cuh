@@ -121,9 +121,12 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
       f32x2_t w7[7];
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
+      uint32_t raw[S + 6];      // the whole input column first: S + 6 independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+      for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW);
 #pragma unroll
       for (int y = 0; y < S + 6; ++y) {
-        const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW));
+        const f32x2_t v = bf2x2_to_f2(raw[y]);
 #pragma unroll
         for (int o = 0; o < S; ++o) {
           const int ky = y - o;
@@ -186,9 +189,12 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v6_kernel(const DwWgP q) {
         if (kx > 0)
           asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
                        "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
+        uint32_t raw[S + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+        for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW);
 #pragma unroll
         for (int y = 0; y < S + 6; ++y) {
-          const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW));
+          const f32x2_t v = bf2x2_to_f2(raw[y]);
 #pragma unroll
           for (int o = 0; o < S; ++o) {
             const int ky = y - o;
@@ -307,9 +313,12 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
     f32x2_t w7[7];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
+    uint32_t raw[G + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+    for (int y = 0; y < G + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW);
 #pragma unroll
     for (int y = 0; y < G + 6; ++y) {
-      const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW));
+      const f32x2_t v = bf2x2_to_f2(raw[y]);
 #pragma unroll
       for (int o = 0; o < G; ++o) {
         const int ky = y - o;
@@ -394,9 +403,12 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q, 
       if (kx > 0)
         asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
                      "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
+      uint32_t raw[G + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+#pragma unroll
+      for (int y = 0; y < G + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW);
 #pragma unroll
       for (int y = 0; y < G + 6; ++y) {
-        const f32x2_t v = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW));
+        const f32x2_t v = bf2x2_to_f2(raw[y]);
 #pragma unroll
         for (int o = 0; o < G; ++o) {
           const int ky = y - o;
