@@ -434,6 +434,17 @@ int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const fl
                     int H, int rpg, const uint8_t* act, mpmae_stream_t stream);
 int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, const float* coef,
                         int M, int H, int rpg, mpmae_stream_t stream);
+/* the same GRN for the DENSE decoder block (one statistics group per sample, norm_layers.py:25-48) as one launch per
+ * direction: statistics + finalisation + application with the group's rows held in registers in between. bf16, H == 2048,
+ * rpg <= 52, M % rpg == 0 (mpmae_grn_group_ok says whether a shape qualifies; other shapes use the three calls above).
+ * forward writes z, Gx[G][H], Ainv[G], scale[G][H]; backward writes dh over dz and the per-group gamma / beta gradient
+ * rows to slab[G][2H] (summed into the gradients by mpmae_fold_group{slab, G, 2H, dgamma, H, dbeta - dgamma, 1}). */
+int mpmae_grn_group_ok(int dt, int M, int H, int rpg);
+int mpmae_grn_group_fwd(int dt, const void* h, void* z, const float* gamma, const float* beta, float eps,
+                        int M, int H, int rpg, float* Gx, float* Ainv, float* scale, mpmae_stream_t stream);
+int mpmae_grn_group_bwd(int dt, void* dz, const void* h, const float* scale, const float* Gx,
+                        const float* Ainv, const float* gamma, int M, int H, int rpg, float* slab,
+                        mpmae_stream_t stream);
 int mpmae_colstats(int dt, const void* h, const void* dz, int mode, float* s0, float* s1, int M,
                    int H, int rpg, float* ws, size_t ws_floats, mpmae_stream_t stream);
 /* MinkowskiDepthwiseConvolution 7x7 (convnextv2_sparse.py:37-39) / dense depthwise 7x7 pad 3

@@ -198,6 +198,11 @@ SYMBOLS = {
                                c_void_p, c_void_p, c_void_p],
     "mpmae_grn_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],
     "mpmae_grn_bwd_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "mpmae_grn_group_ok": [c_int, c_int, c_int, c_int],
+    "mpmae_grn_group_fwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
+    "mpmae_grn_group_bwd": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                            c_void_p],
     "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                        c_void_p],
     "mpmae_rs": [c_int, P(RsArgs), c_void_p],

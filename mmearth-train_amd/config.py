@@ -60,6 +60,10 @@ class ModelCfg:
     norm_pix_loss: bool = True
     loss_aggr: str = "uncertainty"
     out_mods: List[OutMod] = field(default_factory=list)
+    # False: the dense ConvNeXtV2 encoder (fcmae.py:103-111, models/convnextv2.py:58-199) - every patch is computed, masked pixels are
+    # zeroed at the input only; state dict in nn.Conv2d / nn.Linear layouts. Its stem (valid 3x3 convolution, depthwise k = stride =
+    # patch / 8 with padding k // 2) only lines up with the decoder's patch grid when patch_size == 16 (convnextv2.py:108-124).
+    sparse: bool = True
 
     # ---- derived sizes ----------------------------------------------------
     @property
@@ -106,7 +110,7 @@ def kind_of(name: str) -> str:
 def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=None,
              inp_modalities=None, modalities_full=None, norm_pix_loss=True,
              loss_aggr="uncertainty", mask_ratio=0.6, decoder_embed_dim=512,
-             decoder_depth=1) -> ModelCfg:
+             decoder_depth=1, sparse=True) -> ModelCfg:
     depths, dims = SIZES[model]
     out_modalities = OrderedDict(M.OUT_MODALITIES if out_modalities is None else out_modalities)
     inp_modalities = OrderedDict(M.INP_MODALITIES if inp_modalities is None else inp_modalities)
@@ -115,6 +119,11 @@ def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=
     mods.update(out_modalities)
     assert patch_size % 8 == 0 and img_size % patch_size == 0
     assert decoder_depth >= 1
+    if not sparse and patch_size != 16:
+        # (110 + 2 (k // 2) - k) // k + 1 == img / 8 only for k = 2: at patch 8 the reference's dense encoder returns a 6 x 6 map for
+        # a 7 x 7 mask and fails in forward_decoder (fcmae.py:253); its own test runs the dense mode at 112 / 16 (tests/pretrain_test.py:17)
+        raise ValueError("sparse=False needs patch_size == 16 (the dense stem of models/convnextv2.py:108-124 yields img/8 points "
+                         "per side only for the 2x2 stride-2 depthwise stem)")
     in_chans = out_channels("sentinel2", mods, modalities_full)
     oms = []
     for name in out_modalities:
@@ -126,11 +135,11 @@ def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=
     return ModelCfg(name=model, depths=list(depths), dims=list(dims), img_size=img_size,
                     patch_size=patch_size, in_chans=in_chans, decoder_embed_dim=decoder_embed_dim,
                     decoder_depth=decoder_depth, mask_ratio=mask_ratio, norm_pix_loss=norm_pix_loss,
-                    loss_aggr=loss_aggr, out_mods=oms)
+                    loss_aggr=loss_aggr, out_mods=oms, sparse=bool(sparse))
 
 
 def cfg_from_args(model, img_size, patch_size, args: Namespace, norm_pix_loss, mask_ratio,
-                  decoder_embed_dim=512, decoder_depth=1) -> ModelCfg:
+                  decoder_embed_dim=512, decoder_depth=1, sparse=True) -> ModelCfg:
     """Build a ModelCfg from the reference-style `args` namespace (needs .modalities,
     .out_modalities, .modalities_full, .loss_aggr; /root/reference/models/fcmae.py:65-91,102,126,406)."""
     inp = OrderedDict((k, v) for k, v in args.modalities.items() if k not in args.out_modalities
@@ -139,7 +148,7 @@ def cfg_from_args(model, img_size, patch_size, args: Namespace, norm_pix_loss, m
     return make_cfg(model, img_size, patch_size, out_modalities=args.out_modalities,
                     inp_modalities=inp, modalities_full=args.modalities_full,
                     norm_pix_loss=norm_pix_loss, loss_aggr=args.loss_aggr, mask_ratio=mask_ratio,
-                    decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth)
+                    decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth, sparse=sparse)
 
 
 def default_args(out_modalities=None, loss_aggr="uncertainty", use_orig_stem=False) -> Namespace:

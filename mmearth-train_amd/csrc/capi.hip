@@ -20,6 +20,7 @@
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
 #include "gemm_nt4.cuh"
+#include "grn_group.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st);
@@ -1302,6 +1303,46 @@ static int launch_wgrad_fast(WgradP a, hipStream_t st, bool qgrn) {
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
   return launch_status();
+}
+
+// Dense-decoder GRN, one kernel per direction (grn_group.cuh): bf16, H == 2048, rpg <= 52 rows per group, M == G * rpg.
+int mpmae_grn_group_ok(int dt, int M, int H, int rpg) {
+  return dt == 1 && H == GrnGroupCfg<13>::H && rpg >= 1 && rpg <= GrnGroupCfg<13>::MAXROWS && M > 0 && M % rpg == 0;
+}
+
+template <int MAXR>
+static int launch_grn_group(bool bwd, const void* a0, void* a1, const float* p0, const float* p1, const float* p2, const float* p3,
+                            float eps, int G, int rpg, float* o0, float* o1, float* o2, hipStream_t st) {
+  using Cf = GrnGroupCfg<MAXR>;
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute((const void*)grn_group_fwd_kernel<MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_F) != hipSuccess ||
+        hipFuncSetAttribute((const void*)grn_group_bwd_kernel<MAXR>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_B) != hipSuccess)
+      return (int)hipGetLastError();
+    once = true;
+  }
+  if (!bwd) LAUNCH(grn_group_fwd_kernel<MAXR>, dim3(G), dim3(1024), Cf::LDS_F, st, (const bf16_t*)a0, (bf16_t*)a1, p0, p1, eps, rpg, o0, o1, o2);
+  else LAUNCH(grn_group_bwd_kernel<MAXR>, dim3(G), dim3(1024), Cf::LDS_B, st, (bf16_t*)a1, (const bf16_t*)a0, p0, p1, p2, p3, rpg, o0);
+  return 0;
+}
+
+int mpmae_grn_group_fwd(int dt, const void* h, void* z, const float* gamma, const float* beta, float eps, int M, int H,
+                        int rpg, float* Gx, float* Ainv, float* scale, mpmae_stream_t s) {
+  if (!mpmae_grn_group_ok(dt, M, H, rpg) || !h || !z || !gamma || !beta || !Gx || !Ainv || !scale) return (int)hipErrorInvalidValue;
+  const int e = rpg <= 28 ? launch_grn_group<7>(false, h, z, gamma, beta, nullptr, nullptr, eps, M / rpg, rpg, Gx, Ainv, scale, S_(s))
+                          : launch_grn_group<13>(false, h, z, gamma, beta, nullptr, nullptr, eps, M / rpg, rpg, Gx, Ainv, scale, S_(s));
+  if (e) return e;
+  RET();
+}
+
+// dh over dz; slab[G][2H] receives the per-group gamma / beta gradient rows (fold: mpmae_fold_group{slab, G, 2H, dgamma, H, dbeta - dgamma, 1})
+int mpmae_grn_group_bwd(int dt, void* dz, const void* h, const float* scale, const float* Gx, const float* Ainv,
+                        const float* gamma, int M, int H, int rpg, float* slab, mpmae_stream_t s) {
+  if (!mpmae_grn_group_ok(dt, M, H, rpg) || !dz || !h || !scale || !Gx || !Ainv || !gamma || !slab) return (int)hipErrorInvalidValue;
+  const int e = rpg <= 28 ? launch_grn_group<7>(true, h, dz, scale, Gx, Ainv, gamma, 0.f, M / rpg, rpg, slab, nullptr, nullptr, S_(s))
+                          : launch_grn_group<13>(true, h, dz, scale, Gx, Ainv, gamma, 0.f, M / rpg, rpg, slab, nullptr, nullptr, S_(s));
+  if (e) return e;
+  RET();
 }
 
 int mpmae_grn_apply(int dt, const void* h, void* z, const float* scale, const float* beta, int M, int H, int rpg,

@@ -69,6 +69,7 @@ ENGINE_OPTIONS = dict(
     dzr_maxc=80,            # largest C recomputing dz
     dw_group=1,             # ... and ONE launch for its depthwise weight gradients (mpmae_dwconv7_wgrad_group), from this stage index on (stage 0 stays per block: its weight gradients are the tail of the backward; 9 = never)
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
+    grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
 )
 
@@ -904,7 +905,15 @@ class Engine:
                      rpg, kind="colstats", nbytes=M * H * esz)
         fold = blk["grn_fold"] = (rs_n == "fused" and G == 1 and self.grn_fold
                                   and Cc >= int(self.opt["grn_fold_minc"]))
-        if not fold:
+        gg = blk["grn_group"] = (not rs and not blk["sparse"] and not self.grouped_epi and bool(self.opt["grn_group"])
+                                 and bool(lib.mpmae_grn_group_ok(dt, M, H, rpg)))
+        if gg:      # the three GRN launches (statistics just appended, finalisation, application) as one
+            assert lst[-1][0] == tag + ":grn.stats"
+            lst.pop()
+            self._op(lst, tag + ":grn.group", lib.mpmae_grn_group_fwd, dt, _p(blk["h"]), _p(blk["z"]), _p(P[nm["gg"]]),
+                     _p(P[nm["gb"]]), eps, M, H, rpg, _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]),
+                     kind="grn_group_fwd", nbytes=2 * M * H * esz)
+        elif not fold:
             self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                      _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
         # z_free: z is never written - pw2's weight gradient (mpmae_wgrad with the GRN prologue on Q = h) rebuilds it slab by slab
@@ -921,8 +930,9 @@ class Engine:
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
                      v1=P[nm["gb"]], out=blk["out"], xn=None if blk["z_free"] else blk["z"], R=x, act=act, rpg=0, **fin, **hkw)
             return blk["out"]
-        self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
-                 _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
+        if not gg:
+            self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
+                     _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
         if rs_n == "plain":
             self._rs(lst, tag + ":pw2", 2, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["z"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], out=blk["out"], R=x,
@@ -982,15 +992,30 @@ class Engine:
             self._group_add(lst, tag + ":pw2.wgrad", [dout], **w2_args)
         elif not late_w2 and not late_all:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
-        if not blk["sparse"] and not self.grouped_epi:
+        gg = blk.get("grn_group", False)
+        if gg:
+            # statistics + finalisation + dh over dz in one launch; the samples' gamma / beta gradient rows are folded on the side lane
+            # by the decoder's fold op (a static record: slab[G][2H] -> dgamma[H], dbeta[H])
+            if "grn_slab" not in blk:
+                blk["grn_slab"] = torch.empty(G * 2 * H, dtype=torch.float32, device=self.device)
+            self._op(lst, tag + ":grn.bgroup", lib.mpmae_grn_group_bwd, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]), _p(blk["Gx"]),
+                     _p(blk["Ainv"]), _p(P[nm["gg"]]), M, H, rpg, _p(blk["grn_slab"]), kind="grn_group_bwd", nbytes=3 * M * H * esz)
+            delta = (Gd[nm["gb"]].data_ptr() - Gd[nm["gg"]].data_ptr()) // 4
+            assert abs(delta) < 2 ** 31
+            fd = _lib.FoldDesc(blk["grn_slab"].data_ptr(), G, 2 * H, Gd[nm["gg"]].data_ptr(), H, delta, 1)
+            self._keepalive.append(fd)
+            if not hasattr(self, "_fold_pending"):
+                self._fold_pending = []
+            self._fold_pending.append(fd)
+        elif not blk["sparse"] and not self.grouped_epi:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         fold = blk.get("grn_fold", False)
-        if not fold:
+        if not fold and not gg:
             self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                      _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
         rsc = rs_n == "fused"
-        if not rsc:
+        if not rsc and not gg:
             self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
                      _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
         if rsc:  # dh (written over dz) in the operand prologue, pwconv1 data gradient, LayerNorm backward

@@ -22,33 +22,68 @@ def state_dict_spec(cfg: ModelCfg):
     C = cfg.dims
     k = cfg.stem_k
     add = spec.append
-    add(("encoder.initial_conv.0.kernel", (9, cfg.in_chans, C[0]), "w"))
-    add(("encoder.initial_conv.0.bias", (1, C[0]), "b"))
-    add(("encoder.initial_conv.1.ln.weight", (C[0],), "g"))
-    add(("encoder.initial_conv.1.ln.bias", (C[0],), "b"))
-    add(("encoder.stem.0.kernel", (k * k, C[0]), "w"))
-    add(("encoder.stem.0.bias", (1, C[0]), "b"))
-    add(("encoder.stem.1.ln.weight", (C[0],), "g"))
-    add(("encoder.stem.1.ln.bias", (C[0],), "b"))
-    for i in range(3):
-        p = f"encoder.downsample_layers.{i}"
-        add((p + ".0.ln.weight", (C[i],), "g"))
-        add((p + ".0.ln.bias", (C[i],), "b"))
-        add((p + ".1.kernel", (4, C[i], C[i + 1]), "w"))
-        add((p + ".1.bias", (1, C[i + 1]), "b"))
-    for i in range(4):
-        for j in range(cfg.depths[i]):
-            p = f"encoder.stages.{i}.{j}"
-            add((p + ".dwconv.kernel", (49, C[i]), "w"))
-            add((p + ".dwconv.bias", (1, C[i]), "b"))
-            add((p + ".norm.ln.weight", (C[i],), "g"))
-            add((p + ".norm.ln.bias", (C[i],), "b"))
-            add((p + ".pwconv1.linear.weight", (4 * C[i], C[i]), "w"))
-            add((p + ".pwconv1.linear.bias", (4 * C[i],), "b"))
-            add((p + ".pwconv2.linear.weight", (C[i], 4 * C[i]), "w"))
-            add((p + ".pwconv2.linear.bias", (C[i],), "b"))
-            add((p + ".grn.gamma", (1, 4 * C[i]), "gb"))
-            add((p + ".grn.beta", (1, 4 * C[i]), "gb"))
+    if getattr(cfg, "sparse", True):
+        add(("encoder.initial_conv.0.kernel", (9, cfg.in_chans, C[0]), "w"))
+        add(("encoder.initial_conv.0.bias", (1, C[0]), "b"))
+        add(("encoder.initial_conv.1.ln.weight", (C[0],), "g"))
+        add(("encoder.initial_conv.1.ln.bias", (C[0],), "b"))
+        add(("encoder.stem.0.kernel", (k * k, C[0]), "w"))
+        add(("encoder.stem.0.bias", (1, C[0]), "b"))
+        add(("encoder.stem.1.ln.weight", (C[0],), "g"))
+        add(("encoder.stem.1.ln.bias", (C[0],), "b"))
+        for i in range(3):
+            p = f"encoder.downsample_layers.{i}"
+            add((p + ".0.ln.weight", (C[i],), "g"))
+            add((p + ".0.ln.bias", (C[i],), "b"))
+            add((p + ".1.kernel", (4, C[i], C[i + 1]), "w"))
+            add((p + ".1.bias", (1, C[i + 1]), "b"))
+        for i in range(4):
+            for j in range(cfg.depths[i]):
+                p = f"encoder.stages.{i}.{j}"
+                add((p + ".dwconv.kernel", (49, C[i]), "w"))
+                add((p + ".dwconv.bias", (1, C[i]), "b"))
+                add((p + ".norm.ln.weight", (C[i],), "g"))
+                add((p + ".norm.ln.bias", (C[i],), "b"))
+                add((p + ".pwconv1.linear.weight", (4 * C[i], C[i]), "w"))
+                add((p + ".pwconv1.linear.bias", (4 * C[i],), "b"))
+                add((p + ".pwconv2.linear.weight", (C[i], 4 * C[i]), "w"))
+                add((p + ".pwconv2.linear.bias", (C[i],), "b"))
+                add((p + ".grn.gamma", (1, 4 * C[i]), "gb"))
+                add((p + ".grn.beta", (1, 4 * C[i]), "gb"))
+    else:
+        # dense ConvNeXtV2 (models/convnextv2.py:97-155): nn.Conv2d / nn.Linear / norm_layers.LayerNorm, GRN layouts; `norm` and `head`
+        # (:151-152) are part of its state dict but not of the pretraining graph (they never receive a gradient)
+        add(("encoder.initial_conv.0.weight", (C[0], cfg.in_chans, 3, 3), "w"))
+        add(("encoder.initial_conv.0.bias", (C[0],), "b"))
+        add(("encoder.initial_conv.1.weight", (C[0],), "g"))
+        add(("encoder.initial_conv.1.bias", (C[0],), "b"))
+        add(("encoder.stem.0.weight", (C[0], 1, k, k), "w"))
+        add(("encoder.stem.0.bias", (C[0],), "b"))
+        add(("encoder.stem.1.weight", (C[0],), "g"))
+        add(("encoder.stem.1.bias", (C[0],), "b"))
+        for i in range(3):
+            p = f"encoder.downsample_layers.{i}"
+            add((p + ".0.weight", (C[i],), "g"))
+            add((p + ".0.bias", (C[i],), "b"))
+            add((p + ".1.weight", (C[i + 1], C[i], 2, 2), "w"))
+            add((p + ".1.bias", (C[i + 1],), "b"))
+        for i in range(4):
+            for j in range(cfg.depths[i]):
+                p = f"encoder.stages.{i}.{j}"
+                add((p + ".dwconv.weight", (C[i], 1, 7, 7), "w"))
+                add((p + ".dwconv.bias", (C[i],), "b"))
+                add((p + ".norm.weight", (C[i],), "g"))
+                add((p + ".norm.bias", (C[i],), "b"))
+                add((p + ".pwconv1.weight", (4 * C[i], C[i]), "w"))
+                add((p + ".pwconv1.bias", (4 * C[i],), "b"))
+                add((p + ".grn.gamma", (1, 1, 1, 4 * C[i]), "gb"))
+                add((p + ".grn.beta", (1, 1, 1, 4 * C[i]), "gb"))
+                add((p + ".pwconv2.weight", (C[i], 4 * C[i]), "w"))
+                add((p + ".pwconv2.bias", (C[i],), "b"))
+        add(("encoder.norm.weight", (C[3],), "g"))
+        add(("encoder.norm.bias", (C[3],), "b"))
+        add(("encoder.head.weight", (1000, C[3]), "w"))
+        add(("encoder.head.bias", (1000,), "b"))
     D = cfg.decoder_embed_dim
     add(("proj.weight", (D, C[3], 1, 1), "w"))
     add(("proj.bias", (D,), "b"))

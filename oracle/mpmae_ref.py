@@ -7,7 +7,7 @@ shape with the HIP path (which works on compacted row lists). Only `tests/`,
 
 Pinning: checked against golden vectors produced by the reference's OWN modules
 (/root/reference/models/fcmae.py, models/convnextv2_sparse.py, models/sparse_norm_layers.py,
-models/norm_layers.py, models/convnextv2.py Block, custom_loss.py) run in the build container
+models/norm_layers.py, models/convnextv2.py Block and - for FCMAE(sparse=False) - ConvNeXtV2, custom_loss.py) run in the build container
 (tests/golden/make_golden.py, tests/test_oracle_golden.py). The arithmetic of the absent
 third-party MinkowskiEngine (un-pinned submodule) is restated from its published behaviour and
 `helpers.remap_checkpoint_keys` — PARITY AT THE MinkowskiEngine BOUNDARY IS UNPINNED.
@@ -130,6 +130,46 @@ def sparse_encoder(sd, imgs, mask, cfg, taps=None):
         if taps is not None:
             taps[f"stage{i}_out"] = x
     return x                                                     # .dense()[0] (:218): zeros elsewhere
+
+
+# ----------------------------------------------------------------------------
+# dense encoder (FCMAE(sparse=False))
+# ----------------------------------------------------------------------------
+def _ln_cf(x, w, b, eps=1e-6):
+    """norm_layers.LayerNorm, data_format="channels_first" (norm_layers.py:26-31): biased variance over C."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    x = (x - u) / torch.sqrt(s + eps)
+    return w[:, None, None] * x + b[:, None, None]
+
+
+def dense_encoder(sd, imgs, mask, cfg, taps=None):
+    """ConvNeXtV2.forward with a mask (models/convnextv2.py:183-199): masked pixels are zeroed at the input and nothing else is
+    masked - every point of every map is computed. Stem (:108-124): VALID 3x3 convolution (S - 2 points per side) -> LN -> GELU,
+    depthwise k = stride = patch / 8 with padding k // 2 -> LN; downsampling (:126-131): LN -> 2x2 stride-2 convolution; the blocks
+    are the dense Block (:42-55) with its per-sample GRN. imgs [N,Cin,S,S] (NOT modified) -> [N,C3,grid,grid]."""
+    L = mask.shape[1]
+    scale = int(cfg.img_size // (L ** 0.5))
+    up = upsample_mask(mask, scale).unsqueeze(1).type_as(imgs)
+    x = imgs * (1.0 - up)                                        # :190 (in place in the reference)
+    C = cfg.dims
+    k = cfg.stem_k
+    x = F.conv2d(x, sd["encoder.initial_conv.0.weight"], sd["encoder.initial_conv.0.bias"])
+    x = F.gelu(_ln_cf(x, sd["encoder.initial_conv.1.weight"], sd["encoder.initial_conv.1.bias"]))
+    x = F.conv2d(x, sd["encoder.stem.0.weight"], sd["encoder.stem.0.bias"], stride=k, padding=k // 2, groups=C[0])
+    x = _ln_cf(x, sd["encoder.stem.1.weight"], sd["encoder.stem.1.bias"])
+    if taps is not None:
+        taps["stem_out"] = x
+    for i in range(4):
+        if i > 0:
+            p = f"encoder.downsample_layers.{i - 1}"
+            x = _ln_cf(x, sd[p + ".0.weight"], sd[p + ".0.bias"])
+            x = F.conv2d(x, sd[p + ".1.weight"], sd[p + ".1.bias"], stride=2)
+        for j in range(cfg.depths[i]):
+            x = dense_block(sd, f"encoder.stages.{i}.{j}", x)
+        if taps is not None:
+            taps[f"stage{i}_out"] = x
+    return x
 
 
 # ----------------------------------------------------------------------------
@@ -285,7 +325,7 @@ def forward(sd, imgs_dict, noise, cfg, mask_ratio=None, taps=None):
         if k in ("sentinel2", "sentinel1", "aster", "canopy_height_eth"):
             d[k] = torch.nan_to_num(d[k], nan=0.0, posinf=0.0, neginf=0.0)   # :445-449
     mask = gen_random_mask(noise, cfg.len_keep(mask_ratio))
-    x = sparse_encoder(sd, imgs, mask, cfg, taps)
+    x = (sparse_encoder if getattr(cfg, "sparse", True) else dense_encoder)(sd, imgs, mask, cfg, taps)      # fcmae.py:94-111
     if taps is not None:
         taps["enc_out"] = x
     pred = decoder(sd, x, mask, cfg, taps)

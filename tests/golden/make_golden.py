@@ -41,7 +41,7 @@ def run_reference(c, cfg, sd, inputs, noise_seed):
                if c["aggr"] == "uncertainty" else None)
     model = ref.fcmae.__dict__[c["model"]](
         mask_ratio=0.6, decoder_depth=c.get("decoder_depth", 1), decoder_embed_dim=512, norm_pix_loss=c["norm_pix"],
-        patch_size=c["patch"], img_size=c["img"], args=args, loss_fn=loss_fn, sparse=True)
+        patch_size=c["patch"], img_size=c["img"], args=args, loss_fn=loss_fn, sparse=c.get("sparse", True))
     full = expand_aliases(cfg, sd)
     missing = model.load_state_dict(full, strict=True)
     taps = {}

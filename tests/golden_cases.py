@@ -31,6 +31,10 @@ CASES = OrderedDict(
     # decoder_depth = 2 (fcmae.py:119-121: an nn.Sequential of decoder_depth Blocks shared by every modality)
     allmod_atto_56_dec2=dict(model="convnextv2_atto", img=56, patch=8, subset="all_mod", N=2,
                              norm_pix=True, aggr="uncertainty", wseed=17, iseed=27, nseed=37, decoder_depth=2),
+    # FCMAE(sparse=False): the dense ConvNeXtV2 encoder (fcmae.py:103-111), the mode the reference's own test runs
+    # (tests/pretrain_test.py:17); its stem only lines up at patch 16 (convnextv2.py:108-124)
+    allmod_atto_112_dense=dict(model="convnextv2_atto", img=112, patch=16, subset="all_mod", N=2,
+                               norm_pix=True, aggr="uncertainty", wseed=18, iseed=28, nseed=38, sparse=False),
 )
 
 GRAD_SLICES = {
@@ -38,6 +42,10 @@ GRAD_SLICES = {
     "encoder.stages.2.3.grn.gamma": (slice(None), slice(None, None, 4)),
     "encoder.stages.0.1.dwconv.kernel": (slice(None), slice(None, None, 4)),
     "encoder.downsample_layers.1.1.kernel": (slice(None), slice(None, None, 8), slice(None, None, 8)),
+    "encoder.initial_conv.0.weight": (slice(None, None, 4), slice(None)),
+    "encoder.stem.0.weight": (slice(None, None, 4), slice(None)),
+    "encoder.stages.0.1.dwconv.weight": (slice(None, None, 4), slice(None)),
+    "encoder.downsample_layers.1.1.weight": (slice(None, None, 8), slice(None, None, 8)),
     "proj.weight": (slice(None, None, 16), slice(None, None, 8)),
     "mask_token": (slice(None), slice(None, None, 4)),
     "loss_fn.log_vars": (slice(None),),
@@ -48,7 +56,8 @@ GRAD_SLICES = {
 
 def case_cfg(c):
     return make_cfg(c["model"], c["img"], c["patch"], out_modalities=M.subset(c["subset"]),
-                    norm_pix_loss=c["norm_pix"], loss_aggr=c["aggr"], decoder_depth=c.get("decoder_depth", 1))
+                    norm_pix_loss=c["norm_pix"], loss_aggr=c["aggr"], decoder_depth=c.get("decoder_depth", 1),
+                    sparse=c.get("sparse", True))
 
 
 def case_data(c, cfg):

@@ -353,6 +353,52 @@ def test_column_statistics_bf16(M, H, rpg):
     assert _rel(t1, (dz.float() * ge).view(G, rpg, H).sum(1)) < 5e-4
 
 
+@pytest.mark.parametrize("G,rpg", [(6, 49), (3, 52), (5, 16), (4, 1), (258, 49)])
+def test_dense_decoder_grn_one_launch_per_direction(G, rpg):
+    """mpmae_grn_group_fwd / _bwd (csrc/grn_group.cuh: statistics + finalisation + application of the dense decoder block's GRN,
+    norm_layers.py:25-48, one statistics group per sample) against torch fp32 + autograd on the same bf16 operands, and the
+    per-sample gamma / beta gradient rows through the deferred fold (mpmae_fold_group)."""
+    from mmearth_train_amd import _lib as L
+    lib = L.load()
+    H, M = 2048, G * rpg
+    assert lib.mpmae_grn_group_ok(1, M, H, rpg) == 1 and lib.mpmae_grn_group_ok(0, M, H, rpg) == 0
+    assert lib.mpmae_grn_group_ok(1, M, 1024, rpg) == 0 and lib.mpmae_grn_group_ok(1, M, H, 53) == 0
+    torch.manual_seed(G * 100 + rpg)
+    P = lambda t: C.c_void_p(t.data_ptr())
+    h = (torch.randn(M, H, device=DEV) * 1.3).to(bf)
+    h[:, 7] = 0                                         # a dead column: Gx == 0 -> coef 0 (no 0 / 0)
+    dzb = (torch.randn(M, H, device=DEV) * 0.3).to(bf)
+    gamma, beta = torch.randn(H, device=DEV) * 0.5, torch.randn(H, device=DEV) * 0.1
+    eps = 1e-6
+    z = torch.empty(M, H, device=DEV, dtype=bf)
+    Gx, Ainv, scale = torch.empty(G, H, device=DEV), torch.empty(G, device=DEV), torch.empty(G, H, device=DEV)
+    assert lib.mpmae_grn_group_fwd(1, P(h), P(z), P(gamma), P(beta), eps, M, H, rpg, P(Gx), P(Ainv), P(scale), _st()) == 0
+    hf = h.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ge = (0.5 * hf * (1 + torch.erf(hf / math.sqrt(2)))).view(G, rpg, H)
+    gx = torch.linalg.vector_norm(ge, dim=1, keepdim=True)          # (torch.norm as in norm_layers.py:41: zero subgradient at 0)
+    nx = gx / (gx.mean(-1, keepdim=True) + eps)
+    zr = (ge * (1 + gm * nx) + bt).view(M, H)
+    _assert_bf16_close(z, zr.detach(), "z", ulps=1.5)
+    assert _rel(Gx, gx.detach().view(G, H)) < 5e-4
+    assert _rel(Ainv, 1 / (gx.detach().mean(-1).view(G) + eps)) < 5e-4
+    assert _rel(scale, (1 + gm * nx).detach().view(G, H)) < 5e-4
+    zr.backward(dzb.float())
+    dz = dzb.clone()
+    slab = torch.full((G, 2 * H), float("nan"), device=DEV)
+    assert lib.mpmae_grn_group_bwd(1, P(dz), P(h), P(scale), P(Gx), P(Ainv), P(gamma), M, H, rpg, P(slab), _st()) == 0
+    # dh: the polynomial GELU' is within 1.6e-4 of the exact derivative; bound relative to the tensor scale
+    err = (dz.float() - hf.grad).abs().max().item()
+    assert err < 2.0 ** -7 * hf.grad.abs().max().item(), err
+    grads = torch.zeros(2 * H + 64, device=DEV)
+    dgam, dbet = grads[:H], grads[H + 64:]
+    fd = (L.FoldDesc * 1)(L.FoldDesc(slab.data_ptr(), G, 2 * H, dgam.data_ptr(), H, H + 64, 1))
+    assert lib.mpmae_fold_group(fd, 1, _st()) == 0
+    torch.cuda.synchronize()
+    assert _rel(dgam, gm.grad) < 2e-3 and _rel(dbet, bt.grad) < 5e-4
+    assert float(grads[H:H + 64].abs().max()) == 0.0
+
+
 def test_pool_rows_and_mask_token_bf16(eng):
     e, lib = eng, eng.lib
     N, L, D = e.N, e.L, e.D
