@@ -307,6 +307,10 @@ int mpmae_crop_lut(const uint8_t* src, long long* dst, int N, int H, int S, cons
  * (1 = removed), vis [N,keep], inv [N,L]. */
 int mpmae_mask_gen(const float* noise, int N, int L, int keep, float* mask, int* vis, int* inv,
                    mpmae_stream_t stream);
+/* The same mask for FCMAE(sparse=False) (models/convnextv2.py:183-191: the dense encoder computes every patch and only zeroes the
+ * masked input pixels): mask f32 [N,L] as above; inv [N,L] = l for a kept patch (its row within the sample, all L patches being
+ * rows), -1 for a masked one. */
+int mpmae_mask_gen_dense(const float* noise, int N, int L, int keep, float* mask, int* inv, mpmae_stream_t stream);
 /* MinkowskiOps.to_sparse activity rule (convnextv2_sparse.py:199): act[row] = sum_c|x| != 0. */
 int mpmae_activity(const float* img, const int* vis, uint8_t* act, int N, int Cin, int H, int keep,
                    int grid, int S, mpmae_stream_t stream);

@@ -124,8 +124,9 @@ def main(args):
     device = torch.device("cuda", local_rank) if args.device == "cuda" else torch.device(args.device)
     if device.type != "cuda":
         raise RuntimeError("the pretraining path runs on the HIP engine only (no CPU fallback): --device cuda")
-    if not args.sparse:
-        raise NotImplementedError("--sparse False (the reference's dense debug encoder, broken at 56/8) is not provided")
+    if not args.sparse and args.patch_size != 16:
+        raise ValueError("--sparse False: the dense encoder's stem only lines up with the patch grid at --patch_size 16 "
+                         "(models/convnextv2.py:108-124; the reference fails in forward_decoder at patch 8)")
     if args.use_mixed:
         print("--use_mixed: fp16 autocast + GradScaler are replaced by bf16 activations with fp32 master weights "
               "(--compute_dtype bf16, no loss scaling needed)")

@@ -146,6 +146,12 @@ int mpmae_mask_gen(const float* noise, int N, int L, int keep, float* mask, int*
   RET();
 }
 
+int mpmae_mask_gen_dense(const float* noise, int N, int L, int keep, float* mask, int* inv, mpmae_stream_t s) {
+  if (!noise || !mask || !inv || N < 1 || L < 1 || keep < 0 || keep > L) return (int)hipErrorInvalidValue;
+  LAUNCH(mask_gen_dense_kernel, dim3(N), dim3(256), (size_t)L * sizeof(float), S_(s), noise, L, keep, mask, inv);
+  RET();
+}
+
 int mpmae_activity(const float* img, const int* vis, uint8_t* act, int N, int Cin, int H, int keep, int grid, int S,
                    mpmae_stream_t s) {
   const int total = N * keep * S * S;

@@ -37,6 +37,25 @@ __global__ __launch_bounds__(256) void mask_gen_kernel(const float* __restrict__
   }
 }
 
+// The same mask for the DENSE encoder (FCMAE(sparse=False), models/convnextv2.py:183-191): every patch is computed, so the encoder's
+// rows are all N * L patches in patch order and the table only says which of them the mask removed: inv[n, l] = l for a kept patch
+// (its row within the sample), -1 for a masked one (zeroed input pixels, mask token in the decoder input, fcmae.py:253-255).
+__global__ __launch_bounds__(256) void mask_gen_dense_kernel(const float* __restrict__ noise, int L, int keep,
+                                                             float* __restrict__ mask, int* __restrict__ inv) {
+  extern __shared__ float sh[];            // noise row [L]
+  const int n = blockIdx.x;
+  for (int l = threadIdx.x; l < L; l += blockDim.x) sh[l] = noise[(size_t)n * L + l];
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    const float v = sh[l];
+    int rank = 0;
+    for (int j = 0; j < L; ++j) rank += (sh[j] < v) || (sh[j] == v && j < l);
+    const int masked = rank >= keep;
+    mask[(size_t)n * L + l] = masked ? 1.f : 0.f;
+    inv[(size_t)n * L + l] = masked ? -1 : l;
+  }
+}
+
 // act0[row] = (sum_c |img[n,c,y,x]| != 0) for every pixel of every visible patch (ME to_sparse)
 __global__ __launch_bounds__(256) void activity_kernel(const float* __restrict__ img, const int* __restrict__ vis,
                                                        uint8_t* __restrict__ act, int N, int Cin, int H, int keep,

@@ -25,7 +25,7 @@ import torch
 from . import _lib
 from ._lib import EPI, PRO
 from .config import ModelCfg
-from .synth import flat_param_spec, state_dict_spec
+from .synth import dense_aliases, flat_param_spec, param_view, state_dict_spec
 
 F32, BF16 = 0, 1
 
@@ -82,6 +82,18 @@ def _rup(x, m):
     return (x + m - 1) // m * m
 
 
+class _ParamDict(OrderedDict):
+    """Parameters (or gradients) by state-dict key; `alias` holds engine-internal names of the same storage (dense encoder: the stem and
+    downsampling tensors under the sparse encoder's names and layouts, synth.dense_aliases) - looked up, never iterated."""
+
+    def __init__(self):
+        super().__init__()
+        self.alias = {}
+
+    def __missing__(self, key):
+        return self.alias[key]
+
+
 class Engine:
     def __init__(self, cfg: ModelCfg, batch_size: int, dtype: str = "bf16", device="cuda",
                  track_activity: bool = True, mask_ratio=None, block_mode=None, param_buffers=None, lanes=None, options=None):
@@ -108,7 +120,10 @@ class Engine:
         self.dt = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16, "fp8": BF16, "mxfp8": BF16}[dtype]
         self.tdtype = torch.float32 if self.dt == F32 else torch.bfloat16
         self.device = torch.device(device)
-        self.track_activity = track_activity
+        # FCMAE(sparse=False) (fcmae.py:103-111): the dense ConvNeXtV2 encoder computes EVERY patch (rows = all N * L patches in patch order,
+        # geometry tables NULL) and the mask only zeroes input pixels, places the mask token and selects the loss patches
+        self.dense = not getattr(cfg, "sparse", True)
+        self.track_activity = track_activity and not self.dense
         self.block_mode_override = block_mode      # None (policy) | "fused" | "mat"
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.disable_rsc = (not self.opt["rsc"])
@@ -132,7 +147,8 @@ class Engine:
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
         self.L = cfg.num_patches
         self.grid = cfg.grid
-        self.keep = cfg.len_keep(mask_ratio)
+        self.keep_mask = cfg.len_keep(mask_ratio)                    # patches the mask keeps per sample
+        self.keep = self.L if self.dense else self.keep_mask         # patches per sample the encoder has rows for
         self.p = cfg.patch_size
         self.S = [8, 4, 2, 1]
         self.M = [N * self.keep * s * s for s in self.S]
@@ -176,17 +192,24 @@ class Engine:
         self.mflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.vflat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.decay_mask = torch.zeros(total, dtype=torch.uint8, device=dev)
-        self.params, self.grads, self.offsets = OrderedDict(), OrderedDict(), OrderedDict()
+        self.params, self.grads, self.offsets = _ParamDict(), _ParamDict(), OrderedDict()
         off = 0
         for key, shape, _ in spec:
             n = math.prod(shape)
-            self.params[key] = self.pflat[off:off + n].view(shape)
-            self.grads[key] = self.gflat[off:off + n].view(shape)
+            self.params[key] = param_view(self.pflat[off:off + n], key, shape)
+            self.grads[key] = param_view(self.gflat[off:off + n], key, shape)
             self.offsets[key] = (off, n)
-            # timm param_groups_weight_decay: ndim <= 1 or name endswith ".bias" -> no decay
-            if len(shape) > 1 and not key.endswith(".bias"):
+            # timm param_groups_weight_decay: ndim <= 1 or name endswith ".bias" -> no decay. The dense encoder's classifier head
+            # (convnextv2.py:151-152) is in the state dict but not in the pretraining graph: its gradient is None in the reference, so
+            # the optimizer skips it - here its gradient stays zero and it must not decay either
+            if len(shape) > 1 and not key.endswith(".bias") and not key.startswith("encoder.head."):
                 self.decay_mask[off:off + n] = 1
             off += n
+        if self.dense:
+            for akey, key, ashape in dense_aliases(self.cfg):
+                o, n = self.offsets[key]
+                self.params.alias[akey] = self.pflat[o:o + n].view(ashape)
+                self.grads.alias[akey] = self.gflat[o:o + n].view(ashape)
         self.n_params = total
         self.hp = torch.zeros(8, dtype=torch.float32, device=dev)   # {lr, 1/bc1, 1/sqrt(bc2), grad_scale, skip, n_skipped, -, -}
         # hyper-parameter ring: slot t % HP_SLOTS is written by set_hyper for optimizer launch t and read on the
@@ -254,8 +277,21 @@ class Engine:
         self.mask = torch.zeros(N, L, dtype=f32, device=dev)
         self.vis = torch.zeros(N * self.keep, dtype=torch.int32, device=dev)
         self.inv = torch.zeros(N * L, dtype=torch.int32, device=dev)
+        if self.dense:      # every patch is a row, in patch order (the stem's gather walks `vis`; `inv` comes from mpmae_mask_gen_dense)
+            self.vis.copy_(torch.arange(L, dtype=torch.int32, device=dev).repeat(N))
         # activity maps
-        if self.track_activity:
+        if self.dense:
+            # The dense stem's 3x3 convolution is VALID (convnextv2.py:110: S - 2 points per side) and its depthwise k x k stride-k
+            # convolution pads k // 2 (:117-121): in pixel-centred terms the outermost ring of convolution outputs does not exist and
+            # contributes zero to the depthwise sum. That is exactly an inactive site of the sparse stem kernels: a STATIC activity map.
+            S_ = cfg.img_size
+            ring = torch.ones(S_, S_, dtype=torch.uint8)
+            ring[0, :] = 0; ring[-1, :] = 0; ring[:, 0] = 0; ring[:, -1] = 0
+            g_, p_ = self.grid, self.p
+            rows = ring.view(g_, p_, g_, p_).permute(0, 2, 1, 3).reshape(-1)          # (patch, iy, ix) = the row order within a sample
+            self.act_full = rows.repeat(N).contiguous().to(dev)
+            self.act = [None] * 4
+        elif self.track_activity:
             self.act_full = torch.ones(self.Mfull, dtype=torch.uint8, device=dev)
             self.act = [self.act_full if self.p == 8 else torch.ones(self.M[0], dtype=torch.uint8, device=dev)]
             for i in range(1, 4):
@@ -278,7 +314,11 @@ class Engine:
         self.blocks = []           # encoder blocks then the decoder block
         for i in range(4):
             for j in range(cfg.depths[i]):
-                self.blocks.append(self._alloc_block(f"encoder.stages.{i}.{j}", self.M[i], dims[i], 1, i, sparse=True))
+                if self.dense:      # the dense Block (convnextv2.py:18-55): per-sample GRN over the stage's whole map
+                    self.blocks.append(self._alloc_block(f"encoder.stages.{i}.{j}", self.M[i], dims[i], N, i, sparse=False,
+                                                         rpg=self.M[i] // N))
+                else:
+                    self.blocks.append(self._alloc_block(f"encoder.stages.{i}.{j}", self.M[i], dims[i], 1, i, sparse=True))
         # the decoder: nn.Sequential of decoder_depth dense Blocks shared by every modality (fcmae.py:119-121,137,145)
         self.decs = [self._alloc_block(f"decoder_dict.{cfg.out_mods[0].name}.{j}", N * L, D, N, None, sparse=False)
                      for j in range(cfg.decoder_depth)]
@@ -345,10 +385,10 @@ class Engine:
         self.ws2 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # side-lane (weight-gradient) scratch
         self.ws3 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # second side lane (depthwise weight gradients)
 
-    def _alloc_block(self, prefix, M, Cc, G, stage, sparse):
+    def _alloc_block(self, prefix, M, Cc, G, stage, sparse, rpg=None):
         H = 4 * Cc
         f32 = torch.float32
-        blk = dict(prefix=prefix, M=M, C=Cc, H=H, G=G, stage=stage, sparse=sparse,
+        blk = dict(prefix=prefix, M=M, C=Cc, H=H, G=G, stage=stage, sparse=sparse, rpg=rpg or (M if sparse else self.L),
                    d=self._t(M, Cc), dhat=self._t(M, Cc), rstd=self._t(M, dtype=f32),
                    h=self._t(M, H), out=self._t(M, Cc),
                    Gx=self._t(G * H, dtype=f32), Ainv=self._t(G, dtype=f32),
@@ -388,7 +428,7 @@ class Engine:
             add(prefix + ".W2T", w2, H, Cc, 1, H)
 
         for blk in self.blocks:
-            block_weights(blk["prefix"], blk["C"], True)
+            block_weights(blk["prefix"], blk["C"], blk["sparse"])
         for i in range(3):
             kk = P[f"encoder.downsample_layers.{i}.1.kernel"]      # (4, C, C')
             Ci, Co = dims[i], dims[i + 1]
@@ -695,6 +735,8 @@ class Engine:
         g = _lib.Geom()
         if stage is None:      # dense decoder grid
             g.vis, g.inv, g.N, g.keep, g.grid, g.S = 0, 0, self.N, self.L, self.grid, 1
+        elif self.dense:       # every patch present: NULL tables, slot = patch
+            g.vis, g.inv, g.N, g.keep, g.grid, g.S = 0, 0, self.N, self.L, self.grid, self.S[stage]
         else:
             g.vis, g.inv = self.vis.data_ptr(), self.inv.data_ptr()
             g.N, g.keep, g.grid, g.S = self.N, self.keep, self.grid, self.S[stage]
@@ -766,7 +808,7 @@ class Engine:
     # ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------
     def _ps_ok(self, stage):
         """One launch for the whole stage: bf16, (C, S) = (160, 2) or (320, 1), every sample's workgroup resident (N <= CUs)."""
-        if not self.opt["ps"] or self.dt != BF16 or self.disable_rs or (self.block_mode_override or "mat") != "mat":
+        if not self.opt["ps"] or self.dt != BF16 or self.disable_rs or (self.block_mode_override or "mat") != "mat" or self.dense:
             return False
         Cc, S, depth = self.cfg.dims[stage], self.S[stage], self.cfg.depths[stage]
         if (Cc, S) not in ((160, 2), (320, 1)) or depth > _lib.PS_MAXBLK or not (int(self.opt["ps"]) >> (S - 1)) & 1:
@@ -866,7 +908,7 @@ class Engine:
         nm = self._block_names(blk)
         M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
         act = self.act[blk["stage"]] if blk["sparse"] else None
-        rpg = M if blk["sparse"] else self.L
+        rpg = blk["rpg"]
         eps = 1e-6 if blk["sparse"] else 1e-4
         tag = blk["prefix"]
         esz = 4 if dt == F32 else 2
@@ -951,7 +993,7 @@ class Engine:
         nm = self._block_names(blk)
         M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
         act = self.act[blk["stage"]] if blk["sparse"] else None
-        rpg = M if blk["sparse"] else self.L
+        rpg = blk["rpg"]
         tag = blk["prefix"]
         esz = 4 if dt == F32 else 2
         t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1      # dz / dd alternate per block: the side lane reads them
@@ -1128,7 +1170,7 @@ class Engine:
         nm = self._block_names(blk)
         M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
         act = self.act[blk["stage"]] if blk["sparse"] else None
-        rpg = M if blk["sparse"] else self.L
+        rpg = blk["rpg"]
         eps = 1e-6 if blk["sparse"] else 1e-4
         tag = blk["prefix"]
         blk["x"] = x
@@ -1162,8 +1204,11 @@ class Engine:
         # the pixel-activity map and its poolings also only read the inputs (and the mask tables): with `front_side` they follow the weight
         # staging on the side lane, so the main lane goes mask -> im2col directly and the stem GEMM waits for ONE side-lane event
         front_side = prep_side and bool(self.opt["front_side"]) and self.track_activity
-        self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv),
-                 **(dict(signal="mask_done") if front_side else {}))
+        if self.dense:
+            self._op(f, "mask", lib.mpmae_mask_gen_dense, _p(self.noise), N, L, self.keep_mask, _p(self.mask), _p(self.inv))
+        else:
+            self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv),
+                     **(dict(signal="mask_done") if front_side else {}))
         img = self.inp["sentinel2"]
         if self.track_activity:
             fl = dict(lane=1) if front_side else {}
@@ -1463,7 +1508,7 @@ class Engine:
         nm = self._block_names(blk)
         M, Cc, H, G = blk["M"], blk["C"], blk["H"], blk["G"]
         act = self.act[blk["stage"]] if blk["sparse"] else None
-        rpg = M if blk["sparse"] else self.L
+        rpg = blk["rpg"]
         tag = blk["prefix"]
         dz = self.scr_dz[:M * H]
         dxn = self.scr_dxn[:M * Cc]
@@ -1574,6 +1619,8 @@ class Engine:
         if self.proj_compact:
             # the token-gradient pass over dxdec also gathers the visible rows: proj's two gradients are plain GEMMs on [M3, D]
             dyv = self.proj_rows                       # (the forward's compact rows are dead by now)
+            if self.dense:      # rows of masked patches exist here and receive no gradient (x * (1 - mask), fcmae.py:255): the gather skips them
+                self._op(b, "proj.dy.zero", lib.mpmae_memset_async, _p(dyv), 0, dyv.numel() * dyv.element_size())
             self._op(b, "mask_token.bwd", lib.mpmae_mask_token_bwd, dt, _p(dxdec), _p(self.inv), _p(Gd["mask_token"]), N * L, D,
                      _p(dyv), self.keep, L)
             self._side_wgrad(b, "proj.wgrad", "NONE", "NONE", [dyv], P=dyv, Q=self.enc_out, M=self.M[3], Nn=D, Kk=dims[3], ldp=D,
@@ -1891,6 +1938,10 @@ class Engine:
         """Install a caller-supplied mask [N, L] (0 keep / 1 remove, `keep` zeros per row): the rank kernel is
         stable, so ranking the mask values themselves reproduces exactly this mask and its vis / inv tables."""
         self.noise.copy_(mask.reshape(self.N, self.L).to(torch.float32))
+        if self.dense:
+            _lib.check(self.lib.mpmae_mask_gen_dense(_p(self.noise), self.N, self.L, self.keep_mask, _p(self.mask), _p(self.inv),
+                                                     self._stream()), "mask_gen_dense")
+            return
         _lib.check(self.lib.mpmae_mask_gen(_p(self.noise), self.N, self.L, self.keep, _p(self.mask), _p(self.vis),
                                            _p(self.inv), self._stream()), "mask_gen")
 

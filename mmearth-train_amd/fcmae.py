@@ -12,7 +12,8 @@ Parameters are nn.Parameters whose storage is one flat fp32 buffer (the engine's
 the reference's names through a generated module tree, so `state_dict()` / `load_state_dict()` /
 `named_parameters()` / timm-style weight-decay grouping behave as with the reference (the shared
 decoder block appears under every `decoder_dict.<modality>`). There is no CPU fallback: forward
-needs the HIP library and a GPU (`sparse=False`, the reference's dense debug path, is not provided).
+needs the HIP library and a GPU. `sparse=False` selects the dense ConvNeXtV2 encoder (fcmae.py:103-111; patch_size 16 only, as
+in the reference, whose dense stem does not line up with the patch grid at patch 8).
 """
 import math
 from argparse import Namespace
@@ -26,7 +27,7 @@ from torch import Tensor
 from .MODALITIES import PIXEL_WISE_MODALITIES
 from .config import SIZES, cfg_from_args
 from .engine import Engine
-from .synth import flat_param_spec, state_dict_spec
+from .synth import flat_param_spec, param_view, state_dict_spec
 
 
 def _trunc_normal_(t, std, gen=None):
@@ -44,8 +45,8 @@ def init_reference_(params: "OrderedDict[str, Tensor]", generator=None):
                 t.normal_(0.0, 0.02, generator=generator)
             elif k.endswith("bias") or k.endswith(".beta") or k.endswith(".gamma") or k == "loss_fn.log_vars":
                 t.zero_()
-            elif k.endswith("ln.weight") or k.endswith("norm.weight") or k == "layer_norm_tmp.weight":
-                t.fill_(1.0)
+            elif k.endswith("ln.weight") or k.endswith("norm.weight") or k == "layer_norm_tmp.weight" or (k.endswith(".weight") and t.dim() == 1):
+                t.fill_(1.0)                         # (1-d weights are normalisation scales: the dense encoder's LayerNorms are `<layer>.weight`)
             elif k.endswith("dwconv.kernel") or k.endswith("stem.0.kernel") or ".linear.weight" in k:
                 _trunc_normal_(t, 1.0, generator)
             elif k.endswith(".kernel"):
@@ -81,7 +82,7 @@ class _StepFn(torch.autograd.Function):
                                "forward of the same batch size; call loss.backward() before the next forward")
         eng.backward(zero_grad=True)
         g = eng.gflat * grad_out
-        outs = tuple(g[o:o + n].view(p.shape) for p, (o, n) in zip(model._plist, model._poffs))
+        outs = tuple(param_view(g[o:o + n], k, p.shape) for k, p, (o, n) in zip(model._pkeys, model._plist, model._poffs))
         return (None, None) + outs
 
 
@@ -110,8 +111,6 @@ class FCMAE(nn.Module):
                  norm_pix_loss: bool = False, args: Namespace = None, loss_fn=None, sparse: bool = True,
                  device=None, dtype: str = "bf16"):
         super().__init__()
-        if not sparse:
-            raise NotImplementedError("only the sparse encoder (the reference default, main_pretrain.py:157) is provided")
         if getattr(args, "use_orig_stem", False):
             raise NotImplementedError("use_orig_stem=True is not used by any reference recipe (TRAINING.md:39)")
         depths = depths or [3, 3, 9, 3]
@@ -126,7 +125,7 @@ class FCMAE(nn.Module):
         self.decoder_embed_dim, self.decoder_depth = decoder_embed_dim, decoder_depth
         self.norm_pix_loss, self.sparse = norm_pix_loss, sparse
         self.cfg = cfg_from_args(name, img_size, patch_size, args, norm_pix_loss, mask_ratio,
-                                 decoder_embed_dim, decoder_depth)
+                                 decoder_embed_dim, decoder_depth, sparse=sparse)      # (sparse=False: the dense encoder, patch 16 only)
         if (self.cfg.loss_aggr == "uncertainty") != (loss_fn is not None):
             raise ValueError("loss_fn must be given iff args.loss_aggr == 'uncertainty'")
         self.in_chans = self.cfg.in_chans
@@ -139,7 +138,7 @@ class FCMAE(nn.Module):
         total = sum(math.prod(s) for _, s, _ in spec)
         self._pflat = torch.zeros(total, dtype=torch.float32, device=self._device)
         self._gflat = torch.zeros(total + 4, dtype=torch.float32, device=self._device)[:total]      # (+ the loss slot of the exchange, engine.gflat_ext)
-        self._plist, self._poffs, views = [], [], OrderedDict()
+        self._plist, self._pkeys, self._poffs, views = [], [], [], OrderedDict()
         first = self.cfg.out_mods[0].name
         offs, off = {}, 0
         for key, shape, _ in flat_param_spec(self.cfg):      # the engine's layout of the flat buffers
@@ -147,9 +146,10 @@ class FCMAE(nn.Module):
             off += math.prod(shape)
         for key, shape, _ in spec:                            # registration (state-dict) order = the reference's
             n, off = math.prod(shape), offs[key]
-            p = nn.Parameter(self._pflat[off:off + n].view(shape))
+            p = nn.Parameter(param_view(self._pflat[off:off + n], key, shape))
             views[key] = p
             self._plist.append(p)
+            self._pkeys.append(key)
             self._poffs.append((off, n))
         init_reference_(OrderedDict((k, p.data) for k, p in views.items()))
         # module tree with the reference's names
@@ -279,10 +279,10 @@ class FCMAE(nn.Module):
         if not bool(((mask == 0).sum(dim=1) == keep).all()):
             raise ValueError("forward_decoder: every sample must keep the same number of patches")
         eng = self._engine = self._get_engine(N, 1.0 - (keep + 0.5) / self.cfg.num_patches)
-        assert eng.keep == keep
+        assert eng.keep_mask == keep
         eng.set_mask(mask)
         rows = x.permute(0, 2, 3, 1).reshape(N, self.cfg.num_patches, -1)
-        vis = eng.vis.view(N, keep).long()
+        vis = eng.vis.view(N, eng.keep).long()           # (dense encoder: every patch is a row)
         eng.enc_out.copy_(torch.gather(rows, 1, vis[:, :, None].expand(-1, -1, rows.shape[-1]))
                           .reshape(eng.enc_out.shape).to(eng.enc_out.dtype))
         eng.run_segment("decoder")

@@ -115,6 +115,41 @@ def state_dict_spec(cfg: ModelCfg):
     return spec
 
 
+def _dense_conv_key(key):
+    return key == "encoder.initial_conv.0.weight" or (key.startswith("encoder.downsample_layers.") and key.endswith(".1.weight"))
+
+
+def param_view(buf, key, shape):
+    """View of a parameter's slice of a flat buffer in the reference's shape. The convolution weights of the DENSE encoder are STORED
+    kernel-offset-major, [(kw*k + kh)][Cin][Cout] / [(kw*k + kh)][C] - the MinkowskiEngine layout of the sparse encoder, which is what
+    the engine's kernels read (helpers.py:676-688 is the reference's own mapping between the two) - and are exposed here as the
+    permuted, non-contiguous view with nn.Conv2d's [Cout, Cin, kh, kw] / [C, 1, kh, kw] indexing. Everything else is stored as shaped."""
+    if _dense_conv_key(key):
+        co, ci, k, _ = shape
+        return buf.view(k, k, ci, co).permute(3, 2, 1, 0)
+    if key == "encoder.stem.0.weight":
+        c0, _, k, _ = shape
+        return buf.view(k, k, c0).permute(2, 1, 0).unsqueeze(1)
+    return buf.view(shape)
+
+
+def dense_aliases(cfg):
+    """(engine-internal key, state-dict key, internal shape) for the dense encoder's stem and downsampling layers: the engine's launch
+    program addresses them under the sparse encoder's names and layouts (same storage, see param_view)."""
+    C, k = cfg.dims, cfg.stem_k
+    out = [("encoder.initial_conv.0.kernel", "encoder.initial_conv.0.weight", (9, cfg.in_chans, C[0])),
+           ("encoder.initial_conv.1.ln.weight", "encoder.initial_conv.1.weight", (C[0],)),
+           ("encoder.initial_conv.1.ln.bias", "encoder.initial_conv.1.bias", (C[0],)),
+           ("encoder.stem.0.kernel", "encoder.stem.0.weight", (k * k, C[0])),
+           ("encoder.stem.1.ln.weight", "encoder.stem.1.weight", (C[0],)),
+           ("encoder.stem.1.ln.bias", "encoder.stem.1.bias", (C[0],))]
+    for i in range(3):
+        p = f"encoder.downsample_layers.{i}"
+        out += [(p + ".0.ln.weight", p + ".0.weight", (C[i],)), (p + ".0.ln.bias", p + ".0.bias", (C[i],)),
+                (p + ".1.kernel", p + ".1.weight", (4, C[i], C[i + 1]))]
+    return out
+
+
 def _fan_in(key, shape):
     if key.endswith("dwconv.kernel") or key.endswith("stem.0.kernel"):
         return shape[0]

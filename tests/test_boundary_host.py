@@ -62,6 +62,59 @@ def test_init_reference_distributions(lib):
             assert (v == 1).all(), k
 
 
+def test_dense_mode_state_dict_is_the_reference_layout_over_kernel_major_storage():
+    """FCMAE(sparse=False) (fcmae.py:103-111): parameter names / shapes are those of the dense ConvNeXtV2 (convnextv2.py:97-155,
+    incl. its unused `norm` / `head`), initialised as fcmae.py:157-178 leaves them; the convolution weights of the stem and the
+    downsampling layers are nn.Conv2d-shaped VIEWS of kernel-offset-major storage (what the engine's kernels read): loading a
+    reference-layout state dict and reading the flat buffer back must give helpers.py:676-688's layout. patch 8 is refused, as the
+    reference's dense stem cannot serve it."""
+    from mmearth_train_amd import MODALITIES as MM
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args, make_cfg
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    from mmearth_train_amd.synth import dense_aliases, expand_aliases, flat_param_spec, make_state_dict, state_dict_spec
+    from oracle.mpmae_ref import _me_conv_weight, _me_dw_weight
+    args = default_args(out_modalities=MM.subset("all_mod"))
+    mk = lambda **kw: fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True, args=args,
+                                            loss_fn=UncertaintyWeightingStrategy(12), device="cpu", **kw)
+    with pytest.raises(ValueError):
+        mk(patch_size=8, img_size=56, sparse=False)
+    torch.manual_seed(0)
+    m = mk(patch_size=16, img_size=112, sparse=False)
+    cfg = make_cfg("convnextv2_atto", 112, 16, out_modalities=MM.subset("all_mod"), sparse=False)
+    sd = m.state_dict()
+    want = expand_aliases(cfg, OrderedDict((k, s) for k, s, _ in state_dict_spec(cfg)))
+    assert set(sd.keys()) == set(want.keys())
+    for k, shape in want.items():
+        assert tuple(sd[k].shape) == tuple(shape), k
+    assert sd["encoder.head.weight"].shape == (1000, 320) and "encoder.norm.weight" in sd
+    assert not any(".ln." in k or k.endswith(".kernel") or ".linear." in k for k in sd)
+    for k, v in sd.items():      # init: 1-d weights are normalisation scales (1), Conv2d std 1 truncated, Linear std 0.02
+        if k.endswith(".weight") and v.dim() == 1:
+            assert (v == 1).all(), k
+    assert abs(sd["encoder.downsample_layers.1.1.weight"].std().item() - 0.8796) < 0.05
+    assert abs(sd["encoder.stages.2.0.pwconv1.weight"].std().item() - 0.02) < 0.002
+    # load a seeded reference-layout state dict; the flat storage is kernel-offset-major
+    src = make_state_dict(cfg, seed=5)
+    m.load_state_dict(expand_aliases(cfg, src), strict=True)
+    offs, off = {}, 0
+    for key, shape, _ in flat_param_spec(cfg):
+        offs[key] = (off, math.prod(shape))
+        off += math.prod(shape)
+    for akey, key, ashape in dense_aliases(cfg):
+        o, n = offs[key]
+        stored = m._pflat[o:o + n].view(ashape)
+        if key.endswith("conv.0.weight") or key.endswith(".1.weight") and len(ashape) == 3:
+            assert torch.equal(_me_conv_weight(stored, int(round(ashape[0] ** 0.5))), src[key]), key
+        elif key == "encoder.stem.0.weight":
+            assert torch.equal(_me_dw_weight(stored, 2), src[key])
+        else:
+            assert torch.equal(stored.reshape(-1), src[key].reshape(-1)), key
+    back = m.state_dict()
+    for k, v in expand_aliases(cfg, src).items():
+        assert torch.equal(back[k], v), k
+
+
 def test_init_matches_reference_statistics():
     from oracle.refharness import load_reference as LR
     if not LR.available():

@@ -67,6 +67,53 @@ def test_forward_pieces_equal_forward_and_oracle():
     assert abs(l0.item() - ref0[0].item()) <= 1e-4 * abs(ref0[0].item())
 
 
+def test_dense_mode_module_pieces_and_training_step():
+    """FCMAE(sparse=False) (fcmae.py:103-111; the mode of the reference's own tests/pretrain_test.py:17) through the module: the three
+    forward pieces against the oracle's dense encoder, then model(...) + loss.backward(): every .grad in the reference's nn.Conv2d /
+    nn.Linear shapes against the oracle's autograd (fp32 mode bounds), the classifier head untouched (no gradient in the reference)."""
+    from mmearth_train_amd import MODALITIES as MM
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    from mmearth_train_amd.synth import expand_aliases
+    c = CASES["allmod_atto_112_dense"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    args = default_args(out_modalities=MM.subset("all_mod"))
+    model = fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True, patch_size=16,
+                                  img_size=112, args=args, loss_fn=UncertaintyWeightingStrategy(12), sparse=False,
+                                  device="cuda:0", dtype="f32")
+    model.load_state_dict(expand_aliases(cfg, sd), strict=True)
+    dev = {k: v.to("cuda:0") for k, v in inputs.items()}
+    x, mask = model.forward_encoder(dev["sentinel2"].clone(), 0.6)
+    (oloss, opred, omask, oloss_dict, _, ow), taps, ograds = _oracle(cfg, sd, inputs, model._engine.noise.cpu())
+    assert torch.equal(mask.cpu(), omask) and tuple(x.shape) == (2, 320, 7, 7)
+    assert _rel(x, taps["enc_out"]) < 1e-4
+    assert float(x.detach().abs().reshape(2, 320, 49).amax(1).min()) > 0          # masked patches are computed too (nothing is zero)
+    pred = model.forward_decoder(x, mask)
+    for k, v in opred.items():
+        assert _rel(pred[k], v) < 2e-4, k
+    # the training step on the same noise
+    torch.manual_seed(123)                                # (forward() draws its own noise: read it back from the engine for the oracle)
+    out = model(dev, mask_ratio=0.6)
+    out[0].backward()
+    nz = model._engine.noise.cpu()
+    (oloss, _, omask, _, _, _), _, ograds = _oracle(cfg, sd, inputs, nz)
+    assert torch.equal(out[2].cpu(), omask)
+    assert abs(out[0].item() - oloss.item()) <= 1e-4 * abs(oloss.item())
+    named = dict(model.named_parameters())
+    for k, go in ograds.items():
+        if k == "loss_fn.log_vars":
+            p = model.loss_fn.log_vars
+        else:
+            p = named[k]
+        assert tuple(p.shape) == tuple(go.shape), k
+        if k.startswith("encoder.head.") or k.startswith("encoder.norm."):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert (p.grad.cpu() - go).abs().max().item() <= 2e-4 * go.abs().max().item() + 1e-9, k
+
+
 @pytest.mark.parametrize("ratio", [0.75, 0.3])
 def test_call_time_mask_ratio_decides_len_keep(ratio):
     """fcmae.py:415,451 (quirk q9): the constructor's mask_ratio is only stored; forward(mask_ratio=r) keeps int(L(1-r))."""

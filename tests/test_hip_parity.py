@@ -45,7 +45,7 @@ def _rel(a, b):
 
 
 F32_CASES = ["allmod_atto_56", "s2_atto_56_bs4", "allmod_atto_56_unweighted", "pixmod_atto_56",
-             "allmod_atto_56_zeropix", "allmod_tiny_112", "allmod_atto_56_dec2"]
+             "allmod_atto_56_zeropix", "allmod_tiny_112", "allmod_atto_56_dec2", "allmod_atto_112_dense"]
 
 
 @pytest.mark.parametrize("name", F32_CASES)
@@ -146,7 +146,8 @@ def test_other_size_factories_run_on_the_hip_path(model, img, patch):
         torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("name", ["allmod_atto_56", "allmod_tiny_112", "allmod_atto_56_zeropix", "allmod_atto_56_dec2"])
+@pytest.mark.parametrize("name", ["allmod_atto_56", "allmod_tiny_112", "allmod_atto_56_zeropix", "allmod_atto_56_dec2",
+                                  "allmod_atto_112_dense"])
 def test_bf16_step_within_stated_tolerance(name):
     c = CASES[name]
     cfg = case_cfg(c)
