@@ -16,6 +16,7 @@
 #include "stemtail.cuh"
 #include "gemm_nt3.cuh"
 #include "dwband.cuh"
+#include "dwmfma.cuh"
 #include "ps.cuh"
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
@@ -106,7 +107,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_DW6_T4 */ 320,
     /* MPMAE_OPT_DW6_T2 */ 320,
     /* MPMAE_OPT_DW6_GC */ 1,
-    /* MPMAE_OPT_DW */ 7,
+    /* MPMAE_OPT_DW */ 8,
     /* MPMAE_OPT_DWW_S1_NB */ 0,
     /* MPMAE_OPT_DWW_NB */ 128,
     /* MPMAE_OPT_DWW */ 5,
@@ -654,8 +655,36 @@ static int launch_dw_band(const DwP& a, hipStream_t st) {
   return launch_status();
 }
 
+template <int S, int CCH>
+static int launch_dw_mfma(const DwP& a, hipStream_t st) {
+  using D = DwMfma<S, CCH>;
+  const size_t lds = D::lds(a.g.keep);
+  if (lds > 160 * 1024) return -1;
+  static size_t cur = 0;
+  if (lds > cur) {
+    if (hipFuncSetAttribute((const void*)dwconv7_mfma_kernel<S, CCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();      // (launch_status() only reports LAUNCH errors)
+    cur = lds;
+  }
+  LAUNCH((dwconv7_mfma_kernel<S, CCH>), dim3(a.g.N, a.C / CCH), dim3(D::NT), lds, st, a);
+  return launch_status();
+}
+
+// matrix-core depthwise (dwmfma.cuh): sparse stages with S = 8 / 4 whose sample fits the LDS planes; -1 = not taken
+static int try_dw_mfma(const DwP& a, hipStream_t st) {
+  if (!a.g.inv || !a.g.vis || (a.g.S != 8 && a.g.S != 4) || a.g.keep < 1) return -1;
+  if ((((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.add) & 15) || (a.C & 7)) return -1;
+  if (a.C % 40 == 0) return a.g.S == 8 ? launch_dw_mfma<8, 40>(a, st) : launch_dw_mfma<4, 40>(a, st);
+  if (a.C % 32 == 0) return a.g.S == 8 ? launch_dw_mfma<8, 32>(a, st) : launch_dw_mfma<4, 32>(a, st);
+  return -1;
+}
+
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dt == 1 && dw_variant() >= 8) {
+    const int r = try_dw_mfma(*a, S_(s));
+    if (r >= 0) return r;
+  }
   if (dt == 1 && dw_variant() >= 7 && a->g.grid == 7 && a->g.inv && (((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->add) & 15) == 0) {
     // band kernel (dwband.cuh): (sample, patch row) per workgroup, all channels, whole-line loads. Measured at bs 256: stage 0
     // (S = 8, C = 40) 47 / 60 us forward / data gradient against 60 / 67 us for the per-sample kernels; at stage 1 (S = 4, C = 80)
