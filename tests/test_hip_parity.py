@@ -210,6 +210,8 @@ def test_edge_batches_against_the_oracle(N, dead_sample, ratio):
     (loss, pred, mask, loss_dict, log_vars, weighted), taps, grads = _oracle(cfg, sd, inputs, noise)
     ref = np.array([v.item() for v in loss_dict.values()])
     flat_o = torch.cat([grads[k].reshape(-1) for k in sd])
+    # bf16: the per-modality bound is relative (2e-2) plus 4e-3 absolute - at N = 1 an image-level loss of 0.076 moved by 2.2e-3
+    # when the depthwise taps became bf16 (matrix-core depthwise, like every pointwise weight of the bf16 mode already)
     for dtype, ltol, ttol, cos_min in (("f32", 1e-4, 1e-4, 0.99999), ("bf16", 2e-2, 1e-2, 0.999)):
         eng = _engine(cfg, N, dtype, sd, inputs, noise)
         eng.forward()
@@ -218,7 +220,7 @@ def test_edge_batches_against_the_oracle(N, dead_sample, ratio):
         assert torch.equal(eng.mask.cpu(), mask)
         assert int((eng.mask == 0).sum(1).min()) == int((eng.mask == 0).sum(1).max()) == eng.keep == int(49 * (1 - ratio))
         got = np.array(eng.losses.tolist())
-        assert np.all(np.abs(got - ref) <= ltol * np.abs(ref) + 1e-6), (dtype, got, ref)
+        assert np.all(np.abs(got - ref) <= ltol * np.abs(ref) + (4e-3 if dtype == "bf16" else 1e-6)), (dtype, got, ref)
         assert abs(eng.total.item() - loss.item()) <= ttol * abs(loss.item()), dtype
         flat_e = torch.cat([eng.grads[k].cpu().reshape(-1) for k in sd])
         assert torch.isfinite(flat_e).all()

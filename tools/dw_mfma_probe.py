@@ -59,7 +59,7 @@ def run(e, check):
             x = (torch.randn(M, Cc, device=DEV) * 1.3).to(bf) * live
             add = (torch.randn(M, Cc, device=DEV)).to(bf) * live if a.add else None
             outs = {}
-            for dw in (7, 8):
+            for dw in (7, 8, 9):
                 assert lib.mpmae_set_option(_lib.OPT["DW"], dw) == 0
                 out = torch.full((M, Cc), 7.0, device=DEV, dtype=bf)
                 a.x, a.out, a.add = x.data_ptr(), out.data_ptr(), (add.data_ptr() if add is not None else 0)
@@ -89,7 +89,7 @@ def run(e, check):
                     if add is not None:
                         ref = ref + add.float()
                     ref = ref * live
-                    for dw in (7, 8):
+                    for dw in (7, 8, 9):
                         err = (outs[dw].float() - ref).abs()
                         tol = (2.0 ** -7) * ref.abs() + (2.0 ** -9) * ref.abs().max()
                         print(f"    {name} DW={dw} vs torch ({label}): max err {err.max().item():.4e} (max|ref| {ref.abs().max().item():.3f}), "
