@@ -672,9 +672,8 @@ static int launch_dw_mfma(const DwP& a, hipStream_t st) {
 
 // matrix-core depthwise (dwmfma.cuh): sparse stages with S = 8 / 4 whose sample fits the LDS planes; -1 = not taken
 static int try_dw_mfma(const DwP& a, hipStream_t st) {
-  if (!a.g.inv || !a.g.vis || (a.g.S != 8 && a.g.S != 4) || a.g.keep < 1) return -1;
+  if (!a.g.inv || !a.g.vis || (a.g.S != 8 && a.g.S != 4) || a.g.keep < 1 || a.g.keep > 62 || a.g.grid > 8) return -1;
   if ((((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.add) & 15) || (a.C & 7)) return -1;
-  if (dw_variant() == 9 && a.g.S == 4 && a.C % 16 == 0) return launch_dw_mfma<4, 16>(a, st);     // PROBE
   if (a.C % 40 == 0) return a.g.S == 8 ? launch_dw_mfma<8, 40>(a, st) : launch_dw_mfma<4, 40>(a, st);
   if (a.C % 32 == 0) return a.g.S == 8 ? launch_dw_mfma<8, 32>(a, st) : launch_dw_mfma<4, 32>(a, st);
   return -1;

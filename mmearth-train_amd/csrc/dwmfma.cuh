@@ -58,7 +58,7 @@ template <int S, int CCH> struct DwMfma {
   static constexpr int PSTR_T = S * S * CCH * 2 + 16;         // staging bytes per patch of the tail pass (whole patches, <= 4)
   static constexpr int STG = 16 * PSTR;
   static_assert(4 * PSTR_T <= STG, "tail pass fits the staging tile");
-  static size_t lds(int keep) { return (size_t)CCH * S * (keep + 1) * S * 2 + 16 * NV + STG + 16 + (size_t)CCH * 64 * 2 + (size_t)(keep + 1) * 9 * 4 + 64 * 4 + 32 * 4 + (size_t)(keep + 1) * S * S; }
+  static size_t lds(int keep) { return (size_t)CCH * S * (keep + 1) * S * 2 + 16 * NV + STG + 16 + (size_t)CCH * 64 * 2 + (size_t)(keep + 1) * 9 * 4 + 64 * 4 + 64 * 4 + (size_t)(keep + 1) * S * S; }
 };
 
 // The MFMAs of one pass, channel by channel: the 4-5 fragments of a channel (10 reads, 20 registers), then its 4-8 MFMAs. Measured
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(64 * (CCH / 4)) void dwconv7_mfma_kernel(const DwP 
   bf16_t* wt = reinterpret_cast<bf16_t*>(stg + D::STG + 16);
   int* nbt = reinterpret_cast<int*>(stg + D::STG + 16 + CCH * 64 * 2);
   int* invl = nbt + (keep + 1) * 9;                   // [64] slot of each patch of this sample (L <= 64)
-  int* visl = invl + 64;                              // [32] patch of each slot
-  unsigned char* actl = reinterpret_cast<unsigned char*>(visl + 32);      // [keep * S * S] activity bytes of the sample's rows
+  int* visl = invl + 64;                              // [64] patch of each slot (keep < 64: wave 0 writes and reads both tables)
+  unsigned char* actl = reinterpret_cast<unsigned char*>(visl + 64);      // [keep * S * S] activity bytes of the sample's rows
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n = blockIdx.x, c0 = blockIdx.y * CCH, C = p.C;
   const bf16_t* x = reinterpret_cast<const bf16_t*>(p.x);
