@@ -61,6 +61,7 @@ ENGINE_OPTIONS = dict(
     ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
+    tail_main=1,            # the LAST depthwise weight gradient of the backward (stage 0, block 0) on the main lane behind its data gradient: the weight-gradient lane ends 115 us after the main lane (profiles/r04/lanes_one_step.txt); 2: its pointwise pw1 weight gradient too
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
     rs_maxc=100000,         # largest C on the row-streaming kernels
@@ -1131,6 +1132,12 @@ class Engine:
         a.act = act.data_ptr() if act is not None else 0
         a.ws, a.ws_floats = (self.ws3 if self.lanes else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
+        if self.lanes and int(self.opt["tail_main"]) >= 1 and tag == "encoder.stages.0.0":
+            # in order on the main lane right behind the block's data gradient (its operands are fresh: no event, no scratch-ring guard)
+            a.ws = self.ws.data_ptr()              # main-lane scratch
+            self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
+                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc)
+            return
         if (self.lanes and dt == BF16 and blk["sparse"] and blk["stage"] >= int(self.opt["dw_group"]) and self.cfg.depths[blk["stage"]] > 1):
             if not hasattr(self, "_dwg_pending"):
                 self._dwg_pending = []
