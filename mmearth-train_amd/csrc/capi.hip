@@ -17,6 +17,7 @@
 #include "gemm_nt3.cuh"
 #include "dwband.cuh"
 #include "dwmfma.cuh"
+#include "dwmfma_wg.cuh"
 #include "ps.cuh"
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
@@ -110,7 +111,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_DW */ 8,
     /* MPMAE_OPT_DWW_S1_NB */ 0,
     /* MPMAE_OPT_DWW_NB */ 128,
-    /* MPMAE_OPT_DWW */ 5,
+    /* MPMAE_OPT_DWW */ 7,
     /* MPMAE_OPT_NT_GLDS64 */ 1,
     /* MPMAE_OPT_NT_BK32 */ 1,
     /* MPMAE_OPT_NT_GLDS */ 1,
@@ -744,8 +745,43 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   RET();
 }
 
+template <int CCH>
+static int launch_dwwg_mfma(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr, int count) {
+  using D = DwMfmaWg<CCH>;
+  const size_t lds = D::lds(a.g.keep);
+  if (lds > 160 * 1024) return -1;
+  static size_t cur = 0;
+  if (lds > cur) {
+    if (hipFuncSetAttribute((const void*)dwconv7_wgrad_mfma_kernel<CCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    cur = lds;
+  }
+  LAUNCH((dwconv7_wgrad_mfma_kernel<CCH>), dim3(a.g.N, a.C / CCH, count), dim3(D::NT), lds, st, a, gr);
+  return launch_status();
+}
+
+// matrix-core depthwise weight gradient (dwmfma_wg.cuh): S = 8, one workgroup (= one slab) per sample; -1 = not taken
+static int try_dwwg_mfma(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr, int count, size_t ws_floats) {
+  if (g_opt[MPMAE_OPT_DWW] < 7 || !a.g.inv || !a.g.vis || a.g.S != 8 || a.g.keep < 1 || a.g.keep > 62 || a.g.grid > 8) return -1;
+  if ((((uintptr_t)a.x | (uintptr_t)a.dd) & 15) || (a.C & 7)) return -1;
+  if ((size_t)a.g.N * 50 * a.C * count > ws_floats) return -1;
+  if (a.C % 40 == 0) return launch_dwwg_mfma<40>(a, st, gr, count);
+  if (a.C % 32 == 0) return launch_dwwg_mfma<32>(a, st, gr, count);
+  return -1;
+}
+
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  if (dt == 1 && a->ws) {
+    DwWgGroupP gr;
+    gr.count = 0;
+    const int r = try_dwwg_mfma(*a, S_(s), gr, 1, a->ws_floats);
+    if (r > 0) return r;
+    if (r == 0) {
+      launch_reduce(2, a->ws, a->g.N, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
+      RET();
+    }
+  }
   if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
       (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->dd) & 3) == 0) {
     const size_t per = (size_t)50 * a->C;
@@ -773,7 +809,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     // the packed weight-gradient kernel needs 98 accumulator VGPRs per lane and measured slower than v5
     // (62 vs 45 us at stage 1); it stays available for experiments (MPMAE_DWW=6)
     int wg6;
-    wg6 = g_opt[MPMAE_OPT_DWW] >= 6 ? 1 : 0;
+    wg6 = g_opt[MPMAE_OPT_DWW] == 6 ? 1 : 0;
     if (wg6 && dt == 1 && (a->C & 1) == 0 && (((uintptr_t)a->x | (uintptr_t)a->dd) & 3) == 0) {
       switch (a->g.S) { case 8: ok = launch_dwwg_v6<8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v6<4>(*a, nb, S_(s)); break;
                         default: ok = launch_dwwg_v6<2>(*a, nb, S_(s)); }
@@ -841,7 +877,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
 int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, float* ws, size_t ws_floats, mpmae_stream_t s) {
   if (!probs || count < 1 || !ws) return (int)hipErrorInvalidValue;
   const MpmaeDwWgArgs& a0 = probs[0];
-  bool ok = dt == 1 && count <= DWG_MAX && dw_variant() >= 6 && g_opt[MPMAE_OPT_DWW] < 6 && a0.CC >= 1 && a0.TP * a0.g.S <= 8;
+  bool ok = dt == 1 && count <= DWG_MAX && dw_variant() >= 6 && g_opt[MPMAE_OPT_DWW] != 6 && a0.CC >= 1 && a0.TP * a0.g.S <= 8;
   for (int i = 0; ok && i < count; ++i) {
     const MpmaeDwWgArgs& a = probs[i];
     ok = a.C == a0.C && a.g.N == a0.g.N && a.g.keep == a0.g.keep && a.g.grid == a0.g.grid && a.g.S == a0.g.S && a.g.vis == a0.g.vis &&
@@ -851,6 +887,22 @@ int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, flo
   const bool s1 = ok && a0.g.S == 1 && a0.g.grid == 7 && (a0.C & 15) == 0;
   const bool v5 = ok && !s1 && a0.g.S >= 2 && dw_v4_ok(a0.C, a0.g.S);
   const size_t per = (size_t)50 * a0.C;
+  if (ok && count > 1 && a0.g.S == 8) {           // matrix-core kernel: grid.z = problem, one slab per sample and problem
+    DwWgGroupP gr;
+    ReduceGroupP rg;
+    gr.count = rg.count = count;
+    for (int i = 0; i < count; ++i) {
+      gr.x[i] = probs[i].x; gr.dd[i] = probs[i].dd; gr.ws[i] = ws + (size_t)i * a0.g.N * per;
+      rg.part[i] = gr.ws[i]; rg.out[i] = probs[i].dw; rg.out2[i] = probs[i].db;
+    }
+    const int r = try_dwwg_mfma(a0, S_(s), gr, count, ws_floats);
+    if (r > 0) return r;
+    if (r == 0) {
+      const int W = 50 * a0.C;
+      LAUNCH(reduce_partials_group2_kernel, dim3(cdiv(W, 64), 16, count), dim3(256), 0, S_(s), rg, a0.g.N, W, a0.C, a0.s_kh, a0.s_kw, a0.s_c);
+      RET();
+    }
+  }
   int nb = 0;
   if (s1) {
     const int want = g_opt[MPMAE_OPT_DWW_S1_NB] > 0 ? g_opt[MPMAE_OPT_DWW_S1_NB] : (cdiv(a0.C, 64) <= 5 ? 128 : 64);

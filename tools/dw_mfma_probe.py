@@ -109,3 +109,42 @@ print(f"== correctness (N = {NC})")
 run(make(NC), True)
 print("== timing (N = 256)")
 run(make(256), False)
+
+
+def run_wgrad(e, check):
+    """weight gradient: DWW = 5 (VALU kernels) against DWW = 7 (matrix-core kernel at S = 8), against torch at small N"""
+    ops = {o[0]: o for o in e.bwd_ops}
+    for blk in T._blocks(e):
+        if not blk["sparse"] or e.S[blk["stage"]] < 4:
+            continue
+        tag, M, Cc, S = blk["prefix"], blk["M"], blk["C"], e.S[blk["stage"]]
+        live = e.act[blk["stage"]].bool()[:, None]
+        name, fn, args, _ = ops[tag + ":dw.wgrad"]
+        a = type(args[1]._obj).from_buffer_copy(args[1]._obj)
+        torch.manual_seed(3 * M + Cc)
+        x = torch.randn(M, Cc, device=DEV).to(bf) * live
+        dd = (torch.randn(M, Cc, device=DEV) * 0.2).to(bf) * live
+        ws = torch.empty(32 << 20, device=DEV)
+        res = {}
+        for dww in (5, 7):
+            assert lib.mpmae_set_option(_lib.OPT["DWW"], dww) == 0
+            dw = torch.zeros(49, Cc, device=DEV); db = torch.zeros(Cc, device=DEV)
+            a.x, a.dd, a.dw, a.db, a.ws, a.ws_floats = x.data_ptr(), dd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel()
+            assert lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], st()) == 0
+            torch.cuda.synchronize()
+            res[dww] = (dw.clone(), db.clone())
+            us = t_us(lambda: lib.mpmae_dwconv7_wgrad(1, C.byref(a), args[2], st()))
+            print(f"  {name:38s} S={S} C={Cc:4d} M={M:7d} DWW={dww}: {us:7.1f} us")
+        print(f"    DWW 7 vs 5: dw rel {T._rel(res[7][0], res[5][0]):.2e}  db rel {T._rel(res[7][1], res[5][1]):.2e}")
+        if check:
+            xm = F.pad(T._rows_to_map(e, x, S, True), (3, 3, 3, 3)); dm = T._rows_to_map(e, dd, S, True); Hh = dm.shape[-1]
+            ref = torch.stack([torch.stack([(dm * xm[:, :, kh:kh + Hh, kw:kw + Hh]).sum((0, 2, 3)) for kw in range(7)], 1) for kh in range(7)], 1)
+            for dww in (5, 7):
+                got = res[dww][0].view(7, 7, Cc).permute(2, 1, 0)
+                print(f"    DWW={dww} vs torch: dw rel {T._rel(got, ref):.2e}  db rel {T._rel(res[dww][1], dd.float().sum(0)):.2e}")
+
+
+print(f"== weight gradient: correctness (N = {NC})")
+run_wgrad(make(NC), True)
+print("== weight gradient: timing (N = 256)")
+run_wgrad(make(256), False)
