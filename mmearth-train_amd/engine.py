@@ -602,7 +602,7 @@ class Engine:
         for _, reads, _ in pend:
             self._side_read(key, *reads)
 
-    def _fold_flush(self, lst, stage):
+    def _fold_flush(self, lst, stage, lane=1):
         pend = getattr(self, "_fold_pending", [])
         if not pend:
             return
@@ -615,8 +615,8 @@ class Engine:
             for i_, fd in enumerate(_srcs):
                 _arr[i_] = fd
             return self.lib.mpmae_fold_group(_arr, len(_srcs), stream)
-        k = self._after(lst)
-        self._op(lst, f"{stage}:ln.fold[{len(pend)}]", fold, kind="ln_fold_group", lane=1, wait=(k,) if k else ())
+        k = self._after(lst) if lane else None
+        self._op(lst, f"{stage}:ln.fold[{len(pend)}]", fold, kind="ln_fold_group", lane=lane, wait=(k,) if k else ())
 
     def _write_waits(self, *tensors):
         """Event keys a main-lane op must wait for before overwriting these scratch tensors."""
@@ -1664,7 +1664,8 @@ class Engine:
                 bi -= 1
             self._dwg_flush(b)            # the stage's grouped depthwise / pointwise weight gradients: side lane, behind its data-gradient chain
             self._group_flush(b)
-            self._fold_flush(b, f"encoder.stages.{i}")
+            # (tail_main: the last fold group in order on the main lane - the weight-gradient lane is the later one at the end of the step)
+            self._fold_flush(b, f"encoder.stages.{i}", lane=0 if (i == 0 and self.lanes and int(self.opt["tail_main"]) >= 1) else 1)
             if i > 0:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
