@@ -130,6 +130,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_TN3_BLOCKS */ 256,
     /* MPMAE_OPT_TNG_BLOCKS */ 512,
     /* MPMAE_OPT_NT4 */ 1,
+    /* MPMAE_OPT_FOLD_GROUP */ 0,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -2116,7 +2117,31 @@ int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t s) {
   for (int i = 0; i < count; ++i) {
     const MpmaeFoldDesc& d = descs[i];
     if (!d.part || !d.out || d.P < 1 || d.W < 1 || d.a < 1) return (int)hipErrorInvalidValue;
-    launch_reduce(1, d.part, d.P, d.W, d.out, nullptr, d.a, d.b, d.c, 0, S_(s));
+  }
+  if (!g_opt[MPMAE_OPT_FOLD_GROUP]) {
+    for (int i = 0; i < count; ++i) {
+      const MpmaeFoldDesc& d = descs[i];
+      launch_reduce(1, d.part, d.P, d.W, d.out, nullptr, d.a, d.b, d.c, 0, S_(s));
+    }
+    RET();
+  }
+  // ONE launch per FOLDG_MAX records (blockIdx.z = record) instead of one per record
+  for (int i0 = 0; i0 < count; i0 += FOLDG_MAX) {
+    const int n = count - i0 < FOLDG_MAX ? count - i0 : FOLDG_MAX;
+    FoldGroupP g;
+    g.count = n; g.pad = 0;
+    int wmax = 1, pmax = 1;
+    for (int i = 0; i < n; ++i) {
+      const MpmaeFoldDesc& d = descs[i0 + i];
+      g.part[i] = d.part; g.out[i] = d.out; g.P[i] = d.P; g.W[i] = d.W; g.a[i] = d.a; g.b[i] = d.b; g.c[i] = d.c;
+      if (d.W > wmax) wmax = d.W;
+      if (d.P > pmax) pmax = d.P;
+    }
+    for (int i = n; i < FOLDG_MAX; ++i) { g.part[i] = nullptr; g.out[i] = nullptr; g.P[i] = g.W[i] = 0; g.a[i] = 1; g.b[i] = g.c[i] = 0; }
+    int R = pmax / 16;                 // as launch_reduce: >= 4 rows per thread
+    if (R < 1) R = 1;
+    if (R > 32) R = 32;
+    LAUNCH(reduce_partials_group1_kernel, dim3(cdiv(wmax, 64), R, n), dim3(256), 0, S_(s), g);
   }
   RET();
 }

@@ -24,7 +24,9 @@
 template <int CCH> struct DwMfmaWg {
   static constexpr int NQ = CCH / 4, NT = 64 * NQ, NV = CCH / 8, DPS = 8;
   static size_t lds(int keep) {
-    return (size_t)CCH * 8 * (keep + 1) * 16 + 16 * NV + (size_t)CCH * 8 * DPS * 16 + 16 * NV + (size_t)(keep + 1) * 9 * 4 + 64 * 4 + 64 * 4;       // (>= CCH * 7 * 129 * 4: the accumulator tiles at the end)
+    const size_t planes = (size_t)CCH * 8 * (keep + 1) * 16 + 16 * NV + (size_t)CCH * 8 * DPS * 16 + 16 * NV + (size_t)(keep + 1) * 9 * 4 + 64 * 4 + 64 * 4;
+    const size_t tiles = (size_t)CCH * 7 * 129 * 4;          // the accumulator tiles parked at the end (few visible patches: larger than the planes)
+    return planes > tiles ? planes : tiles;
   }
 };
 

@@ -384,6 +384,43 @@ __global__ __launch_bounds__(256) void reduce_partials_group2_kernel(const Reduc
   else atomicAdd(dst, s);
 }
 
+// Mode-1 second stage for a GROUP of records in one launch (mpmae_fold_group: the deferred LayerNorm gamma / beta gradient folds of a
+// gradient-bucket segment - 20 launches of 5-9 us per step on the weight-gradient lane before): blockIdx.z = record (own P / W / layout,
+// read from the kernarg segment), blockIdx.x = 64-column block (blocks beyond a record's width leave at once), blockIdx.y = row chunk.
+#define FOLDG_MAX 16
+struct FoldGroupP { int count, pad; const float* part[FOLDG_MAX]; float* out[FOLDG_MAX]; int P[FOLDG_MAX], W[FOLDG_MAX], a[FOLDG_MAX], b[FOLDG_MAX], c[FOLDG_MAX]; };
+__global__ __launch_bounds__(256) void reduce_partials_group1_kernel(const FoldGroupP r) {
+  __shared__ float red[4][64];
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(4))) const FoldGroupP* kgrp_p;
+  const kgrp_p g = (kgrp_p)__builtin_amdgcn_kernarg_segment_ptr();
+  const float* part = g->part[blockIdx.z];
+  float* out = g->out[blockIdx.z];
+  const int P = g->P[blockIdx.z], W = g->W[blockIdx.z], a = g->a[blockIdx.z], b = g->b[blockIdx.z], c = g->c[blockIdx.z];
+#else
+  const float* part = r.part[0]; float* out = r.out[0];
+  const int P = r.P[0], W = r.W[0], a = r.a[0], b = r.b[0], c = r.c[0];
+#endif
+  if ((int)blockIdx.x * 64 >= W) return;
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  const int chunk = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+  float s = 0.f;
+  if (e < W) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || e >= W) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  const int n = e / a, k = e - n * a;
+  float* dst = out + (size_t)n * b + (size_t)k * c;
+  if (gridDim.y == 1) *dst += s;
+  else atomicAdd(dst, s);
+}
+
 // ---------------------------------------------------------------------------------
 // Aligned random crop of the input stage (kornia RandomCrop in FCMAE.forward, models/fcmae.py:419-434): every pixel-wise
 // modality of sample n is cut at the SAME window (ty[n], tx[n]) - fp32 bands and int64 class maps alike (the reference

@@ -61,7 +61,7 @@ ENGINE_OPTIONS = dict(
     ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
-    tail_main=1,            # the LAST depthwise weight gradient of the backward (stage 0, block 0) on the main lane behind its data gradient: the weight-gradient lane ends 115 us after the main lane (profiles/r04/lanes_one_step.txt); 2: its pointwise pw1 weight gradient too
+    tail_main=1,            # the LAST depthwise weight gradient of the backward (stage 0, block 0) on the main lane behind its data gradient: the weight-gradient lane ends 115 us after the main lane (profiles/r04/lanes_one_step.txt); 2: its pointwise pw1 weight gradient too (measured slower: 4.11 vs 4.07 ms same box)
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
     rs_maxc=100000,         # largest C on the row-streaming kernels
@@ -1099,7 +1099,10 @@ class Engine:
         if grouped:
             self._group_add(lst, tag + ":pw1.wgrad", [dz], **w1_args)
         elif not late_all:
-            self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
+            if self.lanes and int(self.opt["tail_main"]) >= 2 and tag == "encoder.stages.0.0":
+                self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", **w1_args)      # (tail_main = 2: in order on the main lane)
+            else:
+                self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         if rs_n is None:
             self._op(lst, tag + ":ln.bwd", self._ln_bwd_callable(Cc), dt, _p(dxn), 1, 1.0, _p(blk["dhat"]), _p(blk["rstd"]),
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
