@@ -673,6 +673,9 @@ static int launch_dw_mfma(const DwP& a, hipStream_t st) {
 }
 
 // matrix-core depthwise (dwmfma.cuh): sparse stages with S = 8 / 4 whose sample fits the LDS planes; -1 = not taken
+// (S = 2 was tried as a dense-map product - zero-padded 14 x 14 planar map per sample and channel, 7 MFMAs per channel with the 1-D
+// Toeplitz fragment of a tap row: correct, and 28 vs 14.7 us at atto stage 2, 51 vs 31 us at tiny: a sample is 28 MFMAs per wave
+// behind the same fixed costs - loads, two barriers, 224 two-byte tap reads per lane - as a stage-0 sample; profiles/r04/dw_mfma_probes.txt)
 static int try_dw_mfma(const DwP& a, hipStream_t st) {
   if (!a.g.inv || !a.g.vis || (a.g.S != 8 && a.g.S != 4) || a.g.keep < 1 || a.g.keep > 62 || a.g.grid > 8) return -1;
   if ((((uintptr_t)a.x | (uintptr_t)a.out | (uintptr_t)a.add) & 15) || (a.C & 7)) return -1;
