@@ -282,6 +282,7 @@ typedef struct MpmaeStemFrontArgs {
   void* col; int ldc;       /* optional (NULL): also write the bf16 im2col matrix [N*keep*64][ldc] (ldc % 8 == 0, ldc >= 9 Cin, the layout
                                of mpmae_im2col3) that the stem's weight gradient reads - from the kernel's own MFMA operand fragments */
   int N, keep, grid, H, Cin, C0, track_activity;
+  uint8_t* act_out;         /* optional (NULL): the pixel-activity byte of every row [N*keep*64] (what mpmae_activity writes), from the window's centre tap */
 } MpmaeStemFrontArgs;
 int mpmae_stem_front(const MpmaeStemFrontArgs* args, mpmae_stream_t stream);
 

@@ -163,7 +163,7 @@ class StemFrontArgs(C.Structure):
                 ("g1", c_void_p), ("b1", c_void_p), ("w", c_void_p), ("wb", c_void_p), ("g2", c_void_p), ("b2", c_void_p),
                 ("col", c_void_p), ("ldc", c_int),
                 ("N", c_int), ("keep", c_int), ("grid", c_int), ("H", c_int), ("Cin", c_int), ("C0", c_int),
-                ("track_activity", c_int)]
+                ("track_activity", c_int), ("act_out", c_void_p)]
 
 
 OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP".split())}      # enum MpmaeOption (include/mpmae_hip.h)

@@ -1837,6 +1837,7 @@ int mpmae_stem_front(const MpmaeStemFrontArgs* a, mpmae_stream_t s) {
   p.col = reinterpret_cast<bf16_t*>(a->col); p.ldc = a->ldc;
   p.keep = a->keep; p.grid = a->grid; p.H = a->H; p.Cin = a->Cin; p.C0 = a->C0; p.track = a->track_activity;
   p.npatch = a->N * a->keep;
+  p.act_out = a->act_out;
   static int per_cu[2] = {0, 0};                                   // resident workgroups per CU of the two instantiations (asked once)
   const int which = a->Cin == 12 ? 1 : 0;
   if (!per_cu[which]) {

@@ -216,6 +216,7 @@ struct StemFrontP {
   const float* g1; const float* b1; const float* w; const float* wb; const float* g2; const float* b2;
   bf16_t* col; int ldc;     // optional: the im2col matrix [rows][ldc] of the weight gradient, written from the A fragments
   int keep, grid, H, Cin, C0, track, npatch;
+  uint8_t* act_out;         // optional: the activity byte of every row
 };
 
 template <int CIN>
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void stem_front_kernel(const StemFrontP p) {
   #pragma unroll
     for (int j = 0; j < 12; ++j) { const float d = cok[j] ? a2[j] - mean2 : 0.f; q2 += d * d; }
     const float rstd2 = rsqrtf(row_sum(q2) * invC + 1e-6f);
-    if (lg == 0) { p.rstd1[m] = live ? rstd : 0.f; p.rstd2[m] = live ? rstd2 : 0.f; }
+    if (lg == 0) { p.rstd1[m] = live ? rstd : 0.f; p.rstd2[m] = live ? rstd2 : 0.f; if (p.act_out) p.act_out[m] = live ? 1 : 0; }
     bf16_t* o1 = reinterpret_cast<bf16_t*>(p.xhat1) + (size_t)m * C0;
     bf16_t* o2 = reinterpret_cast<bf16_t*>(p.xhat2) + (size_t)m * C0;
     bf16_t* oy = reinterpret_cast<bf16_t*>(p.out) + (size_t)m * C0;

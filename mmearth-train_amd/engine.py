@@ -61,6 +61,7 @@ ENGINE_OPTIONS = dict(
     ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
+    act_in_stem=1,          # the fused stem kernel writes the pixel-activity bytes itself (it computes them anyway): no activity launch, the first stage-0 op waits for nothing on the side lane, the poolings run behind the stem
     tail_main=1,            # the LAST depthwise weight gradient of the backward (stage 0, block 0) on the main lane behind its data gradient: the weight-gradient lane ends 115 us after the main lane (profiles/r04/lanes_one_step.txt); 2: its pointwise pw1 weight gradient too (measured slower: 4.11 vs 4.07 ms same box)
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
@@ -1220,7 +1221,9 @@ class Engine:
             self._op(f, "mask", lib.mpmae_mask_gen, _p(self.noise), N, L, self.keep, _p(self.mask), _p(self.vis), _p(self.inv),
                      **(dict(signal="mask_done") if front_side else {}))
         img = self.inp["sentinel2"]
-        if self.track_activity:
+        # act_in_stem: the fused stem kernel (below) writes act_full; the poolings are issued behind it
+        self._act_in_stem = (front_side and prep_late and bool(self.opt["act_in_stem"]) and self.track_activity and k == 1)
+        if self.track_activity and not self._act_in_stem:
             fl = dict(lane=1) if front_side else {}
             self._op(f, "act0", lib.mpmae_activity, _p(img), _p(self.vis), _p(self.act_full), N, cfg.in_chans,
                      cfg.img_size, self.keep, self.grid, p, **(dict(lane=1, wait=("mask_done",)) if front_side else {}))
@@ -1269,13 +1272,21 @@ class Engine:
             a.N, a.keep, a.grid, a.H, a.Cin, a.C0 = N, self.keep, self.grid, cfg.img_size, cfg.in_chans, C0
             a.track_activity = 1 if self.track_activity else 0
             a.col, a.ldc = self.col.data_ptr(), self.ldk          # the weight gradient's im2col matrix, from the kernel's own A fragments
+            a.act_out = self.act_full.data_ptr() if getattr(self, "_act_in_stem", False) else 0
             self._keepalive.append(a)
             self._op(f, "stem:conv+ln+gelu+dw+ln", lib.mpmae_stem_front, C.byref(a), kind="stem_front",
                      nbytes=3 * self.Mfull * C0 * 2 + self.Mfull * self.ldk * 2 + N * self.keep * 100 * cfg.in_chans * 4,
                      flops=2 * self.Mfull * C0 * 9 * cfg.in_chans)
+        if getattr(self, "_act_in_stem", False):
+            assert self.stem_front
+            f[-1][3]["signal"] = "stem_front_done"
+            for i in range(1, 4):
+                self._op(f, f"actpool{i}", lib.mpmae_activity_pool, _p(self.act[i - 1]), _p(self.act[i]), self.M[i], self.S[i], 2, lane=1,
+                         wait=("stem_front_done",) if i == 1 else ())
+            f[-1][3]["signal"] = "front_done"
         if prep_side:
             if self.stem_front:       # the fused stem kernel reads the fp32 parameter itself; whatever follows it waits for the side-lane front
-                stem_at, rest_key = len(f) - 1, ("front_done" if front_side else "prep_done")
+                stem_at, rest_key = len(f) - 1 - (3 if getattr(self, "_act_in_stem", False) else 0), ("front_done" if front_side else "prep_done")
             else:
                 f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + (("front_done",) if front_side else ("prep_done",))
         if self.stem_front:
@@ -1493,7 +1504,11 @@ class Engine:
         if self._front_rest is not None:          # the first main-lane op behind the fused stem kernel waits for the rest of the side-lane front
             at, key = self._front_rest
             mains = [op for op in f[at + 1:] if op[3]["lane"] == 0]
-            mains[0][3]["wait"] = tuple(mains[0][3]["wait"]) + (key,)
+            if getattr(self, "_act_in_stem", False):      # act[0] came from the stem kernel (same lane); the poolings are first read at stage 1
+                firsts = [op for op in mains if op[0].startswith("encoder.downsample_layers.0")]
+                firsts[0][3]["wait"] = tuple(firsts[0][3]["wait"]) + (key,)
+            else:
+                mains[0][3]["wait"] = tuple(mains[0][3]["wait"]) + (key,)
             if self._prep_late:           # the depthwise kernel reads fp32 taps; the first STAGED weight belongs to the op behind it
                 assert mains[0][0].endswith(":dw"), mains[0][0]
                 mains[1][3]["wait"] = tuple(mains[1][3]["wait"]) + ("prep_done",)
