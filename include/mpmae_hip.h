@@ -369,7 +369,7 @@ enum MpmaeOption {
   MPMAE_OPT_DW,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 7 elsewhere; 7 = band kernel at S = 8 (dwband.cuh) + 6 elsewhere; 6 = packed per-sample kernels; 3..5 = earlier generations (fp32 mode, odd shapes) */
   MPMAE_OPT_DWW_S1_NB,   /* default 0: persistent workgroups of the S = 1 depthwise weight gradient (0 = one per sample) */
   MPMAE_OPT_DWW_NB,   /* default 128: persistent workgroups of the depthwise weight gradient */
-  MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernel at S = 8 (dwmfma_wg.cuh) + 5 elsewhere; 6 = packed kernel for S >= 2; 5 = per-sample LDS-map kernels */
+  MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 6 = packed kernel for S >= 2; 5 = per-sample LDS-map kernels */
   MPMAE_OPT_NT_GLDS64,   /* default 1: direct-to-LDS NT GEMM also for 64-wide N tiles */
   MPMAE_OPT_NT_BK32,   /* default 1: 32-deep K slabs for K <= 512 */
   MPMAE_OPT_NT_GLDS,   /* default 1: direct-to-LDS operand slabs in the NT GEMM (2 = always 32-deep) */

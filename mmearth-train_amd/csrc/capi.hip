@@ -764,11 +764,31 @@ static int launch_dwwg_mfma(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr
   return launch_status();
 }
 
-// matrix-core depthwise weight gradient (dwmfma_wg.cuh): S = 8, one workgroup (= one slab) per sample; -1 = not taken
+template <int CCH>
+static int launch_dwwg_mfma4(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr, int count) {
+  using D = DwMfmaWg4<CCH>;
+  const size_t lds = D::lds(a.g.keep);
+  if (lds > 160 * 1024) return -1;
+  static size_t cur = 0;
+  if (lds > cur) {
+    if (hipFuncSetAttribute((const void*)dwconv7_wgrad_mfma4_kernel<CCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return (int)hipGetLastError();
+    cur = lds;
+  }
+  LAUNCH((dwconv7_wgrad_mfma4_kernel<CCH>), dim3(a.g.N, a.C / CCH, count), dim3(D::NT), lds, st, a, gr);
+  return launch_status();
+}
+
+// matrix-core depthwise weight gradient (dwmfma_wg.cuh): S = 8 / 4, one workgroup (= one slab) per sample; -1 = not taken
 static int try_dwwg_mfma(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr, int count, size_t ws_floats) {
-  if (g_opt[MPMAE_OPT_DWW] < 7 || !a.g.inv || !a.g.vis || a.g.S != 8 || a.g.keep < 1 || a.g.keep > 62 || a.g.grid > 8) return -1;
+  if (g_opt[MPMAE_OPT_DWW] < 7 || !a.g.inv || !a.g.vis || (a.g.S != 8 && a.g.S != 4) || a.g.keep < 1 || a.g.keep > 62 || a.g.grid > 8) return -1;
   if ((((uintptr_t)a.x | (uintptr_t)a.dd) & 15) || (a.C & 7)) return -1;
   if ((size_t)a.g.N * 50 * a.C * count > ws_floats) return -1;
+  if (a.g.S == 4) {
+    if (a.C % 40 == 0) return launch_dwwg_mfma4<40>(a, st, gr, count);
+    if (a.C % 32 == 0) return launch_dwwg_mfma4<32>(a, st, gr, count);
+    return -1;
+  }
   if (a.C % 40 == 0) return launch_dwwg_mfma<40>(a, st, gr, count);
   if (a.C % 32 == 0) return launch_dwwg_mfma<32>(a, st, gr, count);
   return -1;
@@ -891,7 +911,7 @@ int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, flo
   const bool s1 = ok && a0.g.S == 1 && a0.g.grid == 7 && (a0.C & 15) == 0;
   const bool v5 = ok && !s1 && a0.g.S >= 2 && dw_v4_ok(a0.C, a0.g.S);
   const size_t per = (size_t)50 * a0.C;
-  if (ok && count > 1 && a0.g.S == 8) {           // matrix-core kernel: grid.z = problem, one slab per sample and problem
+  if (ok && count > 1 && (a0.g.S == 8 || a0.g.S == 4)) {           // matrix-core kernel: grid.z = problem, one slab per sample and problem
     DwWgGroupP gr;
     ReduceGroupP rg;
     gr.count = rg.count = count;
