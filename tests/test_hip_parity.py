@@ -269,6 +269,41 @@ def test_full_batch_256_against_the_oracle(dtype):
             assert cs >= 0.99, (k, cs)
 
 
+def test_tiny_112_16_at_n16_against_the_oracle():
+    """BASELINE configs[3]'s geometry (all_mod tiny 112/16: S = 8 at C = 96, S = 4 at C = 192 - the matrix-core depthwise kernels on 32-channel
+    chunks - nine blocks at stage 2, C = 768 at stage 3) at N = 16 against oracle.mpmae_ref itself (the bs-256 test of this
+    config compares the bf16 engine with this library's own f32 engine). The stated bf16 bounds: masks bit-exact, per-modality loss 2e-2,
+    total 1e-2, encoder map 2e-2 and predictions 3e-2 of their maxima, flat gradient cosine >= 0.999, every tensor >= 0.99."""
+    from mmearth_train_amd.config import make_cfg
+    from mmearth_train_amd.synth import make_inputs, make_state_dict
+    cfg = make_cfg("convnextv2_tiny", 112, 16)
+    N = 16
+    sd = make_state_dict(cfg, seed=13)
+    inputs, noise = make_inputs(cfg, N, seed=14)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    (loss, pred, mask, loss_dict, _, weighted), taps, grads = _oracle(cfg, sd, inputs, noise)
+    eng = _engine(cfg, N, "bf16", sd, inputs, noise)
+    eng.forward(); eng.backward(); torch.cuda.synchronize()
+    assert torch.equal(eng.mask.cpu(), mask)
+    ref = np.array([v.item() for v in loss_dict.values()])
+    got = np.array(eng.losses.tolist())
+    assert np.all(np.abs(got - ref) <= 2e-2 * np.abs(ref) + 4e-3), (got, ref)
+    assert abs(eng.total.item() - loss.item()) <= 1e-2 * abs(loss.item())
+    enc = eng.dense_map(eng.enc_out, cfg.dims[3], 3)
+    assert _rel(enc, taps["enc_out"]) < 2e-2, _rel(enc, taps["enc_out"])
+    pr = eng.preds()
+    for om in cfg.out_mods:
+        assert _rel(pr[om.name].float(), pred[om.name]) < 3e-2, (om.name, _rel(pr[om.name].float(), pred[om.name]))
+    flat_e = torch.cat([eng.grads[k].cpu().reshape(-1) for k in sd])
+    flat_o = torch.cat([grads[k].reshape(-1) for k in sd])
+    assert torch.nn.functional.cosine_similarity(flat_e.double(), flat_o.double(), dim=0).item() >= 0.999
+    for k in sd:
+        go = grads[k]
+        if go.numel() >= 8 and go.norm() > 0:
+            cs = torch.nn.functional.cosine_similarity(eng.grads[k].cpu().reshape(-1), go.reshape(-1), dim=0).item()
+            assert cs >= 0.99, (k, cs)
+
+
 @pytest.mark.parametrize("model,img,patch,subset,dtype", [("convnextv2_tiny", 112, 16, "all_mod", "bf16"),
                                                           ("convnextv2_atto", 56, 8, "pix_mod", "fp8")])
 def test_configs_4_and_5_at_full_batch_256(model, img, patch, subset, dtype):
