@@ -131,6 +131,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_TNG_BLOCKS */ 512,
     /* MPMAE_OPT_NT4 */ 1,
     /* MPMAE_OPT_FOLD_GROUP */ 0,
+    /* MPMAE_OPT_RSC_W5 */ 1,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -1584,6 +1585,7 @@ static int launch_rs(int which, const MpmaeRsArgs& a, hipStream_t st) {
 
 // chunked variants (rsc.cuh): weights streamed through LDS, any M
 
+static int ps_num_cus();
 template <int KC, int RT, int NC, int KCH, int RTN = RT, int PFN = 0>
 static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   RsP p;
@@ -1629,7 +1631,10 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     }
   } else if (which == 4 || which == 5) {
     const int rpg = a.rpg > 0 ? a.rpg : a.M;
-    const int rowblocks = cdiv(a.M, 64 * RTN);
+    // 80-row tiles (5 waves) where 64-row tiles are more than one round of workgroups and 80-row tiles are not (C = 160 at bs 256:
+    // 304 -> 244 workgroups on 256 CUs): the per-workgroup time is the weight stream, not the rows
+    const bool w5 = KC == 160 && g_opt[MPMAE_OPT_RSC_W5] && cdiv(a.M, 64 * RTN) > ps_num_cus() && cdiv(a.M, 80 * RTN) <= ps_num_cus();
+    const int rowblocks = cdiv(a.M, (w5 ? 80 : 64) * RTN);
     constexpr int NP = ((KC + 15) / 16) * 16;
     const int pf_on = g_opt[MPMAE_OPT_RSC_PF];
     const bool pf = PFN && pf_on && rpg >= a.M;       // LDS-staged GRN vectors (+ early issue): single GRN group only
@@ -1647,10 +1652,13 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       if (((uintptr_t)a.fin_sum | (uintptr_t)a.fin_gamma) & 15) return (int)hipErrorInvalidValue;
     }
     if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
-#define RSC_NARROW(MODE_, PF_) do { \
+#define RSC_NARROW_W(MODE_, PF_, NWV_) do { \
       static size_t cur = 64 * 1024; \
-      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
-      LAUNCH((rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_>), dim3(rowblocks), dim3(256), lds, st, p, HN, rpg); } while (0)
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+      LAUNCH((rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>), dim3(rowblocks), dim3(64 * NWV_), lds, st, p, HN, rpg); } while (0)
+#define RSC_NARROW(MODE_, PF_) do { \
+      if constexpr (KC == 160) { if (w5) RSC_NARROW_W(MODE_, PF_, 5); else RSC_NARROW_W(MODE_, PF_, 4); } \
+      else RSC_NARROW_W(MODE_, PF_, 4); } while (0)
     if (which == 4) { if (dzr) RSC_NARROW(0, (PFN & 4) ? (PFN & 6) : 0); else if (pf) RSC_NARROW(0, (PFN & 3)); else RSC_NARROW(0, 0); }
     else {
       if (dzr) RSC_NARROW(1, (PFN & 4) ? (PFN & 6) : 0);
@@ -1663,6 +1671,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       else launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
     }
 #undef RSC_NARROW
+#undef RSC_NARROW_W
   } else {
     return (int)hipErrorInvalidValue;
   }

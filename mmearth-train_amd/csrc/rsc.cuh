@@ -256,12 +256,15 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 // transposed MFMA leaves 8 consecutive dz columns of row lr in exactly the lane that needs them as the next MFMA's
 // operand, so pw2.dgrad (which = 1) only has to produce the GRN statistics and never stores dz: -105 MB written and
 // -79 MB read per stage-0 block on kernels that run at the HBM roofline.
-template <int KC, int MODE, int RT, int KCH, int PF = 0>
-__global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
+// NWV: waves per workgroup (4; 5 = 80-row tiles: at M = 19 456 rows 64-row tiles are 304 workgroups on 256 CUs - two rounds of a kernel whose
+// per-workgroup time is the weight stream, not the rows - 80-row tiles are 244)
+template <int KC, int MODE, int RT, int KCH, int PF = 0, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void rsc_narrow_kernel(const RsP p, int HN_rt, int rpg) {
+  constexpr int NTH = 64 * NWV;
   using T = bf16_t;
   constexpr int HN = 4 * KC;                    // the ConvNeXt hidden width; a compile-time row pitch keeps address math out of VGPRs
   (void)HN_rt;
-  constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + RSC_PAD, VPR = KCH / 8, WV = (NP * VPR + 255) / 256;
+  constexpr int NT = (KC + 15) / 16, NP = NT * 16, KSC = KCH / 32, LDW = KCH + RSC_PAD, VPR = KCH / 8, WV = (NP * VPR + NTH - 1) / NTH;
   constexpr bool PAD = NP != KC;                 // output columns padded to whole 16-wide tiles (C = 40)
   static_assert(KC % 8 == 0 && KCH % 32 == 0 && ((KCH / 8) & 1) == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
@@ -270,20 +273,20 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   float* vec = red + 2 * KC;                                                           // [2][HN] (PF): scale | beta or coef
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
-  const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
+  const int rbase = blockIdx.x * (16 * NWV * RT) + wave * (16 * RT);
   constexpr int nkc = HN / KCH;
   // RC: the wide operand of this kernel is recomputed instead of read: MODE 1 dz = dout W2, MODE 0 h = xn W1^T + b1
   constexpr bool STG = (PF & 2) != 0, EARLY = (PF & 1) != 0, RC = (PF & 4) != 0, DZR = RC && MODE == 1, HR = RC && MODE == 0;
   static_assert(!RC || (STG && !EARLY), "operand recomputation: staged vectors, no early issue");
-  constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8, WV2 = (KCH * VPR2 + 255) / 256;
+  constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8, WV2 = (KCH * VPR2 + NTH - 1) / NTH;
   bf16_t* W2c = reinterpret_cast<bf16_t*>(vec + 2 * HN + 8);                          // [2][KCH][LDW2] (DZR): W2^T rows of the chunk
-  if (MODE == 1) for (int i = tid; i < 2 * KC; i += 256) red[i] = 0.f;
+  if (MODE == 1) for (int i = tid; i < 2 * KC; i += NTH) red[i] = 0.f;
 
   uint4 wr2[RC ? WV2 : 1];
   auto wload2 = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < WV2; ++i) {
-      const int v = tid + 256 * i, n = v / VPR2, k = (v - n * VPR2) * 8;
+      const int v = tid + NTH * i, n = v / VPR2, k = (v - n * VPR2) * 8;
       wr2[i] = (v < KCH * VPR2 && k < KC) ? *reinterpret_cast<const uint4*>(p.W2 + (size_t)(kc * KCH + n) * p.ldw2 + k)
                                           : make_uint4(0u, 0u, 0u, 0u);
     }
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   auto wstore2 = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WV2; ++i) {
-      const int v = tid + 256 * i, n = v / VPR2, k = (v - n * VPR2) * 8;
+      const int v = tid + NTH * i, n = v / VPR2, k = (v - n * VPR2) * 8;
       if (v < KCH * VPR2) *reinterpret_cast<uint4*>(W2c + (size_t)buf * KCH * LDW2 + n * LDW2 + k) = wr2[i];
     }
   };
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   auto wload = [&](int kc) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      const int v = tid + NTH * i, n = v / VPR, k = (v - n * VPR) * 8;
       const int vc = min(v, NP * VPR - 1), nc = min(vc / VPR, KC - 1), kq = (vc - (vc / VPR) * VPR) * 8;
       wr[i] = and4(*reinterpret_cast<const uint4*>(p.W + (size_t)nc * p.ldw + kc * KCH + kq), v < NP * VPR && (!PAD || n < KC));
     }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   auto wstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < WV; ++i) {
-      const int v = tid + 256 * i, n = v / VPR, k = (v - n * VPR) * 8;
+      const int v = tid + NTH * i, n = v / VPR, k = (v - n * VPR) * 8;
       if (v < NP * VPR) *reinterpret_cast<uint4*>(Wc + (size_t)buf * NP * LDW + n * LDW + k) = wr[i];
     }
   };
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   if (STG) {
     float* fsh = vec + 2 * HN;                      // [4] block-reduction scratch
     if (!p.fin_sum) {
-      for (int i = tid; i < HN / 4; i += 256) {
+      for (int i = tid; i < HN / 4; i += NTH) {
         reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(p.v0)[i];
         reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
       }
@@ -450,25 +453,25 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
       // every vector element this thread owns is requested up front (NJ = ceil(H / 256) is a compile-time count, addresses clamped):
       // as `for (j = tid; j < H; j += 256)` loops with the loads inside, the finalisation was five serial round trips - each behind
       // an s_waitcnt vmcnt(0) that also drained the operand loads already in flight - before the first MFMA of every workgroup
-      constexpr int NJ = (HN + 255) / 256;
+      constexpr int NJ = (HN + NTH - 1) / NTH;
       float fs[NJ], fg[NJ], fb[NJ];
 #pragma unroll
       for (int u = 0; u < NJ; ++u) {
-        const int jc = min(tid + 256 * u, HN - 1);
+        const int jc = min(tid + NTH * u, HN - 1);
         fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fb[u] = p.v1[jc];
       }
       float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < NJ; ++u) { fs[u] = sqrtf(fs[u]); s += (tid + 256 * u < HN) ? fs[u] : 0.f; }
+      for (int u = 0; u < NJ; ++u) { fs[u] = sqrtf(fs[u]); s += (tid + NTH * u < HN) ? fs[u] : 0.f; }
       s = wave_sum(s);
       if (lane == 0) fsh[wave] = s;
       __syncthreads();
-      const float ainv = 1.f / ((fsh[0] + fsh[1] + fsh[2] + fsh[3]) / HN + p.fin_eps);
+      const float ainv = 1.f / ((fsh[0] + fsh[1] + fsh[2] + fsh[3] + (NWV > 4 ? fsh[4] : 0.f)) / HN + p.fin_eps);
       const bool pub = blockIdx.x == 0;
       if (pub && tid == 0) p.fin_ainv[0] = ainv;
 #pragma unroll
       for (int u = 0; u < NJ; ++u) {
-        const int j = tid + 256 * u;
+        const int j = tid + NTH * u;
         if (j < HN) {
           const float gx = fs[u], sc = 1.f + fg[u] * (gx * ainv);
           vec[j] = sc;
@@ -477,26 +480,26 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
         }
       }
     } else {                                        // grn_bwd_finalize_kernel
-      constexpr int NJ = (HN + 255) / 256;
+      constexpr int NJ = (HN + NTH - 1) / NTH;
       float fs[NJ], fg[NJ], fx[NJ], f0[NJ], fv[NJ];
       const float* s0p = p.fin_sum0 ? p.fin_sum0 : p.fin_sum;
 #pragma unroll
       for (int u = 0; u < NJ; ++u) {
-        const int jc = min(tid + 256 * u, HN - 1);
+        const int jc = min(tid + NTH * u, HN - 1);
         fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fx[u] = p.fin_gx[jc]; f0[u] = s0p[jc]; fv[u] = p.v0[jc];
       }
       const float ainv = p.fin_ainv[0];
       float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < NJ; ++u) s += (tid + 256 * u < HN) ? fg[u] * fs[u] * fx[u] : 0.f;
+      for (int u = 0; u < NJ; ++u) s += (tid + NTH * u < HN) ? fg[u] * fs[u] * fx[u] : 0.f;
       s = wave_sum(s);
       if (lane == 0) fsh[wave] = s;
       __syncthreads();
-      const float T2 = (fsh[0] + fsh[1] + fsh[2] + fsh[3]) * ainv * ainv / HN;
+      const float T2 = (fsh[0] + fsh[1] + fsh[2] + fsh[3] + (NWV > 4 ? fsh[4] : 0.f)) * ainv * ainv / HN;
       const bool pub = blockIdx.x == 0;
 #pragma unroll
       for (int u = 0; u < NJ; ++u) {
-        const int j = tid + 256 * u;
+        const int j = tid + NTH * u;
         if (j < HN) {
           const float gx = fx[u], s1 = fs[u];
           const float dGx = fg[u] * s1 * ainv - T2;
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256) void rsc_narrow_kernel(const RsP p, int HN_rt,
   }
   if (MODE == 1) {
     __syncthreads();
-    for (int i = tid; i < KC; i += 256) {
+    for (int i = tid; i < KC; i += NTH) {
       p.ws[((size_t)blockIdx.x * 2 + 0) * KC + i] = red[i];
       p.ws[((size_t)blockIdx.x * 2 + 1) * KC + i] = red[KC + i];
     }
