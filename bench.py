@@ -295,6 +295,8 @@ def main():
         mdist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # HIP events on the launch stream
+    if world > 1:
+        trainer.measure_comm_tail = True        # two more events per step on the main stream (exposed_comm_tail_ms in the line)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
@@ -305,6 +307,8 @@ def main():
         mdist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    comm_tail_pre = trainer.comm_tail_ms() if world > 1 else None
+    trainer.measure_comm_tail = False
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     median_ms = step_ms[len(step_ms) // 2]
     # the same step with the input stage inside the timed region: a fresh resident batch copied into the engine's
@@ -322,6 +326,7 @@ def main():
         trainer.step()
     torch.cuda.synchronize()
     ms_with_inputs = (time.perf_counter() - t1) / n_in * 1e3
+    comm_tail = comm_tail_pre
     per_rank = [elapsed]
     if world > 1:          # every rank's own wall time of the timed region (the line's value uses the slowest)
         import torch.distributed as tdist
@@ -436,6 +441,8 @@ def main():
             out["piece_times"] = pieces
         if world > 1:
             out["per_rank_ms_per_step"] = [round(t / a.steps * 1e3, 4) for t in per_rank]
+            if comm_tail is not None:      # main stream idle between the last backward kernel and the last bucket's all-reduce (rank 0)
+                out["exposed_comm_tail_ms"] = round(comm_tail, 4)
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_all(a, cfg)
         print(json.dumps(out), flush=True)

@@ -185,6 +185,8 @@ class StepRunner:
         self.buckets = plan_buckets(engine.offsets, engine.n_params) if self.exchange else []
         self.segments = split_bwd_segments(engine.bwd_ops) if self.exchange else [engine.bwd_ops]
         self.comm_stream = None             # created behind the program (below): it must not share a hardware queue with a lane
+        self.measure_comm_tail = False      # bench / probes: record (backward end, collectives done) event pairs on the main stream
+        self.comm_tail_events = []
         self.loss_buf = torch.zeros(1, dtype=torch.float32, device=engine.device)
         # fold_loss: the scalar loss is element n_params of the flat gradient buffer (engine.gflat_ext) and is all-reduced WITH the first
         # bucket (the heads end the buffer; the loss exists before any gradient does) - one collective fewer at the tail of the step
@@ -372,8 +374,15 @@ class StepRunner:
             if not self.fold_loss:
                 self.loss_buf.copy_(eng.total)
                 works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
+            tail = self.measure_comm_tail and eng.device.type == "cuda"
+            if tail:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(torch.cuda.current_stream())
             for w in works:
                 w.wait()                     # current stream waits for the collectives
+            if tail:
+                e1.record(torch.cuda.current_stream())
+                self.comm_tail_events.append((e0, e1))
         if self.graphs:
             self.graphs[-1].replay()
             eng.note_optimizer_launch()
@@ -421,8 +430,15 @@ class StepRunner:
         if not self.fold_loss:
             self.loss_buf.copy_(eng.total)
             works.append(dist.all_reduce(self.loss_buf, op=dist.ReduceOp.SUM, async_op=True))
+        tail = getattr(self, "measure_comm_tail", False) and eng.device.type == "cuda"
+        if tail:            # exposed communication = how long the main stream sits between the end of the backward and the last collective
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         for w in works:
             w.wait()
+        if tail:
+            e1.record(torch.cuda.current_stream())
+            self.comm_tail_events.append((e0, e1))
         eng.run_program(self.prog, self._span(OPT, OPT))
         eng.note_optimizer_launch()
 
@@ -441,6 +457,16 @@ class StepRunner:
         eng.vflat.copy_(sd["exp_avg_sq"])
         self.t = int(sd["step"])
         self.micro = 0
+
+    def comm_tail_ms(self):
+        """Mean exposed communication per update step (ms) over the recorded event pairs (measure_comm_tail); host sync. The pairs sit on
+        the main stream: e0 behind the last backward kernel, e1 behind the wait for the last bucket's all-reduce."""
+        if not self.comm_tail_events:
+            return None
+        torch.cuda.synchronize()
+        v = [a.elapsed_time(b) for a, b in self.comm_tail_events]
+        self.comm_tail_events = []
+        return sum(v) / len(v)
 
     def skipped_steps(self) -> int:
         """Updates skipped because the loss was non-finite (device-side guard in mpmae_hp_fetch); host sync."""

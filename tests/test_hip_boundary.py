@@ -329,6 +329,7 @@ def test_rccl_exchange_runs_at_world_size_one():
     for mode in ("program", "eager"):
         m = re.search(mode + r": RCCL world-1 exchange vs no exchange after 2 steps: gradients max rel ([0-9.e+-]+)", r.stdout)
         assert m and float(m.group(1)) < 1e-5, r.stdout
+        assert re.search(mode + r": exposed communication tail [0-9.]+ ms per step", r.stdout), r.stdout      # StepRunner.measure_comm_tail
 
 
 def test_lanes_and_outside_streams_are_probed_for_shared_hardware_queues():

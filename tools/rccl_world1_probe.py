@@ -45,9 +45,14 @@ def main():
             eng.set_inputs(inputs, noise)
             run = mdist.StepRunner(eng, world_size=1, lr=1e-3, mode=mode, force_exchange=exch)
             assert run.exchange == exch and (len(run.buckets) == 4) == exch
+            run.measure_comm_tail = exch                 # (backward end, collectives done) event pairs on the main stream
             for _ in range(2):
                 run.step()
             torch.cuda.synchronize()
+            if exch:
+                tail = run.comm_tail_ms()
+                assert tail is not None and tail >= 0.0, tail
+                print(f"{mode}: exposed communication tail {tail:.4f} ms per step", flush=True)
             res[exch] = (eng.gflat.clone(), eng.pflat.clone(), run.mean_loss())
         g, p = rel(res[True][0], res[False][0]), rel(res[True][1], res[False][1])
         dl = abs(res[True][2] - res[False][2]) / abs(res[False][2])
