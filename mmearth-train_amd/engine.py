@@ -66,6 +66,7 @@ ENGINE_OPTIONS = dict(
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
     rs_maxc=100000,         # largest C on the row-streaming kernels
+    rsn_maxc=192,           # largest C with the GRN application / its backward fused into the NARROW row-streaming kernels (beyond: tiled GEMMs + element-wise kernels; 384 on tiny 112/16: 16.64 vs 15.15 ms)
     grn_fold_minc=0,        # smallest C with folded GRN finalisation
     hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
     dzr_maxc=80,            # largest C recomputing dz
@@ -713,7 +714,7 @@ class Engine:
         if not self._rs_ok(blk) or blk["C"] > int(self.opt["rs_maxc"]):
             return False, None
         if self._rsc_ok(blk):
-            return True, ("fused" if blk["C"] <= 192 else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
+            return True, ("fused" if blk["C"] <= int(self.opt["rsn_maxc"]) else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
         return True, "plain"
 
     def _rsc_ok(self, blk):
