@@ -385,7 +385,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40: 1 = two row tiles per wave, otherwise one */
   MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80: 0 = two row tiles per wave, otherwise one */
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
-  MPMAE_OPT_TN3_BLOCKS,   /* default 256: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2) */
+  MPMAE_OPT_TN3_BLOCKS,   /* default 128: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2). Re-swept after the matrix-core depthwise kernels rebalanced the lanes: 128 (half the CUs, half the slabs) 3.87-3.88 vs 256 3.91 ms in three interleaved pairs - the weight-gradient lane's kernels leave CUs to the main lane's */
   MPMAE_OPT_TNG_BLOCKS,   /* default 512: target workgroup count of the GROUPED weight-gradient kernel (gemm_tng.cuh; 0 = one mpmae_wgrad per problem) */
   MPMAE_OPT_NT4,   /* default 1: 256 x 256-tile NT GEMM (gemm_nt4.cuh) for M >= 8192, N = 1024..2048 a multiple of 256, K % 64 == 0 (decoder pwconv1, pwconv2 data gradient); 2 = every shape with M >= 8192, N >= 256 (256 x 128 tiles under N = 1024); 0 = the 128 x 128 kernels */
   MPMAE_OPT_FOLD_GROUP,   /* default 0: 1 = mpmae_fold_group folds up to 16 records per launch (blockIdx.z = record) instead of one launch per record - measured SLOWER in the step (4.035-4.04 vs 4.005-4.026 ms, three interleaved pairs): the small launches slot in between the weight-gradient lane's kernels, the grouped one waits for all its producers */

@@ -127,7 +127,7 @@ static int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC_N40 */ 2,
     /* MPMAE_OPT_RSC_N80 */ 1,
     /* MPMAE_OPT_STB_BLOCKS */ 512,
-    /* MPMAE_OPT_TN3_BLOCKS */ 256,
+    /* MPMAE_OPT_TN3_BLOCKS */ 128,
     /* MPMAE_OPT_TNG_BLOCKS */ 512,
     /* MPMAE_OPT_NT4 */ 1,
     /* MPMAE_OPT_FOLD_GROUP */ 0,
