@@ -132,12 +132,11 @@ typedef struct MpmaeImgArgs {
 /* Row-streaming fused pointwise kernels of a sparse ConvNeXtV2 block (bf16 only, H = 4C):
  *   which = 0: x-hat, rstd, xn, h = LN(d) W1^T + b1 and sum gelu(h)^2          (LN + pwconv1)
  *   which = 1: dz = dout W2 and (sum dz, sum dz*gelu(h))                        (pwconv2 data grad)
- *   which = 2: out = x + z W2^T + b2                                             (pwconv2 + residual)
- *   which = 3: dd = LayerNorm-backward(dh W1), dgamma, dbeta                     (pwconv1 data grad + LN)
  *   which = 4: z = gelu(h)*scale + beta (stored to xn), out = x + z W2^T + b2    (GRN apply + pwconv2)
- *   which = 5: dh = (dz*scale + coef*gelu(h))*gelu'(h) stored OVER dz (= A), then as which = 3
- * C in {40,80,96}: which 0-3, whole weight matrix resident in LDS (csrc/rs.cuh), M % 16 == 0.
- * C in {160,320}: which 0,1,4,5, weights streamed through LDS in chunks (csrc/rsc.cuh), any M;
+ *   which = 5: dh = (dz*scale + coef*gelu(h))*gelu'(h) stored OVER dz (= A), then dd = LayerNorm-backward(dh W1), dgamma, dbeta
+ *   (which = 2 / 3 - pwconv2 / pwconv1 data gradient on MATERIALISED z / dh, the resident-weights kernels of rounds 1-3 - were
+ *   removed in round 4: invalid value)
+ * C in {40,80,96,160,192,320,384}: weights streamed through LDS in chunks (csrc/rsc.cuh), any M;
  * scale / coef are [M / rpg][H] (rpg = rows per GRN group; 0 = one group).
  * Field use per kernel is documented in those files. Replaces convnextv2_sparse.py:40-43,55 and
  * their autograd. */
@@ -210,33 +209,6 @@ typedef struct MpmaePsArgs {
   MpmaePsBlock blk[MPMAE_PS_MAXBLK];
 } MpmaePsArgs;
 int mpmae_ps_fwd(const MpmaePsArgs* args, mpmae_stream_t stream);
-/* Backward twin (autograd of the same blocks), blocks in REVERSE order of the stage: blk[0] is the stage's LAST block. Per
- * block: dz = dout W2 and the batch-global sums (sum dz, sum dz gelu(h)) -> GRN backward -> dh (stored: operand of pwconv1's
- * weight gradient) -> dxn = dh W1 -> LayerNorm backward -> dd (stored: operand of the depthwise weight gradient) -> depthwise
- * data gradient + residual -> dx (stored: the next block's dout, operand of ITS pwconv2 weight gradient). d_grn_g / d_grn_b /
- * d_ln_g / d_ln_b are ACCUMULATED (GRN ones by workgroup 0 behind the grid barrier, LayerNorm ones by a second-stage launch over
- * the per-workgroup slab rows in ln_slab). The weight / bias gradients of pwconv1, pwconv2 and
- * the depthwise convolution stay with mpmae_wgrad / mpmae_dwconv7_wgrad on the operands saved here and by the forward.
- * Same shape limits, `sync` protocol and `ng` as mpmae_ps_fwd; S0 / S1 are [ng][4C] zero-initialised accumulators. */
-typedef struct MpmaePsBwdBlock {
-  const float* dw_w; const float* ln_g; const float* grn_g;
-  const void* W2T; const void* W1T;            /* staged bf16 [4C][ldw2t] (= W2^T), [C][ldw1t] (= W1^T) */
-  int ldw2t, ldw1t;
-  const void* h; const void* dhat; const float* rstd;            /* saved by the forward */
-  const float* Gx; const float* Ainv; const float* scale;
-  float* S0; float* S1; float* coef;                             /* statistics accumulators; coef [4C] optional output */
-  float* d_grn_g; float* d_grn_b; float* d_ln_g; float* d_ln_b;  /* parameter gradients, accumulated */
-  void* dh; void* dd; void* dx;                                  /* [M, 4C], [M, C], [M, C] */
-} MpmaePsBwdBlock;
-typedef struct MpmaePsBwdArgs {
-  const void* dout_in;                         /* gradient wrt the stage output [M, C] bf16 */
-  MpmaeGeom g; const uint8_t* act;
-  int C, nblk, ng;
-  unsigned* sync;
-  float* ln_slab;                              /* scratch [nblk][N][2C] floats: per-workgroup LayerNorm parameter-gradient partials */
-  MpmaePsBwdBlock blk[MPMAE_PS_MAXBLK];
-} MpmaePsBwdArgs;
-int mpmae_ps_bwd(const MpmaePsBwdArgs* args, mpmae_stream_t stream);
 
 /* im2col of the masked fp32 NCHW image for the sparse 3x3 stem convolution (MinkowskiConvolution
  * 3x3 of convnextv2_sparse.py:113-117): out[(n*keep+slot)*S*S + iy*S + ix][k], k = (kw*3+kh)*Cseg + cin
@@ -381,7 +353,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSC_BLOCKS,   /* default 1536: target workgroup count of the wide row-streaming kernels */
   MPMAE_OPT_RSC_PF,   /* default 1: LDS-staged GRN vectors / early operand issue in the narrow row-streaming kernels */
   MPMAE_OPT_RSC_NC32,   /* (retired in round 3: 32-column weight chunks at C = 160 are the only variant; the value is ignored) */
-  MPMAE_OPT_RSC_SMALL,   /* default 1: chunked row-streaming kernels at C = 40 / 80 too */
+  MPMAE_OPT_RSC_SMALL,   /* (retired in round 4 with the resident-weights kernels of rs.cuh: C = 40 / 80 / 96 always run the chunked kernels; the value is ignored by the library - the ENGINE option rsc_small = 0 still sends those widths to the tiled GEMMs) */
   MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40: 1 = two row tiles per wave, otherwise one */
   MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80: 0 = two row tiles per wave, otherwise one */
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */

@@ -129,21 +129,6 @@ class PsArgs(C.Structure):
                 ("sync", c_void_p), ("blk", PsBlock * PS_MAXBLK)]
 
 
-class PsBwdBlock(C.Structure):
-    _fields_ = [("dw_w", c_void_p), ("ln_g", c_void_p), ("grn_g", c_void_p), ("W2T", c_void_p), ("W1T", c_void_p),
-                ("ldw2t", c_int), ("ldw1t", c_int),
-                ("h", c_void_p), ("dhat", c_void_p), ("rstd", c_void_p), ("Gx", c_void_p), ("Ainv", c_void_p), ("scale", c_void_p),
-                ("S0", c_void_p), ("S1", c_void_p), ("coef", c_void_p),
-                ("d_grn_g", c_void_p), ("d_grn_b", c_void_p), ("d_ln_g", c_void_p), ("d_ln_b", c_void_p),
-                ("dh", c_void_p), ("dd", c_void_p), ("dx", c_void_p)]
-
-
-class PsBwdArgs(C.Structure):
-    _fields_ = [("dout_in", c_void_p), ("g", Geom), ("act", c_void_p),
-                ("C", c_int), ("nblk", c_int), ("ng", c_int),
-                ("sync", c_void_p), ("ln_slab", c_void_p), ("blk", PsBwdBlock * PS_MAXBLK)]
-
-
 class Meters(C.Structure):
     _fields_ = [("losses", c_void_p), ("weighted", c_void_p), ("T", c_int), ("ring", c_void_p), ("window", c_int),
                 ("sums", c_void_p), ("gnorm2", c_void_p), ("err_words", c_void_p), ("n_err", c_int), ("err_stride", c_int)]
@@ -208,7 +193,6 @@ SYMBOLS = {
                        c_void_p],
     "mpmae_rs": [c_int, P(RsArgs), c_void_p],
     "mpmae_ps_fwd": [P(PsArgs), c_void_p],
-    "mpmae_ps_bwd": [P(PsBwdArgs), c_void_p],
     "mpmae_quant_mx": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mpmae_gemm_mx": [c_int, P(GemmArgs), c_void_p, c_int, c_void_p, c_int, c_void_p],
     "mpmae_set_option": [c_int, c_int],

@@ -1,0 +1,178 @@
+// extern "C" surface of libmpmae_hip.so, row-streaming unit: the fused pointwise kernels of a sparse block (mpmae_rs, rsc.cuh) and the
+// persistent per-sample stage kernel (mpmae_ps_fwd, ps.cuh). gfx950 only.
+#include "capi_common.h"
+#include "rs.cuh"
+#include "rsc.cuh"
+#include "ps.cuh"
+
+// ------------------------------------------------------------------------------------------
+// row-streaming fused pointwise kernels
+// ------------------------------------------------------------------------------------------
+// chunked variants (rsc.cuh): weights streamed through LDS, any M
+
+template <int KC, int RT, int NC, int KCH, int RTN = RT, int PFN = 0>
+static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
+  RsP p;
+  p.A = (const bf16_t*)a.A; p.A2 = (const bf16_t*)a.A2; p.W = (const bf16_t*)a.W; p.ldw = a.ldw;
+  p.bias = a.bias; p.v0 = a.v0; p.v1 = a.v1; p.out = (bf16_t*)a.out; p.xhat = (bf16_t*)a.xhat; p.xn = (bf16_t*)a.xn;
+  p.rstd = a.rstd; p.R = (const bf16_t*)a.R; p.lng = a.lng; p.ws = a.ws; p.act = a.act; p.M = a.M;
+  p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
+  p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
+  p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
+  const int HN = a.H;
+  if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
+  if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
+  if ((a.ldw & 7) || HN % NC || HN % KCH) return (int)hipErrorInvalidValue;
+  const int rowblocks = cdiv(a.M, 64 * RT);
+  if (which == 0 || which == 1) {
+    if (a.fin_sum) return (int)hipErrorInvalidValue;
+    // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
+    const int target = g_opt[MPMAE_OPT_RSC_BLOCKS];
+    int nsplit = 1;
+    while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
+    const int cps = HN / nsplit;
+    constexpr int KP = ((KC + 31) / 32) * 32;
+    const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)2 * cps * 4;
+    const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
+    if (!a.ws || a.ws_floats < need || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    dim3 g(rowblocks, nsplit);
+    if (which == 0) {
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 0, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_wide_kernel<KC, 0, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
+      launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+    } else {
+      static size_t cur = 64 * 1024;
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 1, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
+      LAUNCH((rsc_wide_kernel<KC, 1, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
+      if (a.s1 == a.s0 + HN) {        // adjacent outputs (the engine's layout): one launch over [2*HN]
+        launch_reduce(0, a.ws, rowblocks, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
+      } else {                        // e = which*HN + j -> which == 0 ? s0[j] : s1[j]
+        const long long delta = a.s1 - a.s0;
+        if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+        launch_reduce(1, a.ws, rowblocks, 2 * HN, a.s0, nullptr, HN, (int)delta, 1, 0, st);
+      }
+    }
+  } else if (which == 4 || which == 5) {
+    const int rpg = a.rpg > 0 ? a.rpg : a.M;
+    // 80-row tiles (5 waves) where 64-row tiles are more than one round of workgroups and 80-row tiles are not (C = 160 at bs 256:
+    // 304 -> 244 workgroups on 256 CUs): the per-workgroup time is the weight stream, not the rows
+    const bool w5 = KC == 160 && g_opt[MPMAE_OPT_RSC_W5] && cdiv(a.M, 64 * RTN) > ps_num_cus() && cdiv(a.M, 80 * RTN) <= ps_num_cus();
+    const int rowblocks = cdiv(a.M, (w5 ? 80 : 64) * RTN);
+    constexpr int NP = ((KC + 15) / 16) * 16;
+    const int pf_on = g_opt[MPMAE_OPT_RSC_PF];
+    const bool pf = PFN && pf_on && rpg >= a.M;       // LDS-staged GRN vectors (+ early issue): single GRN group only
+    const bool dzr = a.dz_dout != nullptr;            // which 5: dz recomputed from dout; which 4: h recomputed from xn (never read)
+    if (dzr && which == 4 && (!a.dz_bias || ((uintptr_t)a.dz_bias & 15))) return (int)hipErrorInvalidValue;
+    if (dzr && (!(PFN & 4) || !pf || !a.dz_w2t || (a.dz_ldw2 & 7) || (((uintptr_t)a.dz_dout | (uintptr_t)a.dz_w2t) & 15))) return (int)hipErrorInvalidValue;
+    constexpr int KP2 = ((KC + 31) / 32) * 32;
+    const size_t lds = (size_t)2 * NP * (KCH + RSC_PAD) * 2 + (size_t)2 * KC * 4 + (pf ? (size_t)2 * HN * 4 + 32 : 0) +
+                       (dzr ? (size_t)2 * KCH * (KP2 + RSC_PAD) * 2 : 0);
+    if (lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    if (a.fin_sum) {                                   // folded GRN finalisation
+      if (!pf || !a.fin_gamma || !a.fin_gx || !a.fin_ainv) return (int)hipErrorInvalidValue;
+      if (which == 4 && (!a.fin_out || !a.v1)) return (int)hipErrorInvalidValue;
+      if (which == 5 && (!a.fin_sum0 || !a.fin_dgamma || !a.fin_dbeta || !a.v0)) return (int)hipErrorInvalidValue;
+      if (((uintptr_t)a.fin_sum | (uintptr_t)a.fin_gamma) & 15) return (int)hipErrorInvalidValue;
+    }
+    if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
+#define RSC_NARROW_W(MODE_, PF_, NWV_) do { \
+      static size_t cur = 64 * 1024; \
+      if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
+      LAUNCH((rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>), dim3(rowblocks), dim3(64 * NWV_), lds, st, p, HN, rpg); } while (0)
+#define RSC_NARROW(MODE_, PF_) do { \
+      if constexpr (KC == 160) { if (w5) RSC_NARROW_W(MODE_, PF_, 5); else RSC_NARROW_W(MODE_, PF_, 4); } \
+      else RSC_NARROW_W(MODE_, PF_, 4); } while (0)
+    if (which == 4) { if (dzr) RSC_NARROW(0, (PFN & 4) ? (PFN & 6) : 0); else if (pf) RSC_NARROW(0, (PFN & 3)); else RSC_NARROW(0, 0); }
+    else {
+      if (dzr) RSC_NARROW(1, (PFN & 4) ? (PFN & 6) : 0);
+      else if (pf) RSC_NARROW(1, (PFN & 3)); else RSC_NARROW(1, 0);
+      // (direct float atomics into dgamma / dbeta instead of slab rows + this launch: measured 5.06 vs 4.92 ms per step - the
+      // gridDim.x colliding updates per address land together at the kernel's tail)
+      const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
+      if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+      if (a.defer_fold) *a.defer_fold = MpmaeFoldDesc{a.ws, rowblocks, 2 * KC, a.s0, KC, (int)delta, 1};
+      else launch_reduce(1, a.ws, rowblocks, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+    }
+#undef RSC_NARROW
+#undef RSC_NARROW_W
+  } else {
+    return (int)hipErrorInvalidValue;
+  }
+  return launch_status();
+}
+
+int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
+  if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
+  if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));      // 32-column chunks: the N range splits 4 ways (27.7 -> 24.1 us vs 64)
+  if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
+  // ConvNeXtV2-tiny widths (BASELINE config 4: 96 / 192 / 384; 768 stays on the tiled GEMMs)
+  if (a->C == 96 && a->H == 384) return launch_rsc<96, 2, 64, 64, 1, 3>(which, *a, S_(s));
+  if (a->C == 192 && a->H == 768) return launch_rsc<192, 1, 32, 64, 1, 3>(which, *a, S_(s));
+  if (a->C == 384 && a->H == 1536) return launch_rsc<384, 1, 32, 32, 1, 3>(which, *a, S_(s));
+  if (which == 2 || which == 3) return (int)hipErrorInvalidValue;      // (the resident-weights kernels on materialised z / dh: removed in round 4)
+  const int v40 = g_opt[MPMAE_OPT_RSC_N40], v80 = g_opt[MPMAE_OPT_RSC_N80];
+  // (variants without the staged-vector prologue - no folded GRN finalisation, no operand recomputation - were removed in round 3:
+  // the engine's program needs both, and nothing tested them)
+  if (a->C == 40 && a->H == 160) {
+    if (v40 == 1) return launch_rsc<40, 4, 160, 32, 2, 6>(which, *a, S_(s));
+    return launch_rsc<40, 4, 160, 32, 1, 6>(which, *a, S_(s));
+  }
+  if (a->C == 80 && a->H == 320) {
+    if (v80 == 0) return launch_rsc<80, 2, 64, 64, 2, 6>(which, *a, S_(s));
+    return launch_rsc<80, 2, 64, 64, 1, 6>(which, *a, S_(s));
+  }
+  return (int)hipErrorInvalidValue;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// persistent per-sample stage kernels (ps.cuh)
+// ------------------------------------------------------------------------------------------
+int ps_num_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    (void)hipGetLastError();
+    cus = v;
+  }
+  return cus;
+}
+
+static int ps_check(const MpmaePsArgs& a, int S, int keep_max) {
+  if (!a.x_in || !a.g.vis || !a.g.inv || !a.sync || a.nblk < 1 || a.nblk > MPMAE_PS_MAXBLK || a.ng < 1 || a.ng > 16) return (int)hipErrorInvalidValue;
+  if (a.g.S != S || a.g.keep < 1 || a.g.keep > keep_max || a.g.N < 1 || a.g.N > ps_num_cus()) return (int)hipErrorInvalidValue;
+  if ((size_t)a.g.keep * S * S * a.C * 4 >= 65535u) return (int)hipErrorInvalidValue;       // 16-bit LDS offsets of the neighbour table
+  return 0;
+}
+
+template <int C, int S>
+static int launch_ps_fwd(const MpmaePsArgs& a, hipStream_t st) {
+  using K = ps::Cfg<C, S>;
+  if (const int e = ps_check(a, S, S == 2 ? K::RP / 4 : 32)) return e;
+  for (int b = 0; b < a.nblk; ++b) {
+    const MpmaePsBlock& B = a.blk[b];
+    if (!B.dw_w || !B.dw_b || !B.ln_g || !B.ln_b || !B.W1 || !B.b1 || !B.grn_g || !B.grn_b || !B.W2 || !B.b2 || !B.dhat || !B.rstd ||
+        !B.xn || !B.h || !B.z || !B.out || !B.G2 || !B.Gx || !B.Ainv || !B.scale || (B.ldw1 & 7) || (B.ldw2 & 7) || B.ldw1 < C || B.ldw2 < 4 * C)
+      return (int)hipErrorInvalidValue;
+    if (((uintptr_t)B.W1 | (uintptr_t)B.W2 | (uintptr_t)B.dhat | (uintptr_t)B.xn | (uintptr_t)B.h | (uintptr_t)B.z | (uintptr_t)B.out |
+         (uintptr_t)B.dw_w | (uintptr_t)B.dw_b | (uintptr_t)B.ln_g | (uintptr_t)B.ln_b | (uintptr_t)B.b1 | (uintptr_t)B.b2) & 15)
+      return (int)hipErrorInvalidValue;
+  }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)ps::ps_fwd_kernel<C, S>, hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS) != hipSuccess) return (int)hipGetLastError();
+    attr = true;
+  }
+  LAUNCH((ps::ps_fwd_kernel<C, S>), dim3(a.g.N), dim3(ps::NTHR), K::LDS, st, a);
+  return launch_status();
+}
+
+int mpmae_ps_fwd(const MpmaePsArgs* a, mpmae_stream_t s) {
+  if (!a) return (int)hipErrorInvalidValue;
+  if (a->C == 160 && a->g.S == 2) return launch_ps_fwd<160, 2>(*a, S_(s));
+  if (a->C == 320 && a->g.S == 1) return launch_ps_fwd<320, 1>(*a, S_(s));
+  return (int)hipErrorInvalidValue;
+}
+

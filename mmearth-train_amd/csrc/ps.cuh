@@ -1,7 +1,9 @@
-// Persistent per-sample stage kernels ("ps"): ONE launch runs every ConvNeXtV2 block of a sparse stage, forward or backward.
+// Persistent per-sample stage kernels ("ps"): ONE launch runs the FORWARD of every ConvNeXtV2 block of a sparse stage
+// (a backward twin was built in round 3, measured no faster stand-alone and slower in the step - a one-workgroup-per-CU kernel cannot
+// share the GPU with the weight-gradient lane - and removed in round 4).
 //
-// Replaces, per block, the launch chain  dw7x7 -> [LN + pw1 + GELU^2 sums] -> reduce -> [GRN + pw2 + residual]  (and its backward
-// twin) of the row-streaming kernels (rsc.cuh, dwconv6.cuh) at the compute-shaped stages, where those launches are latency chains
+// Replaces, per block, the launch chain  dw7x7 -> [LN + pw1 + GELU^2 sums] -> reduce -> [GRN + pw2 + residual]  of the
+// row-streaming kernels (rsc.cuh, dwconv6.cuh) at the compute-shaped stages, where those launches are latency chains
 // (profiles/r02: 17 + 33 + 33 us per block for ~4 us of roofline work). Reference semantics: models/convnextv2_sparse.py:47-56,
 // models/sparse_norm_layers.py:24-33 (batch-global GRN) and :61-77.
 //
@@ -584,371 +586,6 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     PS_STAMP(7);
   }
   grid_exit(a.sync, nwg);
-}
-
-// =====================================================================================
-// backward: the blocks of one stage in REVERSE order (a.blk[0] = last block of the stage). Per block
-//   dz = dout W2 (-> HA)            | column sums S0 = sum dz, S1 = sum dz gelu(h) -> atomics, grid barrier, GRN backward finalisation
-//   dh = (dz scale + coef gelu(h)) gelu'(h) (-> HA, global)   | dxn = dh W1, LayerNorm backward -> dd (global, fp32 rows XF)
-//   dx = depthwise^T(dd) + dout (-> XA = next block's dout, global)
-// h is read ONCE per block, 16 bytes per lane in the layout of the element-wise passes, and kept in registers from the end of the
-// previous block (its HBM latency hides behind that block's depthwise phase) across the barrier.
-template <int C, int S>
-__global__ __launch_bounds__(512) void ps_bwd_kernel(const MpmaePsBwdArgs a) {
-  using K = Cfg<C, S>;
-  using T = bf16_t;
-  constexpr int H = K::H, SS = K::SS, MT = K::MT, RP = K::RP, LDX = K::LDX, LDH = K::LDH, NCHK = K::NCHK;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  bf16_t* XA = reinterpret_cast<bf16_t*>(smem + K::OFF_XA);
-  bf16_t* HA = reinterpret_cast<bf16_t*>(smem + K::OFF_HA);
-  float* XF = reinterpret_cast<float*>(smem + K::OFF_HA);
-  float* vec = reinterpret_cast<float*>(smem + K::OFF_VEC);
-  float* csum = reinterpret_cast<float*>(smem + K::OFF_CS);
-  unsigned char* live = smem + K::OFF_LIVE;
-  float* red = reinterpret_cast<float*>(smem + K::OFF_RED);
-  float* rowsum = reinterpret_cast<float*>(smem + K::OFF_ROW);
-
-  const int tid0 = threadIdx.x;
-  const int n = blockIdx.x, nwg = gridDim.x;
-  const int keep = a.g.keep, R = keep * SS;
-  const size_t rowbase = (size_t)n * R;
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef __attribute__((address_space(4))) const char* kchar_p;
-  typedef __attribute__((address_space(4))) const MpmaePsBwdBlock* kblk_p;
-  const kblk_p blks = (kblk_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MpmaePsBwdArgs, blk));
-#else
-  const MpmaePsBwdBlock* blks = a.blk;
-#endif
-
-  uint4 hreg[NCHK];                       // this thread's h rows of the CURRENT block (column chunk cc, rows rg + i NRG)
-  auto load_h = [&](const void* hp, int tid) {
-    const int cc = tid % K::NCC, rg = tid / K::NCC;
-    const T* hg = reinterpret_cast<const T*>(hp) + rowbase * H + cc * 8;
-#pragma unroll
-    for (int i = 0; i < NCHK; ++i) {
-      const int m = min(rg + i * K::NRG, R - 1);
-      hreg[i] = *reinterpret_cast<const uint4*>(hg + (size_t)m * H);
-    }
-  };
-  // ---- stage prologue
-  {
-    const int tid = tid0;
-    for (int i = tid; i < K::XA_B / 16; i += NTHR) reinterpret_cast<uint4*>(XA)[i] = make_uint4(0u, 0u, 0u, 0u);
-    build_tab<C, S>(a.g, smem, n);
-    for (int i = tid; i < RP; i += NTHR) live[i] = (i < R) ? (a.act ? a.act[rowbase + i] : (unsigned char)1) : (unsigned char)0;
-    __syncthreads();
-    const T* din = reinterpret_cast<const T*>(a.dout_in) + rowbase * C;
-    for (int i = tid; i < R * (C / 8); i += NTHR) {
-      const int row = i / (C / 8), q = i - row * (C / 8);
-      *reinterpret_cast<uint4*>(XA + row * LDX + q * 8) = *reinterpret_cast<const uint4*>(din + (size_t)row * C + q * 8);
-    }
-    if (tid < (NTHR / K::NCC) * K::NCC) load_h(blks[0].h, tid);
-  }
-  __syncthreads();
-
-  for (int b = 0; b < a.nblk; ++b) {
-    const MpmaePsBwdBlock B = blks[b];
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lg = lane >> 4;
-    const int cc = tid % K::NCC, rg = tid / K::NCC;
-    const bool ew = rg < K::NRG;                           // thread takes part in the element-wise passes
-
-    PS_STAMP(0);
-    // ---- B1: dz = dout W2 (weights: staged W2^T [H][C]), bf16 -> HA
-    {
-      constexpr int NT1 = C / 32, KS1 = C / 32, NTL1 = (NT1 % 5 == 0) ? 5 : NT1, D1 = (KS1 < 3) ? KS1 : 3;
-      const int n0 = wave * (H / 8);
-      const T* W2T = reinterpret_cast<const T*>(B.W2T);
-#pragma unroll 1
-      for (int jg = 0; jg < NT1 / NTL1; ++jg) {
-        const int nb0 = n0 + jg * NTL1 * 16;
-        const T* wl = W2T + (size_t)(nb0 + lr) * B.ldw2t + lg * 8;
-        uint4 wq1[D1][NTL1];
-        gemm_prefetch<NTL1, KS1, D1>(wl, 16 * B.ldw2t, wq1, n % KS1);
-        f32x4_t acc[NTL1][MT];
-#pragma unroll
-        for (int j = 0; j < NTL1; ++j)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        gemm_run<NTL1, MT, KS1, D1, LDX>(wl, 16 * B.ldw2t, XA + lr * LDX + lg * 8, wq1, acc, n % KS1);
-#pragma unroll
-        for (int j = 0; j < NTL1; ++j)
-#pragma unroll
-          for (int m = 0; m < MT; ++m) {
-            const float o[4] = {acc[j][m][0], acc[j][m][1], acc[j][m][2], acc[j][m][3]};
-            *reinterpret_cast<uint2*>(HA + (m * 16 + lr) * LDH + nb0 + j * 16 + lg * 4) = pack_bf16x4(o);
-          }
-      }
-    }
-    for (int i = tid; i < 2 * H; i += NTHR) csum[i] = 0.f;
-    for (int i = tid; i < RP * 2; i += NTHR) rowsum[i] = 0.f;
-    // this block's h (HBM): requested BEHIND the product's weight loads - vmcnt retires in order, so issued in front of them (at the end
-    // of the previous block) every weight load of the product waited for the HBM round trip of h
-    if (b > 0 && ew) load_h(B.h, tid);
-    __syncthreads();
-
-    PS_STAMP(1);
-    // ---- B2: column sums of dz and dz gelu(h) over this sample's rows (thread: 8 columns x its rows), then the exchange
-    constexpr int NT2 = C / 16, NTW = (NT2 + 7) / 8, KS2 = H / 32;
-    auto tail = [&](auto ntl_) {
-      constexpr int NTL = decltype(ntl_)::value;
-      constexpr int D2 = (S == 2) ? 8 : 6;
-      const T* W1T = reinterpret_cast<const T*>(B.W1T);
-      const T* wl2 = W1T + (size_t)(wave * 16 + lr) * B.ldw1t + lg * 8;
-      uint4 wq2[D2][NTL];
-      if (ew) {
-        float s0[8], s1[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < NCHK; ++i) {
-          const int m = rg + i * K::NRG;
-          float dz[8], hv[8], g[8];
-          unpack8(*reinterpret_cast<const uint4*>(HA + min(m, RP - 1) * LDH + cc * 8), dz);
-          unpack8(hreg[i], hv);
-          gelu_n<T, 8>(hv, g);
-          const bool in = m < R;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { s0[e] += in ? dz[e] : 0.f; s1[e] += in ? dz[e] * g[e] : 0.f; }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {            // element-major layout: the lanes of one ds_add hit consecutive banks (column-major was 16-way conflicted)
-          atomicAdd(&csum[e * K::NCC + cc], s0[e]);
-          atomicAdd(&csum[H + e * K::NCC + cc], s1[e]);
-        }
-      }
-      __syncthreads();
-      constexpr int NJ = (2 * H + NTHR - 1) / NTHR;
-#pragma unroll
-      for (int u = 0; u < NJ; ++u) {
-        const int j = tid + NTHR * u;            // [0, H): S0, [H, 2H): S1
-        if (j < 2 * H) {
-          const int jj = j < H ? j : j - H;
-          (void)unsafeAtomicAdd((j < H ? B.S0 : B.S1) + (size_t)(n % a.ng) * H + jj, csum[(j < H ? 0 : H) + (jj & 7) * K::NCC + (jj >> 3)]);
-        }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw1t, wq2, n % KS2);
-      constexpr int NH = (H + NTHR - 1) / NTHR;
-      float gg[NH], gxv[NH], scv[NH];
-#pragma unroll
-      for (int u = 0; u < NH; ++u) {
-        const int jc = min(tid + NTHR * u, H - 1);
-        gg[u] = B.grn_g[jc]; gxv[u] = B.Gx[jc]; scv[u] = B.scale[jc];
-      }
-      const float ainv = B.Ainv[0];
-      grid_barrier(a.sync, (unsigned)(b + 1) * nwg);
-      PS_STAMP(2);
-      // ---- B3: GRN backward finalisation (grn_bwd_finalize_kernel, rows.cuh) by every workgroup; workgroup 0 owns dgamma / dbeta
-      float s0v[NH], s1v[NH], ts = 0.f;
-#pragma unroll
-      for (int u = 0; u < NH; ++u) {
-        const int j = tid + NTHR * u, jc = min(j, H - 1);
-        float t0 = 0.f, t1 = 0.f;
-        for (int q = 0; q < a.ng; ++q) { t0 += atomic_ld(B.S0 + (size_t)q * H + jc); t1 += atomic_ld(B.S1 + (size_t)q * H + jc); }
-        s0v[u] = t0; s1v[u] = t1;
-        ts += (j < H) ? gg[u] * t1 * gxv[u] : 0.f;
-      }
-      ts = wave_sum(ts);
-      if (lane == 0) red[wave] = ts;
-      __syncthreads();
-      float tot = 0.f;
-#pragma unroll
-      for (int w8 = 0; w8 < 8; ++w8) tot += red[w8];
-      const float T2 = tot * ainv * ainv / H;
-#pragma unroll
-      for (int u = 0; u < NH; ++u) {
-        const int j = tid + NTHR * u;
-        if (j < H) {
-          const float dGx = gg[u] * s1v[u] * ainv - T2;
-          const float cf = (gxv[u] > 0.f) ? dGx / gxv[u] : 0.f;
-          vec[j] = scv[u];
-          vec[H + j] = cf;
-          if (n == 0) {
-            if (B.coef) B.coef[j] = cf;
-            B.d_grn_g[j] += gxv[u] * ainv * s1v[u];
-            B.d_grn_b[j] += s0v[u];
-          }
-        }
-      }
-      __syncthreads();
-
-      PS_STAMP(3);
-      // ---- B4: dh = (dz scale + coef gelu(h)) gelu'(h) in place on HA, saved for pw1's weight gradient
-      if (ew) {
-        float sc[8], cf[8];
-        ld8<float>(vec + cc * 8, sc);
-        ld8<float>(vec + H + cc * 8, cf);
-        T* dhg = reinterpret_cast<T*>(B.dh) + rowbase * H + cc * 8;
-#pragma unroll
-        for (int i = 0; i < NCHK; ++i) {
-          const int m = rg + i * K::NRG;
-          float dz[8], hv[8], g[8], dg[8], o[8];
-          unpack8(*reinterpret_cast<const uint4*>(HA + min(m, RP - 1) * LDH + cc * 8), dz);
-          unpack8(hreg[i], hv);
-          gelu_both_n<T, 8>(hv, g, dg);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (dz[e] * sc[e] + cf[e] * g[e]) * dg[e];
-          if (m < R) {
-            const uint4 pk = __builtin_bit_cast(uint4, pack_bf16x8(o));
-            *reinterpret_cast<uint4*>(dhg + (size_t)m * H) = pk;
-            *reinterpret_cast<uint4*>(HA + m * LDH + cc * 8) = pk;
-          }
-        }
-      }
-      // LayerNorm-backward operands: requested before the product
-      const T* xh = reinterpret_cast<const T*>(B.dhat) + rowbase * C;
-      uint2 xraw[NTL][MT];
-      float4 g4[NTL];
-      float rs[MT];
-#pragma unroll
-      for (int m = 0; m < MT; ++m) rs[m] = B.rstd[rowbase + min(m * 16 + lr, R - 1)];
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        g4[j] = *reinterpret_cast<const float4*>(B.ln_g + (wave + 8 * j) * 16 + lg * 4);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          xraw[j][m] = *reinterpret_cast<const uint2*>(xh + (size_t)min(m * 16 + lr, R - 1) * C + (wave + 8 * j) * 16 + lg * 4);
-      }
-      __syncthreads();
-
-      PS_STAMP(4);
-      // ---- B5: dxn = dh W1 (weights: staged W1^T [C][H]), LayerNorm backward
-      f32x4_t acc[NTL][MT];
-#pragma unroll
-      for (int j = 0; j < NTL; ++j)
-#pragma unroll
-        for (int m = 0; m < MT; ++m) acc[j][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-      gemm_run<NTL, MT, KS2, D2, LDH>(wl2, 8 * 16 * B.ldw1t, HA + lr * LDH + lg * 8, wq2, acc, n % KS2);
-      float rs1[MT], rs2[MT];
-      float* lnp = a.ln_slab + ((size_t)b * nwg + n) * 2 * C;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { rs1[m] = 0.f; rs2[m] = 0.f; }
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        const int nc = (wave + 8 * j) * 16 + lg * 4;
-        const float gq4[4] = {g4[j].x, g4[j].y, g4[j].z, g4[j].w};
-        float ca[4] = {0.f, 0.f, 0.f, 0.f}, cb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-          const int row = m * 16 + lr;
-          const bool lvm = live[row] != 0;
-          float xhv[4];
-          unpack4(and2(xraw[j][m], row < R), xhv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float dxn = lvm ? bf2f(f2bf(acc[j][m][r])) : 0.f;      // bf16 like the unfused path
-            ca[r] += dxn * xhv[r];
-            cb[r] += dxn;
-            const float gq = dxn * gq4[r];
-            acc[j][m][r] = gq;
-            rs1[m] += gq;
-            rs2[m] += gq * xhv[r];
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sa = sum16(ca[r]), sb = sum16(cb[r]);
-          if (lr == 0) { lnp[nc + r] = sa; lnp[C + nc + r] = sb; }      // this workgroup's slab row; ps_ln_reduce_kernel folds the rows
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < MT; ++m) { atomicAdd(&rowsum[(m * 16 + lr) * 2], rs1[m]); atomicAdd(&rowsum[(m * 16 + lr) * 2 + 1], rs2[m]); }
-      __syncthreads();                               // row sums complete; every wave is done reading dh: HA's bytes become XF
-      T* ddg = reinterpret_cast<T*>(B.dd) + rowbase * C;
-#pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int row = m * 16 + lr;
-        const bool lvm = live[row] != 0;
-        const float s1 = rowsum[row * 2] / C, s2 = rowsum[row * 2 + 1] / C;
-#pragma unroll
-        for (int j = 0; j < NTL; ++j) {
-          const int nc = (wave + 8 * j) * 16 + lg * 4;
-          float xhv[4], o[4];
-          unpack4(and2(xraw[j][m], row < R), xhv);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = lvm ? rs[m] * (acc[j][m][r] - s1 - xhv[r] * s2) : 0.f;
-          if (row < R) {
-            const uint2 pk = pack_bf16x4(o);
-            *reinterpret_cast<uint2*>(ddg + (size_t)row * C + nc) = pk;
-            float of[4];
-            unpack4(pk, of);
-            *reinterpret_cast<float4*>(XF + row * C + nc) = make_float4(of[0], of[1], of[2], of[3]);
-          }
-        }
-      }
-      for (int i = tid; i < SS * C / 4; i += NTHR) *reinterpret_cast<float4*>(smem + K::OFF_HA + K::ZOFF + i * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    if (wave + 8 * (NTW - 1) < NT2) tail(std::integral_constant<int, NTW>{});
-    else tail(std::integral_constant<int, (NTW > 1 ? NTW - 1 : 1)>{});
-    __syncthreads();
-
-    PS_STAMP(5);
-    // ---- B6: dx = depthwise^T(dd) + dout (XA in place: the next block's dout); items as in the forward
-    {
-      const int nU = keep * K::NFG, nT = nU + (K::CPR ? (keep + K::PPR - 1) / K::PPR : 0);
-      T* dxg = reinterpret_cast<T*>(B.dx) + rowbase * C;
-      auto run_items = [&](int i0, int i1, bool rem) {
-        const int cp = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
-        f32x2_t w[49];
-#pragma unroll
-        for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cp);
-#pragma unroll 1
-        for (int i = i0; i < i1; i += 8) {
-          const int kk = rem ? (i - nU) * K::PPR + lane / (K::CPR ? K::CPR : 1) : i / K::NFG;
-          const bool on = kk < keep;
-          const int k = on ? kk : keep - 1;
-          f32x2_t acc[4];
-#pragma unroll
-          for (int o = 0; o < 4; ++o) acc[o] = (f32x2_t){0.f, 0.f};
-          dw_gather<C, S, 1>(smem, acc, k, cp, w);
-          if (on) {
-#pragma unroll
-            for (int o = 0; o < SS; ++o) {
-              const int row = k * SS + o;
-              const bool lv = live[row] != 0;
-              const unsigned dr = *reinterpret_cast<const unsigned*>(XA + row * LDX + 2 * cp);
-              const float d0 = __uint_as_float(dr << 16), d1 = __uint_as_float(dr & 0xffff0000u);
-              const unsigned pk = lv ? f2bf2(acc[o].x + d0, acc[o].y + d1) : 0u;
-              *reinterpret_cast<unsigned*>(XA + row * LDX + 2 * cp) = pk;
-              *reinterpret_cast<unsigned*>(dxg + (size_t)row * C + 2 * cp) = pk;
-            }
-          }
-        }
-      };
-      if (wave < nU) run_items(wave, nU, false);
-      const int r0 = nU + ((wave - nU % 8) + 8) % 8;
-      if (r0 < nT) run_items(r0, nT, true);
-    }
-    __syncthreads();
-    PS_STAMP(6);
-  }
-  grid_exit(a.sync, nwg);
-}
-
-// second stage of the LayerNorm parameter gradients of ps_bwd_kernel: slab [nblk][nwg][2C] -> d_ln_g / d_ln_b of every block
-__global__ __launch_bounds__(256) void ps_ln_reduce_kernel(const MpmaePsBwdArgs a, int nwg) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef __attribute__((address_space(4))) const char* kchar_p;
-  typedef __attribute__((address_space(4))) const MpmaePsBwdBlock* kblk_p;
-  const kblk_p blks = (kblk_p)((kchar_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(MpmaePsBwdArgs, blk));
-#else
-  const MpmaePsBwdBlock* blks = a.blk;
-#endif
-  __shared__ float part[4][64];
-  const int b = blockIdx.y, C2 = 2 * a.C;
-  const int col = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-  float s = 0.f;
-  if (col < C2)
-    for (int w = q; w < nwg; w += 4) s += a.ln_slab[((size_t)b * nwg + w) * C2 + col];
-  part[q][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (q == 0 && col < C2) {
-    const float t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
-    float* dst = col < a.C ? blks[b].d_ln_g + col : blks[b].d_ln_b + (col - a.C);
-    *dst += t;
-  }
 }
 
 }  // namespace ps

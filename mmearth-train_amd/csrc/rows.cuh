@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
 //   bwd: dgamma[j] += Nx*S1 ; dbeta[j] += S0 ; dNx = gamma*S1
 //        dGx = dNx/(A+eps) - (1/H) * sum_k dNx[k]*Gx[k] / (A+eps)^2 ; coef = dGx/Gx (0 if Gx == 0)
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const float* __restrict__ G2, const float* __restrict__ gamma,
+static __global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const float* __restrict__ G2, const float* __restrict__ gamma,
                                                                float eps, int H, float* __restrict__ Gx,
                                                                float* __restrict__ Ainv, float* __restrict__ scale) {
   __shared__ float red[4];
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const float* __re
 // The statistics of this thread's columns are loaded up front (all loads in flight at once) and kept in registers: written as two
 // loops over j with the float atomics inside, every iteration exposed one global-load latency (the atomics pin the loads behind
 // them) and the kernel took 26 us for the decoder's 2 MB of statistics.
-__global__ __launch_bounds__(256) void grn_bwd_finalize_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
+static __global__ __launch_bounds__(256) void grn_bwd_finalize_kernel(const float* __restrict__ S0, const float* __restrict__ S1,
                                                                const float* __restrict__ Gx, const float* __restrict__ Ainv,
                                                                const float* __restrict__ gamma, int H,
                                                                float* __restrict__ coef, float* __restrict__ dgamma,

@@ -58,7 +58,6 @@ ENGINE_OPTIONS = dict(
     zero_side=1,            # the step's zero fills (statistics, flat gradients, padded stem dW) on the side lane, ONE loss finalisation per step
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     ps=3,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage
-    ps_bwd=0,               # ... and their backward twin (parity-tested; at bs 256 it is no faster than the per-block kernels: 472 vs 492 us at stage 2, 216 vs 147 us at stage 3 - off)
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     dw_lane=1,              # lane of the depthwise weight gradients
     act_in_stem=1,          # the fused stem kernel writes the pixel-activity bytes itself (it computes them anyway): no activity launch, the first stage-0 op waits for nothing on the side lane, the poolings run behind the stem
@@ -697,25 +696,16 @@ class Engine:
         return buf
 
     def _rs_ok(self, blk):
-        if self.dt != BF16 or not blk["sparse"] or self.disable_rs:
-            return False
-        if self._rsc_ok(blk):
-            return True
-        if (blk["C"], blk["H"]) in ((40, 160), (80, 320), (96, 384)):     # whole weight matrix in LDS (rs.cuh)
-            return blk["M"] % 16 == 0
-        return False
+        return self._rsc_ok(blk)
 
     def _rs_plan(self, blk):
         """(wide, narrow): which row-streaming kernels a block uses. wide: LN+pw1 / pw2.dgrad fused with
-        their GRN statistics (which 0/1); narrow: None (tiled GEMMs + element-wise kernels), "plain" (which
-        2/3 on materialised z / dh) or "fused" (which 4/5, GRN application and its backward in the operand
-        prologue). Measured on MI355X at bs 256: fused wins for C <= 160; at C = 320 (M = 4864 rows, 76
-        workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
+        their GRN statistics (which 0/1); narrow: None (tiled GEMMs + element-wise kernels) or "fused" (which 4/5, GRN application
+        and its backward in the operand prologue). Measured on MI355X at bs 256: fused wins for C <= 192; at C = 320 (M = 4864 rows,
+        76 workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
         if not self._rs_ok(blk) or blk["C"] > int(self.opt["rs_maxc"]):
             return False, None
-        if self._rsc_ok(blk):
-            return True, ("fused" if blk["C"] <= int(self.opt["rsn_maxc"]) else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
-        return True, "plain"
+        return True, ("fused" if blk["C"] <= int(self.opt["rsn_maxc"]) else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
 
     def _rsc_ok(self, blk):
         """chunked row-streaming kernels (rsc.cuh) with the GRN application / its backward fused in"""
@@ -857,55 +847,6 @@ class Engine:
         self._op(lst, f"encoder.stages.{stage}:ps.fwd[{len(blks)}]", self.lib.mpmae_ps_fwd, C.byref(a), kind="ps_fwd", nbytes=nbytes, flops=flops)
         return x
 
-    def _stage_bwd_ps(self, lst, stage, blks, dout, ring, ri):
-        """Backward of a whole stage as ONE persistent launch (blocks in reverse order) + the stage's weight gradients on the side lane.
-        dout: gradient wrt the stage output; every block's dx goes to the next slot of the dx ring. Returns (dx of the stage, ring index)."""
-        P, Gd = self.params, self.grads
-        a = _lib.PsBwdArgs()
-        a.dout_in, a.g, a.act = dout.data_ptr(), self._geom(stage), (self.act[stage].data_ptr() if self.act[stage] is not None else 0)
-        a.C, a.nblk, a.ng = blks[0]["C"], len(blks), self.PS_NG
-        a.sync = self.ps_sync[self._ps_launches].data_ptr()
-        self._ps_launches += 1
-        slab = torch.zeros(len(blks) * self.N * 2 * blks[0]["C"], dtype=torch.float32, device=self.device)
-        self._keepalive.append(slab)
-        a.ln_slab = slab.data_ptr()
-        plan, cur = [], dout
-        nbytes = flops = 0
-        for i, blk in enumerate(reversed(blks)):
-            nm, tag = self._block_names(blk), blk["prefix"]
-            M, Cc, H = blk["M"], blk["C"], blk["H"]
-            t = self._bwd_t = getattr(self, "_bwd_t", -1) + 1
-            dh = self.scr_dz2[t % len(self.scr_dz2)][:M * H]
-            dd = self.scr_dd2[t % len(self.scr_dd2)][:M * Cc]
-            dx = ring[ri][:M * Cc]
-            ri = (ri + 1) % len(ring)
-            w2t, w1t = self.w[tag + ".W2T"], self.w[tag + ".W1T"]
-            b = a.blk[i]
-            b.dw_w, b.ln_g, b.grn_g = P[tag + ".dwconv.kernel"].data_ptr(), P[nm["ln_w"]].data_ptr(), P[nm["gg"]].data_ptr()
-            b.W2T, b.ldw2t, b.W1T, b.ldw1t = w2t["t"].data_ptr(), w2t["ld"], w1t["t"].data_ptr(), w1t["ld"]
-            b.h, b.dhat, b.rstd = blk["h"].data_ptr(), blk["dhat"].data_ptr(), blk["rstd"].data_ptr()
-            b.Gx, b.Ainv, b.scale = blk["Gx"].data_ptr(), blk["Ainv"].data_ptr(), blk["scale"].data_ptr()
-            b.S0, b.S1, b.coef = blk["ps_S0"].data_ptr(), blk["ps_S1"].data_ptr(), blk["coef"].data_ptr()
-            b.d_grn_g, b.d_grn_b = Gd[nm["gg"]].data_ptr(), Gd[nm["gb"]].data_ptr()
-            b.d_ln_g, b.d_ln_b = Gd[nm["ln_w"]].data_ptr(), Gd[nm["ln_b"]].data_ptr()
-            b.dh, b.dd, b.dx = dh.data_ptr(), dd.data_ptr(), dx.data_ptr()
-            plan.append((blk, cur, dh, dd, dx))
-            nbytes += (M * H * 2 + 4 * M * Cc) * 2 + 2 * Cc * H * 2      # h read, dh written; x-hat read, dd / dx written (+ dout once); weights
-            flops += 4 * M * Cc * H + 2 * 49 * M * Cc
-            cur = dx
-        self._keepalive.append(a)
-        self._op(lst, f"encoder.stages.{stage}:ps.bwd[{len(blks)}]", self.lib.mpmae_ps_bwd, C.byref(a), kind="ps_bwd", nbytes=nbytes, flops=flops)
-        self._guard(lst, *[p_[2] for p_ in plan], *[p_[3] for p_ in plan], *[p_[4] for p_ in plan])
-        for blk, dout_b, dh, dd, dx in plan:          # the stage's weight gradients: side lane, behind the launch
-            nm, tag = self._block_names(blk), blk["prefix"]
-            M, Cc, H = blk["M"], blk["C"], blk["H"]
-            self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", "NONE", [dout_b], P=dout_b, Q=blk["z"], M=M, Nn=Cc, Kk=H, ldp=Cc, ldq=H,
-                             dW=Gd[nm["w2"]], sn=H, sk=1, db=Gd[nm["b2"]])
-            self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dh], P=dh, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc,
-                             dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-            self._dw_wgrad(lst, blk, dd)
-        return cur, ri
-
     def _block_fwd_mat(self, lst, blk, x):
         P, lib, dt = self.params, self.lib, self.dt
         nm = self._block_names(blk)
@@ -978,11 +919,7 @@ class Engine:
         if not gg:
             self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                      _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
-        if rs_n == "plain":
-            self._rs(lst, tag + ":pw2", 2, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["z"],
-                     W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], out=blk["out"], R=x,
-                     act=act)
-        elif self._mx_block(blk):
+        if self._mx_block(blk):
             qz, qw = self._mx_buf(tag + ".z", M, H), self._mx_weight(tag + ".W2")
             self._quant(lst, tag + ":z.quant", blk["z"], H, qz)
             self._gemm_mx(lst, tag + ":pw2", "RESID", qz, qw, bias=P[nm["b2"]], C=blk["out"], R=x, M=M, N=Cc, K=H, ldc=Cc, ldr=Cc, act=act)
@@ -1083,10 +1020,6 @@ class Engine:
                      **(dict(fin_sum=blk["S1"], fin_sum0=blk["S0"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"],
                              fin_ainv=blk["Ainv"], fin_out=blk["coef"], fin_dgamma=Gd[nm["gg"]],
                              fin_dbeta=Gd[nm["gb"]]) if fold else {}))
-        elif rs_n == "plain":   # pwconv1 data gradient + LayerNorm backward (dd, dgamma, dbeta) in one kernel
-            self._rs(lst, tag + ":pw1.dgrad+ln.bwd", 3, blk, (M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=dz,
-                     W=w1t["t"], ldw=w1t["ld"], out=dd, xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act,
-                     s0=Gd[nm["ln_w"]], s1=Gd[nm["ln_b"]])
         elif self._mx_block(blk):
             qd, qw = self._mx_buf(tag + ".dh", M, H), self._mx_weight(tag + ".W1T")
             self._quant(lst, tag + ":dh.quant", dz, H, qd)
@@ -1667,13 +1600,7 @@ class Engine:
         other = ring[ri]
         bi = len(self.blocks) - 1
         for i in range(3, -1, -1):
-            if self._ps_ok(i) and bool(self.opt["ps_bwd"]):
-                d = cfg.depths[i]
-                cur, ri = self._stage_bwd_ps(b, i, self.blocks[bi - d + 1:bi + 1], cur, ring, ri)
-                other = ring[ri]
-                bi -= d
-            else:
-              for j in range(cfg.depths[i] - 1, -1, -1):
+            for j in range(cfg.depths[i] - 1, -1, -1):
                 blk = self.blocks[bi]
                 nxt = other[:blk["M"] * blk["C"]]
                 self._block_bwd(b, blk, cur, nxt)

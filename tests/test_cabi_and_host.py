@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(tmp_path):
                  MpmaePixContArgs=_lib.PixContArgs, MpmaePixCatArgs=_lib.PixCatArgs, MpmaeImgArgs=_lib.ImgArgs,
                  MpmaeRsArgs=_lib.RsArgs, MpmaeStemTailArgs=_lib.StemTailArgs,
                  MpmaePsBlock=_lib.PsBlock, MpmaePsArgs=_lib.PsArgs,
-                 MpmaePsBwdBlock=_lib.PsBwdBlock, MpmaePsBwdArgs=_lib.PsBwdArgs, MpmaeMeters=_lib.Meters,
+                 MpmaeMeters=_lib.Meters,
                  MpmaeStemFrontArgs=_lib.StemFrontArgs)
     src = tmp_path / "sz.c"
     body = "\n".join(f'  printf("{n} %zu\\n", sizeof({n}));' for n in names)
