@@ -42,10 +42,92 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
   return (int)hipErrorInvalidValue;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Vendor BLAS for PLAIN dense GEMMs (MPMAE_OPT_BLASLT). profiles/r04/blas_yardstick.txt: on the dense decoder / head shapes with a deep
+// K or a wide N (M = 12 544; N = 512, K = 2048: 33 vs 59 us; heads N = 1920, K = 512: 42 vs 70 us; their data gradients 30-33 vs 48-54 us)
+// hipBLASLt's macro-tile kernels run at 0.6-0.8 PF/s where gemm_nt_bf16_kernel's 128 x 128 tiles sit at the LDS-read limit of a
+// 64 x 64 wave tile (0.45 PF/s). Only launches that are a library GEMM go there: bf16, no prologue, epilogue = (+ bias) (+ residual),
+// no activity mask; everything fused (LayerNorm / GRN prologues, statistics epilogues, gathers) stays on this library's kernels.
+// Row-major C[M][N] = A[M][K] W[N][K]^T is the column-major product C^T = W^T-stored-as-[K x N] (op T) x A-stored-as-[K x M] (op N).
+// No workspace is granted (two lanes may run such a GEMM at the same time). Plans are cached per call site.
+// ------------------------------------------------------------------------------------------
+#include <hipblaslt/hipblaslt.h>
+#include <array>
+#include <map>
+#include <mutex>
+struct LtPlan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  bool ok = false;
+};
+static hipblasLtHandle_t g_lt = nullptr;
+static std::mutex g_lt_mu;
+static std::map<std::array<long long, 10>, LtPlan> g_lt_plans;
+
+static const LtPlan* lt_plan(const GemmP& a, bool resid) {
+  std::lock_guard<std::mutex> lock(g_lt_mu);
+  const std::array<long long, 10> key = {a.M, a.N, a.K, a.lda, a.ldb, a.ldc, resid ? a.ldr : 0, resid ? 1 : 0,
+                                         (long long)(uintptr_t)a.bias, 0};
+  auto it = g_lt_plans.find(key);
+  if (it != g_lt_plans.end()) return it->second.ok ? &it->second : nullptr;
+  LtPlan& pl = g_lt_plans[key];
+  if (!g_lt && hipblasLtCreate(&g_lt) != HIPBLAS_STATUS_SUCCESS) { g_lt = nullptr; return nullptr; }
+  if (hipblasLtMatmulDescCreate(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  const int32_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
+  bool good = hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS &&
+              hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) == HIPBLAS_STATUS_SUCCESS;
+  if (a.bias) {
+    const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
+    const int32_t btype = HIP_R_32F;
+    const void* bp = a.bias;
+    good = good && hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &btype, sizeof(btype)) == HIPBLAS_STATUS_SUCCESS &&
+           hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) == HIPBLAS_STATUS_SUCCESS;
+  }
+  good = good && hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, a.K, a.N, a.ldb) == HIPBLAS_STATUS_SUCCESS &&
+         hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, a.K, a.M, a.lda) == HIPBLAS_STATUS_SUCCESS &&
+         hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, a.N, a.M, resid ? a.ldr : a.ldc) == HIPBLAS_STATUS_SUCCESS &&
+         hipblasLtMatrixLayoutCreate(&pl.ld, HIP_R_16BF, a.N, a.M, a.ldc) == HIPBLAS_STATUS_SUCCESS;
+  if (!good) return nullptr;
+  hipblasLtMatmulPreference_t pref = nullptr;
+  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  const uint64_t wsmax = 0;
+  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
+  hipblasLtMatmulHeuristicResult_t res[8];
+  int n = 0;
+  const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_lt, pl.desc, pl.la, pl.lb, pl.lc, pl.ld, pref, 8, res, &n);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  for (int i = 0; i < n; ++i)
+    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize == 0) { pl.algo = res[i].algo; pl.ok = true; break; }
+  return pl.ok ? &pl : nullptr;
+}
+
+// 0 = issued (or recorded), -1 = not a library GEMM / no plan: the caller falls through to this library's kernels
+static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) {
+  if (!g_opt[MPMAE_OPT_BLASLT] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || a.act) return -1;
+  if (a.M < 4096 || a.N < 256 || a.K < 256 || (long long)a.N * a.K < 512LL * 1024) return -1;
+  if (((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) || (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15)) return -1;
+  const bool resid = epi == EPI_RESID;
+  if (resid && (!a.R || (a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
+  const LtPlan* pl = lt_plan(a, resid);
+  if (!pl) return -1;
+  const void* A = a.A; const void* W = a.B; const void* R = resid ? a.R : a.C; void* D = a.C;
+  submit(st, [=](hipStream_t s_) {
+    const float alpha = 1.f, beta = resid ? 1.f : 0.f;
+    const hipblasStatus_t e = hipblasLtMatmul(g_lt, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, nullptr, 0, s_);
+    if (e != HIPBLAS_STATUS_SUCCESS && !g_launch_err) g_launch_err = 100000 + (int)e;
+  });
+  return launch_status();
+}
+
 int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t s) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
+  { const int r = try_blaslt(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
   const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);
   const bool single = stats && args->rpg >= args->M;
