@@ -44,13 +44,14 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
 
 
 // ------------------------------------------------------------------------------------------
-// Vendor BLAS for PLAIN dense GEMMs (MPMAE_OPT_BLASLT). profiles/r04/blas_yardstick.txt: on the dense decoder / head shapes with a deep
-// K or a wide N (M = 12 544; N = 512, K = 2048: 33 vs 59 us; heads N = 1920, K = 512: 42 vs 70 us; their data gradients 30-33 vs 48-54 us)
-// hipBLASLt's macro-tile kernels run at 0.6-0.8 PF/s where gemm_nt_bf16_kernel's 128 x 128 tiles sit at the LDS-read limit of a
-// 64 x 64 wave tile (0.45 PF/s). Only launches that are a library GEMM go there: bf16, no prologue, epilogue = (+ bias) (+ residual),
-// no activity mask; everything fused (LayerNorm / GRN prologues, statistics epilogues, gathers) stays on this library's kernels.
+// Vendor BLAS for PLAIN dense GEMMs (MPMAE_OPT_BLASLT). profiles/r04/blas_yardstick.txt measures hipBLASLt on every GEMM shape of the
+// step next to this library's kernels: ours are ahead on 12 of 16 (every weight gradient, every fused pointwise product, the
+// 256 x 256-tile shapes), the vendor's deep-K kernels are ahead on the dense decoder's N = 512, K = 2048 products and the pixel heads
+// (M = 12 544: 32-41 us against 48-59 us of gemm_nt_bf16_kernel, whose 64 x 64 wave tiles sit at the LDS-read limit - 0.45 PF/s).
+// Only launches that ARE a library GEMM go there: bf16, no prologue, epilogue = (+ bias) (+ residual), no activity mask; everything
+// fused (LayerNorm / GRN prologues, statistics epilogues, gathers, masks) stays on this library's kernels.
 // Row-major C[M][N] = A[M][K] W[N][K]^T is the column-major product C^T = W^T-stored-as-[K x N] (op T) x A-stored-as-[K x M] (op N).
-// No workspace is granted (two lanes may run such a GEMM at the same time). Plans are cached per call site.
+// Plans (descriptor + heuristic's first workspace-free algorithm) are cached per call site.
 // ------------------------------------------------------------------------------------------
 #include <hipblaslt/hipblaslt.h>
 #include <array>
@@ -60,6 +61,7 @@ struct LtPlan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
   hipblasLtMatmulAlgo_t algo;
+  void* ws = nullptr; size_t ws_bytes = 0;      // owned by the plan (= call site): such GEMMs are all issued on ONE lane, in order
   bool ok = false;
 };
 static hipblasLtHandle_t g_lt = nullptr;
@@ -69,7 +71,7 @@ static std::map<std::array<long long, 10>, LtPlan> g_lt_plans;
 static const LtPlan* lt_plan(const GemmP& a, bool resid) {
   std::lock_guard<std::mutex> lock(g_lt_mu);
   const std::array<long long, 10> key = {a.M, a.N, a.K, a.lda, a.ldb, a.ldc, resid ? a.ldr : 0, resid ? 1 : 0,
-                                         (long long)(uintptr_t)a.bias, 0};
+                                         (long long)(uintptr_t)a.bias, g_opt[MPMAE_OPT_BLASLT]};
   auto it = g_lt_plans.find(key);
   if (it != g_lt_plans.end()) return it->second.ok ? &it->second : nullptr;
   LtPlan& pl = g_lt_plans[key];
@@ -93,15 +95,21 @@ static const LtPlan* lt_plan(const GemmP& a, bool resid) {
   if (!good) return nullptr;
   hipblasLtMatmulPreference_t pref = nullptr;
   if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;
-  const uint64_t wsmax = 0;
+  const uint64_t wsmax = g_opt[MPMAE_OPT_BLASLT] >= 2 ? (uint64_t)64 << 20 : 0;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
-  hipblasLtMatmulHeuristicResult_t res[8];
+  constexpr int NCAND = 8;
+  hipblasLtMatmulHeuristicResult_t res[NCAND];
   int n = 0;
-  const hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(g_lt, pl.desc, pl.la, pl.lb, pl.lc, pl.ld, pref, 8, res, &n);
+  const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(g_lt, pl.desc, pl.la, pl.lb, pl.lc, pl.ld, pref, NCAND, res, &n);
   hipblasLtMatmulPreferenceDestroy(pref);
-  if (st != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  if (hs != HIPBLAS_STATUS_SUCCESS) return nullptr;
+  // (timing every workspace-free candidate once per call site and keeping the fastest was tried: the heuristic's first choice is already it)
   for (int i = 0; i < n; ++i)
-    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize == 0) { pl.algo = res[i].algo; pl.ok = true; break; }
+    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= wsmax) {
+      if (res[i].workspaceSize > 0 && hipMalloc(&pl.ws, res[i].workspaceSize) != hipSuccess) { pl.ws = nullptr; continue; }
+      pl.ws_bytes = res[i].workspaceSize; pl.algo = res[i].algo; pl.ok = true;
+      break;
+    }
   return pl.ok ? &pl : nullptr;
 }
 
@@ -109,6 +117,8 @@ static const LtPlan* lt_plan(const GemmP& a, bool resid) {
 static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) {
   if (!g_opt[MPMAE_OPT_BLASLT] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || a.act) return -1;
   if (a.M < 4096 || a.N < 256 || a.K < 256 || (long long)a.N * a.K < 512LL * 1024) return -1;
+  if (g_opt[MPMAE_OPT_BLASLT] < 3 && g_opt[MPMAE_OPT_NT4] && a.M >= 8192 && a.N >= 1024 && a.N <= 2048 && a.N % 256 == 0 && a.K % 64 == 0 && a.K <= 1024)
+    return -1;      // the 256 x 256-tile kernel of gemm_nt4.cuh holds its own there (64 vs 67 us, 60 vs 65 us stand-alone)
   if (((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) || (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15)) return -1;
   const bool resid = epi == EPI_RESID;
   if (resid && (!a.R || (a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
@@ -117,7 +127,7 @@ static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) 
   const void* A = a.A; const void* W = a.B; const void* R = resid ? a.R : a.C; void* D = a.C;
   submit(st, [=](hipStream_t s_) {
     const float alpha = 1.f, beta = resid ? 1.f : 0.f;
-    const hipblasStatus_t e = hipblasLtMatmul(g_lt, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, nullptr, 0, s_);
+    const hipblasStatus_t e = hipblasLtMatmul(g_lt, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, pl->ws, pl->ws_bytes, s_);
     if (e != HIPBLAS_STATUS_SUCCESS && !g_launch_err) g_launch_err = 100000 + (int)e;
   });
   return launch_status();
