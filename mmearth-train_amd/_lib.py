@@ -261,6 +261,10 @@ def load():
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    # The library shares streams and device pointers with PyTorch, so both must sit on ONE HIP runtime (and one hipBLASLt): PyTorch ships
+    # its own copies under torch/lib with the same sonames as ROCm's - whichever is loaded first serves both. Import torch first so that
+    # the order (and therefore the copy) is always the same, whatever the caller imported before.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SYMBOLS.items():
         fn = getattr(lib, name)       # AttributeError if the symbol is not exported
