@@ -12,7 +12,6 @@
 #include "rows2.cuh"
 #include "dwconv6.cuh"
 #include "stemtail.cuh"
-#include "dwband.cuh"
 #include "dwmfma.cuh"
 #include "dwmfma_wg.cuh"
 
@@ -387,19 +386,6 @@ static bool dw_v4_ok(int C, int S) {
   return C % (64 / S) == 0;
 }
 
-template <int S, int C, int BR>
-static int launch_dw_band(const DwP& a, hipStream_t st) {
-  using D = DwBand<S, C, BR>;
-  static bool once = false;
-  if (!once) {
-    if (hipFuncSetAttribute((const void*)dwconv7_band_kernel<S, C, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D::LDS) != hipSuccess)
-      return (int)hipGetLastError();      // (launch_status() only reports LAUNCH errors: it would return success without a launch)
-    once = true;
-  }
-  LAUNCH((dwconv7_band_kernel<S, C, BR>), dim3(a.g.N, cdiv(a.g.grid, BR)), dim3(512), D::LDS, st, a);
-  return launch_status();
-}
-
 template <int S, int CCH>
 static int launch_dw_mfma(const DwP& a, hipStream_t st) {
   using D = DwMfma<S, CCH>;
@@ -432,12 +418,6 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (dt == 1 && dw_variant() >= 8) {
     const int r = try_dw_mfma(*a, S_(s));
     if (r >= 0) return r;
-  }
-  if (dt == 1 && dw_variant() >= 7 && a->g.grid == 7 && a->g.inv && (((uintptr_t)a->x | (uintptr_t)a->out | (uintptr_t)a->add) & 15) == 0) {
-    // band kernel (dwband.cuh): (sample, patch row) per workgroup, all channels, whole-line loads. Measured at bs 256: stage 0
-    // (S = 8, C = 40) 47 / 60 us forward / data gradient against 60 / 67 us for the per-sample kernels; at stage 1 (S = 4, C = 80)
-    // it LOSES (36 / 40 vs 25 / 27 us) and with two patch rows per workgroup (one workgroup per CU) it loses everywhere
-    if (a->g.S == 8 && a->C == 40) return launch_dw_band<8, 40, 1>(*a, S_(s));
   }
   if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
       (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->out | (uintptr_t)a->add) & 3) == 0) {

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void dwconv7_v5_kernel(const DwP p) {
       float w7[7];
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) w7[ky] = wl[(ky * 7 + kx) * CW + cw];
-      float col[S + 6];      // the whole input column first: independent LDS reads in flight (see dwband.cuh)
+      float col[S + 6];      // the whole input column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
       for (int y = 0; y < S + 6; ++y) col[y] = ldf<T>(tile + (y * MS + ox + kx) * CW + cw);
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q, co
         if (kx > 0)
           asm volatile("" : "+v"(toff) : "v"(adw[kx - 1]), "v"(adw[7 + kx - 1]), "v"(adw[14 + kx - 1]),
                        "v"(adw[21 + kx - 1]), "v"(adw[28 + kx - 1]), "v"(adw[35 + kx - 1]), "v"(adw[42 + kx - 1]) : "memory");
-        float col[S + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+        float col[S + 6];      // column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
         for (int y = 0; y < S + 6; ++y) col[y] = ldf<T>(tile + toff + (y * MS + ox + kx) * CW + cw);
 #pragma unroll

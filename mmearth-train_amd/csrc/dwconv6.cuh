@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
       f32x2_t w7[7];
 #pragma unroll
       for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
-      uint32_t raw[S + 6];      // the whole input column first: S + 6 independent LDS reads in flight (see dwband.cuh)
+      uint32_t raw[S + 6];      // the whole input column first: S + 6 independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
       for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW);
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v6_kernel(const DwWgP q) {
         if (kx > 0)
           asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
                        "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
-        uint32_t raw[S + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+        uint32_t raw[S + 6];      // column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
         for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW);
 #pragma unroll
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
     f32x2_t w7[7];
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) w7[ky] = *reinterpret_cast<const f32x2_t*>(wl + (ky * 7 + kx) * CW + 2 * cp);
-    uint32_t raw[G + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+    uint32_t raw[G + 6];      // column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
     for (int y = 0; y < G + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + (y * MS + kx) * CW);
 #pragma unroll
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void dwconv7_wgrad_v6s1_kernel(const DwWgP q, 
       if (kx > 0)
         asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
                      "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
-      uint32_t raw[G + 6];      // column first: independent LDS reads in flight (see dwband.cuh)
+      uint32_t raw[G + 6];      // column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
 #pragma unroll
       for (int y = 0; y < G + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW);
 #pragma unroll

@@ -5,7 +5,7 @@
 // map for every patch of every sample. So per channel
 //      D[i = output point of the patch][n = patch] = sum_k  A_c[i][k = window point] * B_c[k][n]
 // with A_c the (2-D Toeplitz) matrix of channel c's 49 taps and B_c the windows of 16 patches in channel-PLANAR form. 49 of the
-// 128 products of a row are real taps: 38 % of 2.5 PFLOP/s against the VALU kernels' 22-25 TFLOP/s (dwband.cuh / dwconv6.cuh:
+// 128 products of a row are real taps: 38 % of 2.5 PFLOP/s against the VALU kernels' 22-25 TFLOP/s (dwconv6.cuh:
 // 4 vector instructions per multiply-add).
 //
 //   S = 8: an MFMA row block is two output rows (16 points), its k range the 8 window rows x 16 columns they see = 4 k-steps of

@@ -16,7 +16,7 @@ import sys
 FAMILIES = collections.OrderedDict([
     ("rs", r"rsc_wide_kernel|rsc_narrow_kernel|rs_kernel|reduce_partials_kernel<0>|reduce_partials_kernel<1>"),
     ("wgrad", r"gemm_tn2_kernel|gemm_tn3_kernel|gemm_tng_kernel|gemm_tng48_kernel|gemm_tn_bf16_kernel|wgrad_kernel|wgrad_group_fold_kernel|reduce_partials_kernel<3>"),
-    ("dwconv7", r"dwconv7_mfma_kernel|dwconv7_band_kernel|dwconv7_v6_kernel|dwconv7_v6s1_kernel|dwconv7_v5_kernel"),
+    ("dwconv7", r"dwconv7_mfma_kernel|dwconv7_v6_kernel|dwconv7_v6s1_kernel|dwconv7_v5_kernel"),
     ("dwconv7_wgrad", r"dwconv7_wgrad|reduce_partials_kernel<2>|reduce_partials_group2_kernel"),
     ("ps_fwd", r"ps_fwd_kernel"),
     ("gemm_nt", r"gemm_nt_bf16_kernel|gemm_nt4_kernel|gemm_nt3_kernel|gemm_kernel|^Cijk_|Cijk_Alik"),      # (Cijk_*: hipBLASLt kernels of the plain decoder / head GEMMs)
