@@ -9,6 +9,7 @@
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
 #include "gemm_nt4.cuh"
+#include "gemm_nt5.cuh"
 #include "grn_group.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
@@ -133,10 +134,29 @@ static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) 
   return launch_status();
 }
 
+// deep-K NT kernel (gemm_nt5.cuh): plain products with K >= 1024 (MPMAE_OPT_NT5); -1 = not taken
+static int try_nt5(int dt, int pro, int epi, const GemmP& a0, hipStream_t st) {
+  if (!g_opt[MPMAE_OPT_NT5] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID)) return -1;
+  if (a0.M < 2048 || a0.N < 256 || a0.K < 1024 || (a0.K % NT5_BK) || ((a0.N | a0.lda | a0.ldb | a0.ldc) & 7)) return -1;
+  if (((uintptr_t)a0.A | (uintptr_t)a0.B | (uintptr_t)a0.C) & 15) return -1;
+  GemmP a = a0;
+  if (epi == EPI_STORE) a.R = nullptr;
+  if (a.R && ((a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_nt5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT5_LDS) != hipSuccess) return (int)hipGetLastError();
+    attr = true;
+  }
+  const int mtiles = cdiv(a.M, NT5_BM), ntiles = cdiv(a.N, NT5_BN);
+  LAUNCH(gemm_nt5_kernel, dim3(8 * cdiv(mtiles, 8) * ntiles), dim3(256), NT5_LDS, st, a, mtiles, ntiles);
+  return launch_status();
+}
+
 int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t s) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
+  { const int r = try_nt5(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   { const int r = try_blaslt(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
   const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);

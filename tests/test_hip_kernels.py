@@ -497,3 +497,46 @@ def test_dz_recomputation_matches_the_materialised_path(M, Cc):
     hf, r_dz = h.float(), (dout.float() @ W2T.float().t()).to(bf)
     r_dh = ((r_dz.float() * scale + coef * _gelu(hf)) * _dgelu(hf)).to(bf)
     assert _rel(dh1, r_dh) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,N,K,resid,bias_on,act_on", [(12544, 512, 2048, True, True, False), (4100, 392, 1408, True, True, True),
+                                                        (3584, 320, 1280, False, False, True), (8200, 520, 2816, False, True, False)])
+def test_deep_k_ring_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
+    """MPMAE_OPT_NT5 = 1 (not the default): the deep-K NT kernel of csrc/gemm_nt5.cuh - 128 x 256 tile, 64 x 128 wave tiles, three-stage
+    DMA ring with counted vmcnt waits and inline-asm fragment reads, XCD-aware tile order - on plain products with K >= 1024: ragged
+    last row / column tiles, optional bias / residual / row mask; against an fp32 matmul of the same bf16 operands and within one bf16
+    ulp of the 128 x 128 kernel (same rounding contract: one bf16 rounding of the fp32 sum)."""
+    L, lib = _lib()
+    dev = "cuda"
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device=dev).to(bf)
+    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
+    bias = torch.randn(N, device=dev)
+    r = torch.randn(M, N, device=dev).to(bf)
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    g = L.GemmArgs()
+    g.A, g.B = a.data_ptr(), w.data_ptr()
+    g.bias = bias.data_ptr() if bias_on else 0
+    g.act = act.data_ptr() if act_on else 0
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
+    if resid:
+        g.R, g.ldr = r.data_ptr(), N
+    outs = []
+    for nt5 in (1, 0):
+        c = torch.full((M, N), 7.0, device=dev, dtype=bf)
+        g.C = c.data_ptr()
+        assert lib.mpmae_set_option(L.OPT["NT5"], nt5) == 0 and lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0
+        try:
+            assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+        finally:
+            lib.mpmae_set_option(L.OPT["NT5"], 0)
+            lib.mpmae_set_option(L.OPT["BLASLT"], 1)
+        torch.cuda.synchronize()
+        outs.append(c)
+    ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
+    if act_on:
+        ref = ref * act.bool()[:, None]
+        assert (outs[0][~act.bool()] == 0).all()
+    assert _rel(outs[0], ref) < 6e-3
+    d = (outs[0].float() - outs[1].float()).abs()
+    assert (d <= 2.0 ** -7 * outs[1].float().abs() + 1e-6).all(), float(d.max())
