@@ -48,7 +48,8 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
 // Vendor BLAS for PLAIN dense GEMMs (MPMAE_OPT_BLASLT). profiles/r04/blas_yardstick.txt measures hipBLASLt on every GEMM shape of the
 // step next to this library's kernels: ours are ahead on 12 of 16 (every weight gradient, every fused pointwise product, the
 // 256 x 256-tile shapes), the vendor's deep-K kernels are ahead on the dense decoder's N = 512, K = 2048 products and the pixel heads
-// (M = 12 544: 32-41 us against 48-59 us of gemm_nt_bf16_kernel, whose 64 x 64 wave tiles sit at the LDS-read limit - 0.45 PF/s).
+// (M = 12 544: 32-41 us against 48-59 us of gemm_nt_bf16_kernel, 0.45-0.6 PF/s: 128 x 128 tiles move 1.27x the operand bytes of the vendor's
+// 128 x 256 tiles through the same ~9-10 TB/s of L2 -> LDS fill, and whole tiles leave CUs idle where the vendor's stream-K schedule does not).
 // Only launches that ARE a library GEMM go there: bf16, no prologue, epilogue = (+ bias) (+ residual), no activity mask; everything
 // fused (LayerNorm / GRN prologues, statistics epilogues, gathers, masks) stays on this library's kernels.
 // Row-major C[M][N] = A[M][K] W[N][K]^T is the column-major product C^T = W^T-stored-as-[K x N] (op T) x A-stored-as-[K x M] (op N).

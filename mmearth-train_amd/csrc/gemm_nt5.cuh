@@ -3,9 +3,10 @@
 // models/fcmae.py:126-151.)
 //
 // Why another NT kernel: profiles/r04/blas_yardstick.txt. On these shapes the vendor library runs at 0.8-0.9 PF/s and the 128 x 128
-// kernel of gemm_fast.cuh at 0.45: its 64 x 64 wave tiles issue two MFMAs per 16-byte LDS fragment read (the LDS-read limit), it
-// prefetches ONE 64-deep slab ahead and every __syncthreads() of its K loop is also an s_waitcnt vmcnt(0). This kernel takes the two
-// structural points of the vendor's choice for the shape (MT128x256x64, wave tile 64 x 128) and the slab ring of gemm_tn3.cuh:
+// kernel of gemm_fast.cuh at 0.45-0.6. Both pull operands L2 -> LDS at the same ~9-10 TB/s ("The operand-fill
+// ceiling, re-derived"); the vendor's kernel for the shape (MT128x256x64, wave tile 64 x 128, stream-K) moves 1.27x fewer bytes per flop
+// and keeps every CU pulling. This kernel takes the tile and the slab ring of gemm_tn3.cuh; the stream-K schedule is NOT here yet
+// (196 tiles on 256 CUs for N = 512: 0.57 PF/s, which is why MPMAE_OPT_NT5 is off by default):
 //   * 128 x 256 tile, 4 waves (2 x 2), wave tile 64 rows x 128 columns: 12 fragment reads feed 32 MFMAs per 32-deep k-step
 //     (2.67 MFMAs per read instead of 2) and a wave issues 64 MFMAs per barrier;
 //   * both operand slabs go global -> LDS by DMA (global_load_lds_dwordx4) into a ring of THREE 64-deep stages (3 x 48 KB): two
