@@ -68,6 +68,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC_W5 */ 1,
     /* MPMAE_OPT_BLASLT */ 1,
     /* MPMAE_OPT_NT5 */ 0,
+    /* MPMAE_OPT_RSC_ATOMIC */ 0,
 };
 
 int mpmae_set_option(int option, int value) {

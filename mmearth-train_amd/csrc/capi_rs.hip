@@ -19,6 +19,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
   p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
   p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
+  p.s0a = nullptr; p.s1a = nullptr;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
@@ -34,18 +35,22 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     constexpr int KP = ((KC + 31) / 32) * 32;
     const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)2 * cps * 4;
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
-    if (!a.ws || a.ws_floats < need || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+    // MPMAE_OPT_RSC_ATOMIC = largest row-block count whose statistics are accumulated with atomics instead of slab + fold launch
+    const bool at = rowblocks <= g_opt[MPMAE_OPT_RSC_ATOMIC] && a.s0 && (which == 0 || a.s1);
+    if (at) { p.s0a = a.s0; p.s1a = a.s1; }
+    if ((!at && (!a.ws || a.ws_floats < need)) || lds > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
     dim3 g(rowblocks, nsplit);
     if (which == 0) {
       static size_t cur = 64 * 1024;
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 0, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
       LAUNCH((rsc_wide_kernel<KC, 0, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
-      launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+      if (!at) launch_reduce(0, a.ws, rowblocks, HN, a.s0, nullptr, 0, 0, 0, 0, st);
     } else {
       static size_t cur = 64 * 1024;
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_wide_kernel<KC, 1, RT, NC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; }
       LAUNCH((rsc_wide_kernel<KC, 1, RT, NC>), g, dim3(256), lds, st, p, HN, cps);
-      if (a.s1 == a.s0 + HN) {        // adjacent outputs (the engine's layout): one launch over [2*HN]
+      if (at) {
+      } else if (a.s1 == a.s0 + HN) {        // adjacent outputs (the engine's layout): one launch over [2*HN]
         launch_reduce(0, a.ws, rowblocks, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
       } else {                        // e = which*HN + j -> which == 0 ? s0[j] : s1[j]
         const long long delta = a.s1 - a.s0;

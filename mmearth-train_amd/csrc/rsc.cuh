@@ -234,6 +234,15 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
     __syncthreads();
   }
   // slab row of a workgroup: MODE 0 [HN]; MODE 1 [2][HN] (sum dz | sum dz*gelu(h)) so ONE second-stage launch folds both
+  if (p.s0a) {
+    // few row blocks (stages 2-3: <= a few hundred adds per column): the statistics go straight into the zero-initialised accumulators of
+    // the step with hardware float atomics - the second-stage launch (5-6 us on the main lane, 10 per step) disappears
+    for (int i = tid; i < cols_per_split; i += 256) {
+      (void)unsafeAtomicAdd(p.s0a + n_begin + i, red[i]);
+      if (MODE == 1) (void)unsafeAtomicAdd(p.s1a + n_begin + i, red[cols_per_split + i]);
+    }
+    return;
+  }
   for (int i = tid; i < cols_per_split; i += 256) {
     if (MODE == 0) p.ws[(size_t)blockIdx.x * HN + n_begin + i] = red[i];
     else {
