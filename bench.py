@@ -115,9 +115,9 @@ def family_of(kind):
 FAMILY_SYMBOLS = {
     "rs": ("rsc_wide_kernel", "rsc_narrow_kernel"),
     "wgrad": ("gemm_tn2_kernel", "gemm_tn3_kernel", "gemm_tng_kernel", "gemm_tn_bf16_kernel"),
-    "dwconv7": ("dwconv7_band_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
-    "dwconv7_wgrad": ("dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
-    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt4_kernel", "gemm_nt3_kernel"),
+    "dwconv7": ("dwconv7_mfma_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
+    "dwconv7_wgrad": ("dwconv7_wgrad_mfma_kernel", "dwconv7_wgrad_mfma4_kernel", "dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
+    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt4_kernel", "gemm_nt3_kernel", "Cijk_* (hipBLASLt: four plain decoder / head products)"),
     "ps_fwd": ("ps_fwd_kernel",),
 }
 FAMILY_TEXT = {
@@ -126,8 +126,8 @@ FAMILY_TEXT = {
     "wgrad": "weight-gradient GEMMs dW = P^T Q (transpose-read, DMA-ring and grouped kernels) with their slab folds",
     "dwconv7": "depthwise 7x7 forward / data gradient",
     "dwconv7_wgrad": "depthwise 7x7 weight gradient with its folds",
-    "gemm_nt": "dense NT GEMMs (decoder block, heads, downsample, stage-3 pointwise)",
-    "ps_fwd": "persistent per-sample stage kernels (all blocks of stage 2 / 3 forward)",
+    "gemm_nt": "dense NT GEMMs (decoder block, heads, downsample, stage-3 pointwise; four plain ones through hipBLASLt)",
+    "ps_fwd": "persistent per-sample stage kernel (all blocks of stage 2 forward; stage 3 with ps = 3)",
 }
 
 
