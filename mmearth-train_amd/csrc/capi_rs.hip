@@ -33,7 +33,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
     constexpr int KP = ((KC + 31) / 32) * 32;
-    const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)2 * cps * 4;
+    const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)4 * 2 * cps * 4;      // weight chunks + per-wave statistic rows
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
     // MPMAE_OPT_RSC_ATOMIC = largest row-block count whose statistics are accumulated with atomics instead of slab + fold launch
     const bool at = rowblocks <= g_opt[MPMAE_OPT_RSC_ATOMIC] && a.s0 && (which == 0 || a.s1);

@@ -61,13 +61,15 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   static_assert(KC % 8 == 0 && ((KP / 8) & 1) == 0, "LDS rows must be an odd multiple of 16 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
   bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                   // [2][NC][LDW]
-  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NC * LDW * sizeof(bf16_t));   // [2][cols_per_split]
+  float* red = reinterpret_cast<float*>(rsc_smem + (size_t)2 * NC * LDW * sizeof(bf16_t));   // [4 waves][2][cols_per_split]: every wave
+  // visits each column of the split exactly once, so its column sums are plain stores into its own row and the four rows are added in
+  // a fixed order at the end (LDS float atomics from four waves made the statistics - and everything behind them - differ from run to run)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
   const int n_begin = blockIdx.y * cols_per_split;
   const int nch = cols_per_split / NC;
-  for (int i = tid; i < 2 * cols_per_split; i += 256) red[i] = 0.f;
+  float* redw = red + (size_t)wave * 2 * cols_per_split;
 
   uint4 wr[WV];
   auto wload = [&](int c) {
@@ -223,10 +225,10 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = sum16(cs0[e]);
-        if (lr == 0) atomicAdd(&red[nl + e], a);
+        if (lr == 0) redw[nl + e] = a;
         if (MODE == 1) {
           const float b = sum16(cs1[e]);
-          if (lr == 0) atomicAdd(&red[cols_per_split + nl + e], b);
+          if (lr == 0) redw[cols_per_split + nl + e] = b;
         }
       }
     }
@@ -237,17 +239,21 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   if (p.s0a) {
     // few row blocks (stages 2-3: <= a few hundred adds per column): the statistics go straight into the zero-initialised accumulators of
     // the step with hardware float atomics - the second-stage launch (5-6 us on the main lane, 10 per step) disappears
+    const int w2a = 2 * cols_per_split;
     for (int i = tid; i < cols_per_split; i += 256) {
-      (void)unsafeAtomicAdd(p.s0a + n_begin + i, red[i]);
-      if (MODE == 1) (void)unsafeAtomicAdd(p.s1a + n_begin + i, red[cols_per_split + i]);
+      (void)unsafeAtomicAdd(p.s0a + n_begin + i, ((red[i] + red[w2a + i]) + red[2 * w2a + i]) + red[3 * w2a + i]);
+      if (MODE == 1) (void)unsafeAtomicAdd(p.s1a + n_begin + i, ((red[cols_per_split + i] + red[w2a + cols_per_split + i]) + red[2 * w2a + cols_per_split + i]) + red[3 * w2a + cols_per_split + i]);
     }
     return;
   }
+  const int w2 = 2 * cols_per_split;
   for (int i = tid; i < cols_per_split; i += 256) {
-    if (MODE == 0) p.ws[(size_t)blockIdx.x * HN + n_begin + i] = red[i];
+    const float r0 = ((red[i] + red[w2 + i]) + red[2 * w2 + i]) + red[3 * w2 + i];
+    if (MODE == 0) p.ws[(size_t)blockIdx.x * HN + n_begin + i] = r0;
     else {
-      p.ws[(size_t)blockIdx.x * 2 * HN + n_begin + i] = red[i];
-      p.ws[(size_t)blockIdx.x * 2 * HN + HN + n_begin + i] = red[cols_per_split + i];
+      const float r1 = ((red[cols_per_split + i] + red[w2 + cols_per_split + i]) + red[2 * w2 + cols_per_split + i]) + red[3 * w2 + cols_per_split + i];
+      p.ws[(size_t)blockIdx.x * 2 * HN + n_begin + i] = r0;
+      p.ws[(size_t)blockIdx.x * 2 * HN + HN + n_begin + i] = r1;
     }
   }
 }

@@ -73,6 +73,7 @@ ENGINE_OPTIONS = dict(
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
+    det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
 
 
@@ -113,6 +114,9 @@ class Engine:
         unknown = set(self.opt) - set(ENGINE_OPTIONS)
         if unknown:
             raise KeyError(f"unknown engine options {sorted(unknown)}")
+        if self.opt["det"]:          # reproducible forward: ordered folds in the library (process-wide switch, read when the program is built), no persistent stage kernel
+            self.opt["ps"] = 0
+            _lib.check(self.lib.mpmae_set_option(_lib.OPT["DET"], 1), "set_option DET")
         self.cfg = cfg
         self.N = N = int(batch_size)
         # "fp8": the bf16 program with the decoder block's pointwise layers (K % 128 == 0) on the MX-fp8 MFMA path: e4m3
