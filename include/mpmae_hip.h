@@ -365,7 +365,7 @@ enum MpmaeOption {
   MPMAE_OPT_BLASLT,   /* default 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */
   MPMAE_OPT_NT5,   /* default 0: 1 = the deep-K NT kernel of gemm_nt5.cuh (128 x 256 tile, 64 x 128 wave tiles, 3-stage DMA ring with counted waits) for plain bf16 products with K >= 1024, N >= 256, M >= 2048 - row masks included - ahead of the vendor route */
   MPMAE_OPT_RSC_ATOMIC,   /* default 0: largest row-block count of a WIDE fused pointwise launch (mpmae_rs which = 0 / 1) whose GRN column statistics are added straight into s0 / s1 with hardware float atomics instead of slab rows + a second-stage fold launch (0 = never) */
-  MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical */
+  MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical; -1 = the pre-round-4 behaviour of the wide pointwise kernels everywhere (one shared LDS statistics row, float atomics between the waves) for A/B: by default a row per wave is used wherever it does not cost a resident workgroup per CU */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

@@ -21,7 +21,7 @@ void launch_reduce(int mode, const float* part, int P, int W, float* out, float*
   int R = P / 16;                 // >= 4 rows per thread (4 row lanes per block)
   if (R < 1) R = 1;
   if (R > 32) R = 32;
-  if (g_opt[MPMAE_OPT_DET]) R = 1;      // one row group per column block: plain `+=` in a fixed order instead of atomics between row groups
+  if (g_opt[MPMAE_OPT_DET] > 0) R = 1;      // one row group per column block: plain `+=` in a fixed order instead of atomics between row groups
   dim3 g(cdiv(W, 64), R);
   if (mode == 0) LAUNCH(reduce_partials_kernel<0>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
   else if (mode == 1) LAUNCH(reduce_partials_kernel<1>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);

@@ -19,7 +19,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
   p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
   p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
-  p.s0a = nullptr; p.s1a = nullptr;
+  p.s0a = nullptr; p.s1a = nullptr; p.perwave = 0;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
@@ -33,7 +33,13 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
     constexpr int KP = ((KC + 31) / 32) * 32;
-    const size_t lds = (size_t)2 * NC * (KP + RSC_PAD) * 2 + (size_t)4 * 2 * cps * 4;      // weight chunks + per-wave statistic rows
+    // weight chunks + statistic rows: one per wave (fixed summation order, no LDS atomics) unless that costs a resident workgroup per CU
+    // (tiny stage 2, C = 384: 53 -> 62 KB = 3 -> 2 workgroups per CU, +1.5 % on the step); MPMAE_OPT_DET forces the per-wave rows
+    const size_t lds_w = (size_t)2 * NC * (KP + RSC_PAD) * 2, lds1 = lds_w + (size_t)2 * cps * 4, lds4 = lds_w + (size_t)4 * 2 * cps * 4;
+    const size_t cap = 160 * 1024;
+    const int det = g_opt[MPMAE_OPT_DET];      // (-1: the shared row + LDS atomics everywhere, for A/B)
+    p.perwave = (det > 0 || (det == 0 && (cap / lds4 == cap / lds1 || cap / lds1 > 4))) ? 1 : 0;
+    const size_t lds = p.perwave ? lds4 : lds1;
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
     // MPMAE_OPT_RSC_ATOMIC = largest row-block count whose statistics are accumulated with atomics instead of slab + fold launch
     const bool at = rowblocks <= g_opt[MPMAE_OPT_RSC_ATOMIC] && a.s0 && (which == 0 || a.s1);

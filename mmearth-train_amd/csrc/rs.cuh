@@ -34,6 +34,7 @@ struct RsP {
   const bf16_t* D; const bf16_t* W2; int ldw2;     // rsc_narrow with operand recomputation: dout / xn [M][C], W2^T / W1 [H][ldw2]
   const float* hb;                                 // MODE 0: pwconv1 bias [H]
   float* s0a; float* s1a;                          // rsc_wide: accumulate the column statistics HERE with no-return float atomics (no slab, no fold launch)
+  int perwave;                                     // rsc_wide: one LDS statistics row per wave, added in a fixed order (0: one shared row, LDS float atomics)
 };
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(const float (&v)[8]) {

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   const int rbase = blockIdx.x * (64 * RT) + wave * (16 * RT);
   const int n_begin = blockIdx.y * cols_per_split;
   const int nch = cols_per_split / NC;
-  float* redw = red + (size_t)wave * 2 * cols_per_split;
+  float* redw = red + (p.perwave ? (size_t)wave * 2 * cols_per_split : 0);
+  if (!p.perwave) for (int i = tid; i < 2 * cols_per_split; i += 256) red[i] = 0.f;      // (the launcher falls back to one shared row + LDS atomics where
+                                                                                         //  the per-wave rows would cost a resident workgroup per CU)
 
   uint4 wr[WV];
   auto wload = [&](int c) {
@@ -225,10 +227,10 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float a = sum16(cs0[e]);
-        if (lr == 0) redw[nl + e] = a;
+        if (lr == 0) { if (p.perwave) redw[nl + e] = a; else atomicAdd(&redw[nl + e], a); }
         if (MODE == 1) {
           const float b = sum16(cs1[e]);
-          if (lr == 0) redw[cols_per_split + nl + e] = b;
+          if (lr == 0) { if (p.perwave) redw[cols_per_split + nl + e] = b; else atomicAdd(&redw[cols_per_split + nl + e], b); }
         }
       }
     }
@@ -239,19 +241,19 @@ __global__ __launch_bounds__(256) void rsc_wide_kernel(const RsP p, int HN_rt, i
   if (p.s0a) {
     // few row blocks (stages 2-3: <= a few hundred adds per column): the statistics go straight into the zero-initialised accumulators of
     // the step with hardware float atomics - the second-stage launch (5-6 us on the main lane, 10 per step) disappears
-    const int w2a = 2 * cols_per_split;
+    const int w2a = p.perwave ? 2 * cols_per_split : 0;
     for (int i = tid; i < cols_per_split; i += 256) {
-      (void)unsafeAtomicAdd(p.s0a + n_begin + i, ((red[i] + red[w2a + i]) + red[2 * w2a + i]) + red[3 * w2a + i]);
-      if (MODE == 1) (void)unsafeAtomicAdd(p.s1a + n_begin + i, ((red[cols_per_split + i] + red[w2a + cols_per_split + i]) + red[2 * w2a + cols_per_split + i]) + red[3 * w2a + cols_per_split + i]);
+      (void)unsafeAtomicAdd(p.s0a + n_begin + i, p.perwave ? ((red[i] + red[w2a + i]) + red[2 * w2a + i]) + red[3 * w2a + i] : red[i]);
+      if (MODE == 1) (void)unsafeAtomicAdd(p.s1a + n_begin + i, p.perwave ? ((red[cols_per_split + i] + red[w2a + cols_per_split + i]) + red[2 * w2a + cols_per_split + i]) + red[3 * w2a + cols_per_split + i] : red[cols_per_split + i]);
     }
     return;
   }
-  const int w2 = 2 * cols_per_split;
+  const int w2 = p.perwave ? 2 * cols_per_split : 0;
   for (int i = tid; i < cols_per_split; i += 256) {
-    const float r0 = ((red[i] + red[w2 + i]) + red[2 * w2 + i]) + red[3 * w2 + i];
+    const float r0 = p.perwave ? ((red[i] + red[w2 + i]) + red[2 * w2 + i]) + red[3 * w2 + i] : red[i];
     if (MODE == 0) p.ws[(size_t)blockIdx.x * HN + n_begin + i] = r0;
     else {
-      const float r1 = ((red[cols_per_split + i] + red[w2 + cols_per_split + i]) + red[2 * w2 + cols_per_split + i]) + red[3 * w2 + cols_per_split + i];
+      const float r1 = p.perwave ? ((red[cols_per_split + i] + red[w2 + cols_per_split + i]) + red[2 * w2 + cols_per_split + i]) + red[3 * w2 + cols_per_split + i] : red[cols_per_split + i];
       p.ws[(size_t)blockIdx.x * 2 * HN + n_begin + i] = r0;
       p.ws[(size_t)blockIdx.x * 2 * HN + HN + n_begin + i] = r1;
     }
