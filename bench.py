@@ -297,12 +297,14 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # HIP events on the launch stream
     if world > 1:
         trainer.measure_comm_tail = True        # two more events per step on the main stream (exposed_comm_tail_ms in the line)
+    vendor0 = int(eng.lib.mpmae_vendor_launches())
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
         trainer.step()
         marks[i + 1].record()
     torch.cuda.synchronize()
+    vendor_per_step = (int(eng.lib.mpmae_vendor_launches()) - vendor0) / a.steps
     if world > 1:
         mdist.barrier()
     torch.cuda.synchronize()
@@ -436,7 +438,9 @@ def main():
                                input_stage="outside the timed region of `value` (inputs and mask noise resident in HBM); "
                                            "ms_per_step_with_input_stage includes the D2D batch copy and device randn of every step, issued on an input stream "
                                            "behind the previous step's last reader of the input buffers (Engine.set_inputs_async)"),
-                   roofline=roof)
+                   roofline=roof,
+                   # kernels of a vendor library (hipBLASLt) inside the timed step: 0 with the default options since round 5
+                   vendor_kernels_per_step=vendor_per_step)
         if pieces:
             out["piece_times"] = pieces
         if world > 1:

@@ -22,8 +22,10 @@
  *   - the compute entry points allocate nothing and never synchronise the host: the caller owns all memory and passes
  *     workspace; work is enqueued on `stream` (a hipStream_t passed as void*). The library's only state is explicit:
  *     the process-wide option table (mpmae_set_option: developer A/B switches, defaults are the measured-best kernels), the
- *     launch-program handles a caller creates (mpmae_program_*: they own HIP events and side streams until destroyed), and a
- *     cached device-property query (CU count / resident workgroups of the persistent kernels);
+ *     launch-program handles a caller creates (mpmae_program_*: they own HIP events and side streams until destroyed), a
+ *     cached device-property query (CU count / resident workgroups of the persistent kernels), and - ONLY after the caller has
+ *     opted into the vendor route with mpmae_set_option(MPMAE_OPT_BLASLT, >= 1), which is OFF by default - one process-global
+ *     hipblasLtHandle_t per device plus a plan cache (descriptor, layouts, algorithm, optional workspace) per call site;
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch.
  *
  * Row layout. A sparse stage holds only the visible patches: row = (n*keep + slot)*S*S + iy*S + ix
@@ -362,7 +364,7 @@ enum MpmaeOption {
   MPMAE_OPT_NT4,   /* default 1: 256 x 256-tile NT GEMM (gemm_nt4.cuh) for M >= 8192, N = 1024..2048 a multiple of 256, K % 64 == 0 (decoder pwconv1, pwconv2 data gradient); 2 = every shape with M >= 8192, N >= 256 (256 x 128 tiles under N = 1024); 0 = the 128 x 128 kernels */
   MPMAE_OPT_FOLD_GROUP,   /* default 0: 1 = mpmae_fold_group folds up to 16 records per launch (blockIdx.z = record) instead of one launch per record - measured SLOWER in the step (4.035-4.04 vs 4.005-4.026 ms, three interleaved pairs): the small launches slot in between the weight-gradient lane's kernels, the grouped one waits for all its producers */
   MPMAE_OPT_RSC_W5,   /* default 1: 80-row (5-wave) tiles in the narrow fused pointwise kernels at C = 160 when 64-row tiles need more than one round of workgroups and 80-row tiles do not */
-  MPMAE_OPT_BLASLT,   /* default 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */
+  MPMAE_OPT_BLASLT,   /* default 0 (round 5: every GEMM of the default step is this library's own kernel; the vendor route stays as a measured yardstick, tools/probes/blas_yardstick.py). 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */
   MPMAE_OPT_NT5,   /* default 0: 1 = the deep-K NT kernel of gemm_nt5.cuh (128 x 256 tile, 64 x 128 wave tiles, 3-stage DMA ring with counted waits) for plain bf16 products with K >= 1024, N >= 256, M >= 2048 - row masks included - ahead of the vendor route */
   MPMAE_OPT_RSC_ATOMIC,   /* default 0: largest row-block count of a WIDE fused pointwise launch (mpmae_rs which = 0 / 1) whose GRN column statistics are added straight into s0 / s1 with hardware float atomics instead of slab rows + a second-stage fold launch (0 = never) */
   MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical; -1 = the pre-round-4 behaviour of the wide pointwise kernels everywhere (one shared LDS statistics row, float atomics between the waves) for A/B: by default a row per wave is used wherever it does not cost a resident workgroup per CU */
@@ -487,6 +489,13 @@ int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, i
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale,
                         float* losses, float* weighted, float* total, float* coef,
                         float* dlog_vars, mpmae_stream_t stream);
+/* The same, guarded: err_words / n_err / err_stride as in MpmaeMeters (the grid-barrier error words of the persistent stage kernels).
+ * A non-zero word makes total[0] = +inf, so that the non-finite guard of mpmae_hp_fetch skips the update - in a data-parallel run on
+ * EVERY rank, because the guard there reads the all-reduced loss (the reference's equivalent is the collective sys.exit of
+ * engine_pretrain.py:83-85 on a non-finite all-reduced loss). n_err = 0: identical to mpmae_loss_finalize. */
+int mpmae_loss_finalize_guarded(const float* acc, int N, const float* log_vars, int T, float loss_scale,
+                                float* losses, float* weighted, float* total, float* coef, float* dlog_vars,
+                                const unsigned* err_words, int n_err, int err_stride, mpmae_stream_t stream);
 
 /* ---- optimizer (main_pretrain.py:312-320; helpers.py:509-526) ------------------------------ */
 /* hp (device, 8 floats) = {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale, skip, skipped_steps, -, -}:
@@ -511,8 +520,9 @@ typedef struct MpmaeMeters {
   float* ring; int window; float* sums; float* gnorm2;
   /* error words of the persistent stage kernels' grid barriers (mpmae_ps_fwd / _bwd: args->sync[2] != 0 after a spin timeout, i.e. a
    * workgroup that never became resident): n_err rows of err_stride unsigneds, word 2 of each. Any non-zero word makes hp_fetch skip
-   * this update like a non-finite loss (hp[4] = 1, hp[5] += 1) and counts it in hp[6]; NULL / 0: not checked. */
-  const unsigned* err_words; int n_err; int err_stride;
+   * this update like a non-finite loss (hp[4] = 1, hp[5] += 1), counts it in hp[6] and CLEARS the word (one timeout = one skipped
+   * update); NULL / 0: not checked. */
+  unsigned* err_words; int n_err; int err_stride;
 } MpmaeMeters;
 int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp, const float* total,
                    const MpmaeMeters* meters, mpmae_stream_t stream);
@@ -555,6 +565,9 @@ int mpmae_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, mpma
 
 /* library identification: returns the gfx arch the kernels were built for (950). */
 int mpmae_arch(void);
+/* Kernels of a VENDOR library (hipBLASLt, MPMAE_OPT_BLASLT >= 1) this process has issued through this library so far: 0 forever with the
+ * default options. bench.py reports the per-step difference as "vendor_kernels_per_step". */
+long long mpmae_vendor_launches(void);
 
 #ifdef __cplusplus
 }

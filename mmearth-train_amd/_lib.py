@@ -216,6 +216,8 @@ SYMBOLS = {
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
+    "mpmae_loss_finalize_guarded": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
@@ -243,6 +245,7 @@ SYMBOLS = {
 OTHER_SYMBOLS = {
     "mpmae_program_create": ([], c_void_p),
     "mpmae_program_destroy": ([c_void_p], None),
+    "mpmae_vendor_launches": ([], C.c_longlong),
 }
 
 _lib = None

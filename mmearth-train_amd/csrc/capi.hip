@@ -67,7 +67,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_NT4 */ 1,
     /* MPMAE_OPT_FOLD_GROUP */ 0,
     /* MPMAE_OPT_RSC_W5 */ 1,
-    /* MPMAE_OPT_BLASLT */ 1,
+    /* MPMAE_OPT_BLASLT */ 0,
     /* MPMAE_OPT_NT5 */ 0,
     /* MPMAE_OPT_RSC_ATOMIC */ 0,
     /* MPMAE_OPT_DET */ 0,
@@ -863,12 +863,18 @@ int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, i
   RET();
 }
 
+int mpmae_loss_finalize_guarded(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
+                                float* weighted, float* total, float* coef, float* dlog_vars, const unsigned* err_words, int n_err,
+                                int err_stride, mpmae_stream_t s) {
+  if (T > 16 || T < 1 || n_err < 0 || (n_err > 0 && (!err_words || err_stride < 3))) return (int)hipErrorInvalidValue;
+  LAUNCH(loss_finalize_kernel, dim3(1), dim3(64 * T), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
+                     total, coef, dlog_vars, err_words, err_words ? n_err : 0, err_stride);
+  RET();
+}
+
 int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, float loss_scale, float* losses,
                         float* weighted, float* total, float* coef, float* dlog_vars, mpmae_stream_t s) {
-  if (T > 16 || T < 1) return (int)hipErrorInvalidValue;
-  LAUNCH(loss_finalize_kernel, dim3(1), dim3(64 * T), 0, S_(s), acc, N, log_vars, T, loss_scale, losses, weighted,
-                     total, coef, dlog_vars);
-  RET();
+  return mpmae_loss_finalize_guarded(acc, N, log_vars, T, loss_scale, losses, weighted, total, coef, dlog_vars, nullptr, 0, 0, s);
 }
 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,

@@ -59,25 +59,59 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
 #include <array>
 #include <map>
 #include <mutex>
+#include <atomic>
 struct LtPlan {
   hipblasLtMatmulDesc_t desc = nullptr;
   hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
   hipblasLtMatmulAlgo_t algo;
+  hipblasLtHandle_t handle = nullptr;           // the handle of the device the plan was made on
   void* ws = nullptr; size_t ws_bytes = 0;      // owned by the plan (= call site): such GEMMs are all issued on ONE lane, in order
   bool ok = false;
 };
-static hipblasLtHandle_t g_lt = nullptr;
+// one handle per DEVICE (a handle binds the device that was current at its creation: a second device of the process must not reuse it)
+static std::map<int, hipblasLtHandle_t> g_lt_by_dev;
 static std::mutex g_lt_mu;
-static std::map<std::array<long long, 10>, LtPlan> g_lt_plans;
+static std::atomic<long long> g_vendor_launches{0};
+long long mpmae_vendor_launches(void) { return g_vendor_launches.load(std::memory_order_relaxed); }
+static std::map<std::array<long long, 11>, LtPlan> g_lt_plans;
+
+// The library is compiled against ROCm's hipblaslt headers but binds at run time to whichever libhipblaslt the process loaded first
+// (torch's bundled copy): the heuristic-result / algorithm structs are passed BY LAYOUT, so a different major.minor than the build-time
+// headers disables the route (the caller falls through to this library's kernels) instead of risking silent corruption.
+static bool lt_version_ok(hipblasLtHandle_t h) {
+  static int ok = -1;
+  if (ok < 0) {
+    int v = 0;
+    ok = (hipblasLtGetVersion(h, &v) == HIPBLAS_STATUS_SUCCESS && (v / 100 == HIPBLASLT_VERSION_MAJOR * 1000 + HIPBLASLT_VERSION_MINOR || v / 100 == HIPBLASLT_VERSION_MAJOR * 100 + HIPBLASLT_VERSION_MINOR)) ? 1 : 0;      // (major * 100000 + minor * 100 + patch; older releases major * 10000 + ...)
+    if (!ok) fprintf(stderr, "[mpmae] hipBLASLt run-time version %d does not match the build-time headers %d.%d: vendor route disabled\n",
+                     v, HIPBLASLT_VERSION_MAJOR, HIPBLASLT_VERSION_MINOR);
+  }
+  return ok == 1;
+}
+static hipblasLtHandle_t lt_handle(int dev) {
+  auto it = g_lt_by_dev.find(dev);
+  if (it != g_lt_by_dev.end()) return it->second;
+  hipblasLtHandle_t h = nullptr;
+  if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) h = nullptr;
+  // (MPMAE_OPT_BLASLT >= 10: a developer's "measure it anyway" for the yardstick runs - level = value - 10 - on a box whose bundled
+  // hipBLASLt differs from the build-time headers; this image: torch ships 1.0.0, ROCm's headers are 1.2)
+  if (h && g_opt[MPMAE_OPT_BLASLT] < 10 && !lt_version_ok(h)) { hipblasLtDestroy(h); h = nullptr; }
+  g_lt_by_dev[dev] = h;
+  return h;
+}
 
 static const LtPlan* lt_plan(const GemmP& a, bool resid) {
   std::lock_guard<std::mutex> lock(g_lt_mu);
-  const std::array<long long, 10> key = {a.M, a.N, a.K, a.lda, a.ldb, a.ldc, resid ? a.ldr : 0, resid ? 1 : 0,
-                                         (long long)(uintptr_t)a.bias, g_opt[MPMAE_OPT_BLASLT]};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  const std::array<long long, 11> key = {a.M, a.N, a.K, a.lda, a.ldb, a.ldc, resid ? a.ldr : 0, resid ? 1 : 0,
+                                         (long long)(uintptr_t)a.bias, g_opt[MPMAE_OPT_BLASLT], dev};
   auto it = g_lt_plans.find(key);
   if (it != g_lt_plans.end()) return it->second.ok ? &it->second : nullptr;
   LtPlan& pl = g_lt_plans[key];
-  if (!g_lt && hipblasLtCreate(&g_lt) != HIPBLAS_STATUS_SUCCESS) { g_lt = nullptr; return nullptr; }
+  hipblasLtHandle_t g_lt = lt_handle(dev);
+  if (!g_lt) return nullptr;
+  pl.handle = g_lt;
   if (hipblasLtMatmulDescCreate(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return nullptr;
   const int32_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
   bool good = hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS &&
@@ -97,7 +131,7 @@ static const LtPlan* lt_plan(const GemmP& a, bool resid) {
   if (!good) return nullptr;
   hipblasLtMatmulPreference_t pref = nullptr;
   if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;
-  const uint64_t wsmax = g_opt[MPMAE_OPT_BLASLT] >= 2 ? (uint64_t)64 << 20 : 0;
+  const uint64_t wsmax = g_opt[MPMAE_OPT_BLASLT] % 10 >= 2 ? (uint64_t)64 << 20 : 0;
   hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
   constexpr int NCAND = 8;
   hipblasLtMatmulHeuristicResult_t res[NCAND];
@@ -119,7 +153,7 @@ static const LtPlan* lt_plan(const GemmP& a, bool resid) {
 static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) {
   if (!g_opt[MPMAE_OPT_BLASLT] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || a.act) return -1;
   if (a.M < 4096 || a.N < 256 || a.K < 256 || (long long)a.N * a.K < 512LL * 1024) return -1;
-  if (g_opt[MPMAE_OPT_BLASLT] < 3 && g_opt[MPMAE_OPT_NT4] && a.M >= 8192 && a.N >= 1024 && a.N <= 2048 && a.N % 256 == 0 && a.K % 64 == 0 && a.K <= 1024)
+  if (g_opt[MPMAE_OPT_BLASLT] % 10 < 3 && g_opt[MPMAE_OPT_NT4] && a.M >= 8192 && a.N >= 1024 && a.N <= 2048 && a.N % 256 == 0 && a.K % 64 == 0 && a.K <= 1024)
     return -1;      // the 256 x 256-tile kernel of gemm_nt4.cuh holds its own there (64 vs 67 us, 60 vs 65 us stand-alone)
   if (((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) || (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15)) return -1;
   const bool resid = epi == EPI_RESID;
@@ -128,8 +162,9 @@ static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) 
   if (!pl) return -1;
   const void* A = a.A; const void* W = a.B; const void* R = resid ? a.R : a.C; void* D = a.C;
   submit(st, [=](hipStream_t s_) {
+    g_vendor_launches.fetch_add(1, std::memory_order_relaxed);
     const float alpha = 1.f, beta = resid ? 1.f : 0.f;
-    const hipblasStatus_t e = hipblasLtMatmul(g_lt, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, pl->ws, pl->ws_bytes, s_);
+    const hipblasStatus_t e = hipblasLtMatmul(pl->handle, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, pl->ws, pl->ws_bytes, s_);
     if (e != HIPBLAS_STATUS_SUCCESS && !g_launch_err) g_launch_err = 100000 + (int)e;
   });
   return launch_status();

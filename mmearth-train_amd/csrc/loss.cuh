@@ -714,7 +714,8 @@ __global__ __launch_bounds__(256) void loss_img_multi_kernel(const ImgP* __restr
 // acc layout: [T][N][2] per-sample partial {sum, count}
 __global__ void loss_finalize_kernel(const float* __restrict__ acc, int Nn, const float* __restrict__ log_vars, int Tn,
                                      float loss_scale, float* __restrict__ losses, float* __restrict__ weighted,
-                                     float* __restrict__ total, float* __restrict__ coef, float* __restrict__ dlog_vars) {
+                                     float* __restrict__ total, float* __restrict__ coef, float* __restrict__ dlog_vars,
+                                     const unsigned* __restrict__ err_words, int n_err, int err_stride) {
   // one wave per modality: its 64 lanes fold the per-sample {sum, count} partials (fixed order -> deterministic)
   __shared__ float w[64];
   const int i = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -746,6 +747,11 @@ __global__ void loss_finalize_kernel(const float* __restrict__ acc, int Nn, cons
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int j = 0; j < Tn; ++j) t += w[j];
-    total[0] = t;
+    // a persistent stage kernel whose grid barrier timed out in THIS forward (ps.cuh grid_barrier: sync[2] != 0) computed on partial GRN
+    // statistics: the total becomes +inf, which the non-finite guard of hp_fetch turns into a skipped update - on EVERY rank of a
+    // data-parallel run, because the guard there reads the all-reduced loss (a rank-local skip let the replicas diverge)
+    unsigned perr = 0;
+    for (int j = 0; j < n_err; ++j) perr |= err_words[(size_t)j * err_stride + 2];
+    total[0] = perr ? __builtin_huge_valf() : t;
   }
 }

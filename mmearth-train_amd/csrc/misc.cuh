@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ ds
 // step is accumulated by adamw_kernel (sum g^2 of the exchanged gradients) and lands in ITS record at the next fetch. The host reads
 // ring + sums with one copy per print, ranks fold their sums with one all-reduce per epoch.
 struct MeterP { const float* losses; const float* weighted; int T; float* ring; int window; float* sums; float* gnorm2;
-                const unsigned* err_words; int n_err; int err_stride; };
+                unsigned* err_words; int n_err; int err_stride; };
 __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict__ ring, int R, int* __restrict__ counter, float* __restrict__ hp,
                                                        const float* __restrict__ total, const MeterP mt) {
   // 1024 threads, every global read issued up front from a clamped address (a runtime-length loop of dependent loads was 64 serial
@@ -264,7 +264,8 @@ __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict_
     t = wave_sum(t);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0 && cnt > 0) {                       // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526)
+    if (threadIdx.x == 0 && cnt > 0 && nb > 0) {             // gradient norm of the PREVIOUS update (helpers.get_grad_norm_, :509-526); nb == 0:
+                                                             // that update was skipped (non-finite loss / barrier timeout) and leaves NO record
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) a += red[j];
@@ -288,8 +289,15 @@ __global__ __launch_bounds__(1024) void hp_fetch_kernel(const float* __restrict_
     // device: hp[4] makes this step's AdamW a no-op, hp[5] counts skipped steps (the host polls it lazily)
     // ... and a persistent stage kernel whose grid barrier timed out trained this step on partial GRN statistics (ps.cuh
     // grid_barrier): same treatment, counted separately in hp[6] so that the host can tell the two apart
+    // (the timed-out rank's loss_finalize has already poisoned ITS loss with +inf - mpmae_loss_finalize_guarded - so in a data-parallel
+    // run the all-reduced guard loss is non-finite on EVERY rank and all of them skip; the word is cleared once it has been counted)
     unsigned perr = 0;
-    for (int i = 0; i < mt.n_err; ++i) perr |= mt.err_words[(size_t)i * mt.err_stride + 2];
+    for (int i = 0; i < mt.n_err; ++i) {
+      unsigned* w = mt.err_words + (size_t)i * mt.err_stride + 2;
+      const unsigned e = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      perr |= e;
+      if (e) __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const bool bad = !(fabsf(tot) <= 3.0e38f) || perr != 0;
     hp[4] = bad ? 1.f : 0.f;
     if (bad) hp[5] += 1.f;

@@ -91,8 +91,9 @@ def plan_buckets(offsets, n_params):
     lo_proj, lo_s2, lo_pred = offsets[first_proj][0], offsets[first_s2][0], offsets[first_pred][0]
     for k in keys:
         o = offsets[k][0]
-        if lo_s2 <= o < lo_proj:      # everything from stages.2 up to the first non-encoder tensor must be stages.2/.3 only
-            assert k.startswith("encoder.stages.2.") or k.startswith("encoder.stages.3."), k
+        if lo_s2 <= o < lo_proj:      # everything from stages.2 up to the first non-encoder tensor must be stages.2/.3 - or, with the dense
+            # encoder (sparse=False), its final norm / classifier head (convnextv2.py:151-152), which never receive a gradient: any bucket will do
+            assert k.startswith(("encoder.stages.2.", "encoder.stages.3.", "encoder.norm.", "encoder.head.")), k
         if lo_proj <= o < lo_pred:    # proj, mask token, the shared decoder block
             assert k.startswith(("proj.", "mask_token", "decoder_dict.")), k
         if o >= lo_pred:              # heads, their shared LayerNorm, the uncertainty weights

@@ -116,7 +116,11 @@ class Engine:
             raise KeyError(f"unknown engine options {sorted(unknown)}")
         if self.opt["det"]:          # reproducible forward: ordered folds in the library (process-wide switch, read when the program is built), no persistent stage kernel
             self.opt["ps"] = 0
-            _lib.check(self.lib.mpmae_set_option(_lib.OPT["DET"], 1), "set_option DET")
+        # DET is a process-wide library switch read while THIS engine's launches are built / recorded: set it from this engine's option
+        # every time (an earlier det = 1 engine of the process must not leave later engines on the slower ordered folds);
+        # a developer override MPMAE_ENGINE_OPTS="DET=..." (A/B of the shared-row behaviour, -1) is kept
+        if "DET=" not in os.environ.get("MPMAE_ENGINE_OPTS", ""):
+            _lib.check(self.lib.mpmae_set_option(_lib.OPT["DET"], 1 if self.opt["det"] else 0), "set_option DET")
         self.cfg = cfg
         self.N = N = int(batch_size)
         # "fp8": the bf16 program with the decoder block's pointwise layers (K % 128 == 0) on the MX-fp8 MFMA path: e4m3
@@ -1460,9 +1464,16 @@ class Engine:
         """12 per-modality losses, uncertainty weighting, total, backward coefficients
         (and, with_dlogvars, d total / d log_vars accumulated into the gradient buffer)."""
         a = self._fin_args
-        err = self.lib.mpmae_loss_finalize(a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6],
-                                           a[7] if with_dlogvars else None, stream)
+        err = self.lib.mpmae_loss_finalize_guarded(a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6],
+                                                   a[7] if with_dlogvars else None, *self._err_words(), stream)
         _lib.check(err, "loss_finalize")
+
+    def _err_words(self):
+        """(err_words, n_err, err_stride): grid-barrier error words of the persistent stage kernels (MpmaeMeters) - a timeout poisons this
+        rank's loss with +inf in the finalisation, so that the all-reduced guard loss skips the update on every rank."""
+        if hasattr(self, "ps_sync"):
+            return _p(self.ps_sync), int(self._ps_launches), int(self.ps_sync.shape[1])
+        return None, 0, 0
 
     # ------------------------------------------------------------------ backward program
     def _block_bwd_fused(self, lst, blk, dout, dx):
@@ -1980,8 +1991,8 @@ class Engine:
         def fin(dlv):      # the forward finalisation also joins the image-head chain that ran on the side lane
             w = tuple(getattr(self, "_fwd_join_keys", ())) if (zs or not dlv) else ()
             m = dict(lane=0, wait=w + (("grads_zero",) if dlv and zs else ()), signal=None)
-            return ("loss.finalize", lib.mpmae_loss_finalize,
-                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None), m)
+            return ("loss.finalize", lib.mpmae_loss_finalize_guarded,
+                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None) + tuple(self._err_words()), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
         # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane

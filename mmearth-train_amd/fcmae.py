@@ -82,7 +82,10 @@ class _StepFn(torch.autograd.Function):
                                "forward of the same batch size; call loss.backward() before the next forward")
         eng.backward(zero_grad=True)
         g = eng.gflat * grad_out
-        outs = tuple(param_view(g[o:o + n], k, p.shape) for k, p, (o, n) in zip(model._pkeys, model._plist, model._poffs))
+        # parameters outside the pretraining graph (the dense encoder's classifier head and final norm, convnextv2.py:151-152: grad is
+        # None in the reference, so torch.optim.AdamW skips them - a zero tensor would still apply the decoupled weight decay)
+        outs = tuple(None if (eng.dense and k.startswith(("encoder.head.", "encoder.norm."))) else param_view(g[o:o + n], k, p.shape)
+                     for k, p, (o, n) in zip(model._pkeys, model._plist, model._poffs))
         return (None, None) + outs
 
 

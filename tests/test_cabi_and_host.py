@@ -104,6 +104,14 @@ def test_bucket_plan_and_segments(lib):
         lo = b[0][0]
         assert all(k.startswith(("pred_dict.", "layer_norm_tmp.", "loss_fn.")) for k, (o, n) in eng.offsets.items() if o >= lo)
     assert b[0][1] - b[0][0] > 0
+    # the dense encoder (sparse=False, patch 16): its final norm / classifier head sit behind stages.3 in the state dict and receive no
+    # gradient; the bucket plan and the segment cut must take them (plan_buckets asserted on encoder.norm.weight)
+    eng = Engine(make_cfg("convnextv2_atto", 112, 16, sparse=False), 2, dtype="bf16", device="cpu")
+    b = plan_buckets(eng.offsets, eng.n_params)
+    assert len(b) == 4 and b[0][1] == eng.n_params and b[3][0] == 0 and all(b[i][0] == b[i + 1][1] for i in range(3))
+    o_norm = eng.offsets["encoder.norm.weight"][0]
+    assert b[2][0] <= o_norm < b[2][1]
+    assert sum(len(s) for s in split_bwd_segments(eng.bwd_ops)) == len(eng.bwd_ops)
 
 
 def _worker(rank, world, port, q):

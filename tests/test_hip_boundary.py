@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) of the drop-in boundary: FCMAE.forward_encoder / forward_decoder / forward_loss, call-time
 mask_ratio, gradient accumulation (update_freq) on the fused path, the device-side non-finite guard, and
 main_pretrain.main end to end (train, checkpoint, auto-resume == uninterrupted run, hub consumer)."""
+import math
 import os
 import re
 import subprocess
@@ -560,6 +561,26 @@ def test_meter_records_the_rank_mean_loss_and_a_barrier_timeout_skips_the_update
     torch.cuda.synchronize()
     assert torch.equal(eng.pflat, before), "the update must be skipped"
     assert eng.hp[5].item() == 1 and eng.hp[6].item() == 1
+    # one timeout = ONE skipped update (the word is cleared once counted) ...
+    assert int(eng.ps_sync[:, 2].sum()) == 0
+    # ... a skipped update leaves NO gradient-norm record (`gn = 0` biased the grad-norm statistics) ...
+    gsum = float(eng.meter_sums[-2].item())
+    eng.step_count += 1
+    eng.set_hyper(1e-3, eng.step_count)
+    eng.launch_adamw()
+    torch.cuda.synchronize()
+    assert float(eng.meter_sums[-2].item()) == gsum, "the fetch after a skipped update must not add a grad-norm record"
+    assert not torch.equal(eng.pflat, before) and eng.hp[5].item() == 1 and eng.hp[6].item() == 1
+    # ... and the skip is COLLECTIVE: the loss finalisation of the timed-out rank writes +inf as its total, which is what the data-parallel
+    # exchange all-reduces into every rank's guard loss
+    eng.ps_sync[0, 2] = 1
+    eng.forward()
+    torch.cuda.synchronize()
+    assert math.isinf(eng.total.item()) and eng.total.item() > 0
+    eng.ps_sync[0, 2] = 0
+    eng.forward()
+    torch.cuda.synchronize()
+    assert math.isfinite(eng.total.item()) and abs(eng.total.item() - L) <= 0.2 * abs(L)      # (one lr = 1e-3 update lies between the two)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible GPUs (one rank per GPU over RCCL)")
