@@ -70,8 +70,13 @@ typedef struct MpmaeGemmArgs {
   const int* vis; const int* inv; const uint8_t* act; const uint8_t* act_src;
   int keep, L, S, Cseg, grid;
   int H;
-  float* ws; size_t ws_floats;       /* scratch for per-block statistic slabs (stats epilogues) */
+  float* ws; size_t ws_floats;       /* scratch for per-block statistic slabs (stats epilogues) and the stream-K partial slots */
+  unsigned* sk_flags;                /* optional (NULL): MPMAE_SK_FLAGS zero-initialised unsigneds owned by the caller, ONE buffer per stream.
+                                        With them (and ws_floats >= MPMAE_SK_WS_FLOATS) plain bf16 NT products of the shapes in MPMAE_OPT_SK
+                                        run on the stream-K schedule of csrc/gemm_sk.cuh, which leaves the flags zero after every launch */
 } MpmaeGemmArgs;
+#define MPMAE_SK_FLAGS 2048
+#define MPMAE_SK_WS_FLOATS ((size_t)256 * 128 * 256)      /* 256 workgroups x one 128 x 256 fp32 partial slot (32 MiB) */
 
 /* dW[n*sn + k*sk] += sum_m proP(P)[m,n]*proQ(Q)[m,k] ; db[n] += sum_m proP(P)[m,n] */
 typedef struct MpmaeWgradArgs {
@@ -367,6 +372,7 @@ enum MpmaeOption {
   MPMAE_OPT_BLASLT,   /* default 0 (round 5: every GEMM of the default step is this library's own kernel; the vendor route stays as a measured yardstick, tools/probes/blas_yardstick.py). 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */
   MPMAE_OPT_NT5,   /* default 0: 1 = the deep-K NT kernel of gemm_nt5.cuh (128 x 256 tile, 64 x 128 wave tiles, 3-stage DMA ring with counted waits) for plain bf16 products with K >= 1024, N >= 256, M >= 2048 - row masks included - ahead of the vendor route */
   MPMAE_OPT_RSC_ATOMIC,   /* default 0: largest row-block count of a WIDE fused pointwise launch (mpmae_rs which = 0 / 1) whose GRN column statistics are added straight into s0 / s1 with hardware float atomics instead of slab rows + a second-stage fold launch (0 = never) */
+  MPMAE_OPT_SK,   /* default 0 (measured SLOWER than whole tiles in round 5: 51-56 vs 37-41 us at N = 512, K = 2048 - each workgroup pays two pipeline fills, a 128 KB publish and a 128 KB fix-up read serially, one workgroup per CU hides none of it; csrc/gemm_sk.cuh). 1: the stream-K NT kernel of gemm_sk.cuh (128 x 256 tiles cut into 64-deep K iterations, every CU takes the same number of iterations, partial tiles fixed up through write-through fp32 slots) for plain bf16 products (no prologue, epilogue = bias / residual / row mask) with K >= 1024, K % 64 == 0, N >= 256, M >= 2048 when the caller passes MpmaeGemmArgs.sk_flags: the dense decoder's pwconv2 and pwconv1 data gradient, the heads' data gradient, the stage-3 pwconv2 / pwconv1 data gradient. 2 = also K >= 512 (decoder pwconv1 / pwconv2.dgrad, pixel heads). 0 = whole-tile kernels */
   MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical; -1 = the pre-round-4 behaviour of the wide pointwise kernels everywhere (one shared LDS statistics row, float atomics between the waves) for A/B: by default a row per wave is used wherever it does not cost a resident workgroup per CU */
   MPMAE_OPT_COUNT_
 };

@@ -70,6 +70,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_BLASLT */ 0,
     /* MPMAE_OPT_NT5 */ 0,
     /* MPMAE_OPT_RSC_ATOMIC */ 0,
+    /* MPMAE_OPT_SK */ 0,
     /* MPMAE_OPT_DET */ 0,
 };
 

@@ -10,6 +10,7 @@
 #include "gemm_tng.cuh"
 #include "gemm_nt4.cuh"
 #include "gemm_nt5.cuh"
+#include "gemm_sk.cuh"
 #include "grn_group.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
@@ -188,11 +189,43 @@ static int try_nt5(int dt, int pro, int epi, const GemmP& a0, hipStream_t st) {
   return launch_status();
 }
 
+// stream-K NT kernel (gemm_sk.cuh, MPMAE_OPT_SK): plain products, deep K; -1 = not taken
+static int try_sk(int dt, int pro, int epi, const GemmP& a0, hipStream_t st) {
+  const int lvl = g_opt[MPMAE_OPT_SK];
+  if (!lvl || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || !a0.sk_flags || !a0.ws) return -1;
+  if (a0.M < 2048 || a0.N < 256 || a0.K < (lvl >= 2 ? 512 : 1024) || (a0.K % NT5_BK) || ((a0.N | a0.lda | a0.ldb | a0.ldc) & 7)) return -1;
+  if (((uintptr_t)a0.A | (uintptr_t)a0.B | (uintptr_t)a0.C | (uintptr_t)a0.ws) & 15) return -1;
+  GemmP a = a0;
+  if (epi == EPI_STORE) a.R = nullptr;
+  if (a.R && ((a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT5_LDS) != hipSuccess) return (int)hipGetLastError();
+    attr = true;
+  }
+  SkP sk;
+  sk.part = a.ws; sk.flags = a.sk_flags;
+  sk.mtiles = cdiv(a.M, NT5_BM); sk.ntiles = cdiv(a.N, NT5_BN);
+  // one workgroup per CU (144 KB of LDS each), a multiple of 8 (workgroup b -> XCD b % 8), at least ~2 iterations per workgroup
+  // Q = G groups x ntiles column tiles per XCD (gemm_sk.cuh), as many whole groups as the XCD has CUs; >= ~2 iterations per workgroup
+  int cus8 = ps_num_cus() / 8;
+  if (cus8 < 1) cus8 = 32;
+  int G = cus8 / sk.ntiles;
+  if (G < 1) return -1;                                     // (more column tiles than CUs per XCD: whole tiles)
+  const long long rb_iters = (long long)(sk.mtiles / 8 > 0 ? sk.mtiles / 8 : 1) * (a.K / NT5_BK);      // per XCD
+  while (G > 1 && rb_iters / G < 2) G /= 2;
+  const int Q = G * sk.ntiles;
+  if (sk.mtiles < 8 || 8 * Q > MPMAE_SK_FLAGS || a.ws_floats < (size_t)8 * Q * SK_SLOT_FLOATS) return -1;
+  LAUNCH(gemm_sk_kernel, dim3(8 * Q), dim3(256), NT5_LDS, st, a, sk);
+  return launch_status();
+}
+
 int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t s) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
   { const int r = try_nt5(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
+  { const int r = try_sk(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   { const int r = try_blaslt(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
   const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);

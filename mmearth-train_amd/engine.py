@@ -394,6 +394,7 @@ class Engine:
         self.ws = torch.empty(self.ws_floats, dtype=f32, device=dev)
         self.ws2 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # side-lane (weight-gradient) scratch
         self.ws3 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # second side lane (depthwise weight gradients)
+        self.sk_flags = torch.zeros(_lib.SK_FLAGS, dtype=torch.int32, device=dev)      # MpmaeGemmArgs.sk_flags (main lane: every mpmae_gemm of the step is issued there or, for the tiny image-head products, never takes the stream-K kernel)
 
     def _alloc_block(self, prefix, M, Cc, G, stage, sparse, rpg=None):
         H = 4 * Cc
@@ -641,6 +642,7 @@ class Engine:
         if not kw.get("rpg"):
             a.rpg = max(int(a.M), 1)
         a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
+        a.sk_flags = self.sk_flags.data_ptr()      # stream-K hand-off flags of the main lane (self-resetting, gemm_sk.cuh)
         self._keepalive.append(a)
         esz = 4 if self.dt == F32 else 2
         M_, N_, K_ = int(a.M), int(a.N), int(a.K)

@@ -24,7 +24,7 @@ def test_header_symbols_exported(lib):
     declared = set(re.findall(r"\bint\s+(mpmae_\w+)\s*\(", hdr))
     from mmearth_train_amd import _lib
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
-    others = set(re.findall(r"\b(?:void|MpmaeProgram\*)\s+(mpmae_\w+)\s*\(", hdr))
+    others = set(re.findall(r"\b(?:void|MpmaeProgram\*|long long)\s+(mpmae_\w+)\s*\(", hdr))
     assert others == set(_lib.OTHER_SYMBOLS), others ^ set(_lib.OTHER_SYMBOLS)
     for name in declared | others:
         assert hasattr(lib, name), name
