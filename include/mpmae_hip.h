@@ -223,6 +223,13 @@ int mpmae_ps_fwd(const MpmaePsArgs* args, mpmae_stream_t stream);
  * are written as zeros). The plain GEMM / weight-gradient entry points then run on `out`. */
 int mpmae_im2col3(int dt, const float* img, const int* vis, const int* inv, void* out, int ldo, int N,
                   int keep, int grid, int S, int Cseg, int H, mpmae_stream_t stream);
+/* Operand matrix of the ORIGINAL ConvNeXtV2 patchify stem (use_orig_stem=True: convnextv2_sparse.py:99-110,202-203 - MinkowskiConvolution
+ * k = stride = patch / 8 on the to_sparse input; convnextv2.py:97-106 for the dense encoder): out[(n*keep+slot)*64 + iy*8 + ix][(kw*k+kh)*Cseg + cin]
+ * = the k x k pixels under stage-0 point (iy, ix) of visible patch `slot` (vis = NULL: every patch, slot = patch; inv != NULL: a patch with inv[n*L + patch] < 0 - masked, dense encoder - reads as zeros), row stride ldo >= k*k*Cseg
+ * (padding columns are zeros). The convolution is then a plain mpmae_gemm on `out` (row mask = the pooled activity map), its weight
+ * gradient a plain mpmae_wgrad. Needs p == 8 k, H == grid p. */
+int mpmae_gather_kxk(int dt, const float* img, const int* vis, const int* inv, void* out, int ldo, int N, int keep, int grid,
+                     int p, int k, int Cseg, int H, mpmae_stream_t stream);
 /* dst[r*dst_sr + c*dst_sc] += src[r*src_ld + c]: folds a padded contiguous gradient into a strided
  * parameter layout (e.g. ME's (9, Cin, Cout) convolution kernel). */
 int mpmae_strided_add(float* dst, const float* src, int rows, int cols, int src_ld, int dst_sr,

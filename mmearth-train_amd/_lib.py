@@ -163,6 +163,7 @@ SYMBOLS = {
     "mpmae_crop": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mpmae_crop_norm": [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p],
     "mpmae_crop_lut": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_gather_kxk": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_mask_gen": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_mask_gen_dense": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p],
     "mpmae_activity": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -64,6 +64,9 @@ class ModelCfg:
     # zeroed at the input only; state dict in nn.Conv2d / nn.Linear layouts. Its stem (valid 3x3 convolution, depthwise k = stride =
     # patch / 8 with padding k // 2) only lines up with the decoder's patch grid when patch_size == 16 (convnextv2.py:108-124).
     sparse: bool = True
+    # True: the original ConvNeXtV2 patchify stem instead of initial_conv + depthwise stem (convnextv2_sparse.py:99-110,202-203;
+    # convnextv2.py:97-106,161-162): ONE convolution k = stride = patch / 8, 12 -> C0, + LayerNorm
+    use_orig_stem: bool = False
 
     # ---- derived sizes ----------------------------------------------------
     @property
@@ -110,7 +113,7 @@ def kind_of(name: str) -> str:
 def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=None,
              inp_modalities=None, modalities_full=None, norm_pix_loss=True,
              loss_aggr="uncertainty", mask_ratio=0.6, decoder_embed_dim=512,
-             decoder_depth=1, sparse=True) -> ModelCfg:
+             decoder_depth=1, sparse=True, use_orig_stem=False) -> ModelCfg:
     depths, dims = SIZES[model]
     out_modalities = OrderedDict(M.OUT_MODALITIES if out_modalities is None else out_modalities)
     inp_modalities = OrderedDict(M.INP_MODALITIES if inp_modalities is None else inp_modalities)
@@ -135,7 +138,7 @@ def make_cfg(model="convnextv2_atto", img_size=56, patch_size=8, out_modalities=
     return ModelCfg(name=model, depths=list(depths), dims=list(dims), img_size=img_size,
                     patch_size=patch_size, in_chans=in_chans, decoder_embed_dim=decoder_embed_dim,
                     decoder_depth=decoder_depth, mask_ratio=mask_ratio, norm_pix_loss=norm_pix_loss,
-                    loss_aggr=loss_aggr, out_mods=oms, sparse=bool(sparse))
+                    loss_aggr=loss_aggr, out_mods=oms, sparse=bool(sparse), use_orig_stem=bool(use_orig_stem))
 
 
 def cfg_from_args(model, img_size, patch_size, args: Namespace, norm_pix_loss, mask_ratio,
@@ -148,7 +151,8 @@ def cfg_from_args(model, img_size, patch_size, args: Namespace, norm_pix_loss, m
     return make_cfg(model, img_size, patch_size, out_modalities=args.out_modalities,
                     inp_modalities=inp, modalities_full=args.modalities_full,
                     norm_pix_loss=norm_pix_loss, loss_aggr=args.loss_aggr, mask_ratio=mask_ratio,
-                    decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth, sparse=sparse)
+                    decoder_embed_dim=decoder_embed_dim, decoder_depth=decoder_depth, sparse=sparse,
+                    use_orig_stem=bool(getattr(args, "use_orig_stem", False)))
 
 
 def default_args(out_modalities=None, loss_aggr="uncertainty", use_orig_stem=False) -> Namespace:

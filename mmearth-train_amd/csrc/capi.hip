@@ -122,13 +122,17 @@ template <typename T>
 static void launch_ln_fwd(const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta,
                           int act, float eps, int M, int C, const uint8_t* rowmask, hipStream_t st) {
   const int blocks = grid1d((long long)M * 64, 256, 8192);
-  LAUNCH(ln_fwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
+  if (C <= 64 * LN_MAXPER)
+    LAUNCH(ln_fwd_kernel<T>, dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
+                     act, eps, M, C, rowmask);
+  else      // large / huge stage 3 (C = 1536 / 2816)
+    LAUNCH((ln_fwd_kernel<T, LN_MAXPER_WIDE>), dim3(blocks), dim3(256), 0, st, (const T*)x, (T*)xhat, rstd, (T*)y, gamma, beta,
                      act, eps, M, C, rowmask);
 }
 
 static int ln_fwd_impl(int dt, const void* x, void* xhat, float* rstd, void* y, const float* gamma, const float* beta, int act,
                        float eps, int M, int C, const uint8_t* rowmask, int down_S, mpmae_stream_t s) {
-  if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if (C > 64 * LN_MAXPER_WIDE) return (int)hipErrorInvalidValue;
   if (down_S && ((C & 7) || C > 1024 || (down_S & 1))) return (int)hipErrorInvalidValue;
   if ((C & 7) == 0 && C <= 1024) {
     const int nvec = C / 8;
@@ -163,7 +167,7 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
                        const float* gamma, const float* beta, int act, void* dx, int accumulate, float* dgamma, float* dbeta,
                        int M, int C, const uint8_t* rowmask, float* ws, size_t ws_floats, int down_S, mpmae_stream_t s,
                        MpmaeFoldDesc* defer = nullptr) {
-  if (C > 64 * LN_MAXPER) return (int)hipErrorInvalidValue;
+  if (C > 64 * LN_MAXPER_WIDE) return (int)hipErrorInvalidValue;
   if (down_S && ((C & 7) || C > 1024 || (down_S & 1))) return (int)hipErrorInvalidValue;
   int blocks = grid1d((long long)M * 64, 256, 1024);
   if (!ws || ws_floats < (size_t)2 * C) return (int)hipErrorInvalidValue;
@@ -187,6 +191,13 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
 #undef LNB_T
 #undef LNB
     blocks = b2;                                                      // slab rows = workgroups (the 4 waves fold in LDS)
+  } else if (C > 64 * LN_MAXPER) {      // large / huge stage 3 (C = 1536 / 2816): the generic kernel's wide instantiation
+    if (dt == 0)
+      LAUNCH((ln_bwd_kernel<float, LN_MAXPER_WIDE>), dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
+                       (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);
+    else
+      LAUNCH((ln_bwd_kernel<bf16_t, LN_MAXPER_WIDE>), dim3(blocks), dim3(256), 0, S_(s), (const bf16_t*)dy, dy_div, dy_scale,
+                       (const bf16_t*)xhat, rstd, gamma, beta, act, (bf16_t*)dx, accumulate, ws, M, C, rowmask);
   } else if (dt == 0)
     LAUNCH(ln_bwd_kernel<float>, dim3(blocks), dim3(256), 0, S_(s), (const float*)dy, dy_div, dy_scale,
                        (const float*)xhat, rstd, gamma, beta, act, (float*)dx, accumulate, ws, M, C, rowmask);
@@ -924,6 +935,16 @@ int mpmae_im2col3(int dt, const float* img, const int* vis, const int* inv, void
   if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
   if (dt == 0) LAUNCH(im2col3_kernel<float>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (float*)out, ldo, keep, grid, S, Cseg, H);
   else LAUNCH(im2col3_kernel<bf16_t>, dim3(N * keep), dim3(256), lds, S_(s), img, vis, inv, (bf16_t*)out, ldo, keep, grid, S, Cseg, H);
+  RET();
+}
+
+int mpmae_gather_kxk(int dt, const float* img, const int* vis, const int* inv, void* out, int ldo, int N, int keep, int grid, int p, int k, int Cseg, int H,
+                     mpmae_stream_t s) {
+  if (!img || !out || N < 1 || keep < 1 || k < 1 || p != 8 * k || H != grid * p || ldo < k * k * Cseg) return (int)hipErrorInvalidValue;
+  const int rows = N * keep * 64;
+  const int g = grid1d((long long)rows * ldo, 256, 8192);
+  if (dt == 0) LAUNCH(gather_kxk_kernel<float>, dim3(g), dim3(256), 0, S_(s), img, vis, inv, (float*)out, ldo, keep, grid, p, k, Cseg, H, rows);
+  else LAUNCH(gather_kxk_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), img, vis, inv, (bf16_t*)out, ldo, keep, grid, p, k, Cseg, H, rows);
   RET();
 }
 

@@ -334,7 +334,9 @@ static bool tng_ok(int dt, const WgradP* pr, int count, int* WX_, int* WY_) {
 int mpmae_wgrad_group(int dt, const MpmaeWgradArgs* probs, int count, float* ws, size_t ws_floats, mpmae_stream_t s) {
   if (!probs || count < 1 || !ws) return (int)hipErrorInvalidValue;
   int WX = 0, WY = 0;
-  if (!tng_ok(dt, probs, count, &WX, &WY)) {            // one call per problem (each with the scratch given here)
+  // (the grouped kernel needs one slab set per problem in the scratch: large / huge stage 3 - 6 problems of 1536 x 6144 - do not fit and go
+  // one by one like the shapes the kernel does not take)
+  if (!tng_ok(dt, probs, count, &WX, &WY) || (size_t)count * ((size_t)WX * WY + WY) > ws_floats) {            // one call per problem (each with the scratch given here)
     for (int i = 0; i < count; ++i) {
       MpmaeWgradArgs a = probs[i];
       a.ws = ws; a.ws_floats = ws_floats;

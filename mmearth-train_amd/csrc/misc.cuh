@@ -215,6 +215,32 @@ __global__ __launch_bounds__(256) void im2col3_kernel(const float* __restrict__ 
   }
 }
 
+// Operand matrix of the ORIGINAL ConvNeXtV2 stem (use_orig_stem: convnextv2_sparse.py:99-110, MinkowskiConvolution k = stride = patch / 8):
+// out[(n*keep + slot)*64 + iy*8 + ix][(kw*k + kh)*Cseg + cin] = img[n][cin][py*p + iy*k + kh][px*p + ix*k + kw] for the k x k pixels
+// under stage-0 point (iy, ix) of visible patch `slot` (ME's kernel-offset order: first spatial coordinate fastest, helpers.py:676-683);
+// columns >= k*k*Cseg are written as zeros; inv != NULL (dense encoder, every patch a row): patches with inv < 0 read as zeros. Only pixels of visible patches are read (the masked ones never reach the encoder), all-zero
+// pixels contribute zeros by value - their ACTIVITY is a row mask of the GEMM that follows (mpmae_activity / mpmae_activity_pool).
+template <typename T>
+__global__ __launch_bounds__(256) void gather_kxk_kernel(const float* __restrict__ img, const int* __restrict__ vis, const int* __restrict__ inv,
+                                                         T* __restrict__ out, int ldo, int keep, int grid, int p, int k, int Cseg, int H, int rows) {
+  const int K = k * k * Cseg;
+  const long long total = (long long)rows * ldo;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % ldo), row = (int)(i / ldo);
+    float v = 0.f;
+    if (col < K) {
+      const int tap = col / Cseg, cin = col - tap * Cseg, kh = tap % k, kw = tap / k;
+      const int nk = row >> 6, q = row & 63, iy = q >> 3, ix = q & 7, n = nk / keep;
+      const int patch = vis ? vis[nk] : nk - n * keep;
+      const int py = patch / grid, px = patch - py * grid;
+      v = img[((size_t)(n * Cseg + cin) * H + py * p + iy * k + kh) * H + px * p + ix * k + kw];
+      if (inv && inv[n * grid * grid + patch] < 0) v = 0.f;      // dense encoder: a masked patch is a row whose pixels were zeroed (x *= 1 - mask)
+    }
+    if (sizeof(T) == 2) reinterpret_cast<bf16_t*>(out)[i] = f2bf(v);
+    else reinterpret_cast<float*>(out)[i] = v;
+  }
+}
+
 // dst[r*dsr + c*dsc] += src[r*sld + c]   (fold a padded, contiguous gradient into a strided parameter layout)
 __global__ __launch_bounds__(256) void strided_add_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows,
                                                           int cols, int sld, int dsr, int dsc) {

@@ -3,14 +3,15 @@
 #pragma once
 #include "common.cuh"
 
-constexpr int LN_MAXPER = 16;   // supports C <= 1024 with one wave per row
+constexpr int LN_MAXPER = 16;   // C <= 1024 with one wave per row; LN_MAXPER_WIDE: the generic kernels' second instantiation (large / huge stage 3: C = 1536 / 2816)
+constexpr int LN_MAXPER_WIDE = 48;
 
 // ---------------------------------------------------------------------------------
 // LayerNorm forward: xhat = (x - mean) * rstd (biased variance, eps inside the sqrt);
 //   optional y = act(xhat*gamma + beta), act in {0: identity, 1: GELU}
 //   rows with rowmask[m] == 0 produce zeros (inactive sparse sites).
 // ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int MP = LN_MAXPER>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T* __restrict__ xhat,
                                                      float* __restrict__ rstd_out, T* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -21,10 +22,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
   for (int m = wave_global; m < M; m += nwaves) {
     const bool live = !rowmask || rowmask[m];
-    float v[LN_MAXPER];
+    float v[MP];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < MP; ++i) {
       const int c = lane + i * 64;
       v[i] = (c < C) ? ldf<T>(x + (size_t)m * C + c) : 0.f;
       s += v[i];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     const float mean = wave_sum(s) / C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < MP; ++i) {
       const int c = lane + i * 64;
       const float d = (c < C) ? v[i] - mean : 0.f;
       q += d * d;
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
     const float rstd = rsqrtf(wave_sum(q) / C + eps);
     if (lane == 0 && rstd_out) rstd_out[m] = live ? rstd : 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < MP; ++i) {
       const int c = lane + i * 64;
       if (c < C) {
         float xh = live ? (v[i] - mean) * rstd : 0.f;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, T*
 //   dx (+)= rstd * (dxh - mean(dxh) - xhat*mean(dxh*xhat)),  dxh = dy'*gamma
 //   dgamma += sum_m dy'*xhat ; dbeta += sum_m dy'
 // ---------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int MP = LN_MAXPER>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, int dy_div, float dy_scale,
                                                      const T* __restrict__ xhat, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -75,15 +76,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  float ag[LN_MAXPER], ab[LN_MAXPER];
+  float ag[MP], ab[MP];
 #pragma unroll
-  for (int i = 0; i < LN_MAXPER; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int i = 0; i < MP; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   for (int m = wave_global; m < M; m += nwaves) {
     const bool live = !rowmask || rowmask[m];
-    float g[LN_MAXPER], xh[LN_MAXPER];
+    float g[MP], xh[MP];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < MP; ++i) {
       const int c = lane + i * 64;
       g[i] = 0.f; xh[i] = 0.f;
       if (c < C && live) {
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
     s2 = wave_sum(s2) / C;
     const float rs = live ? rstd[m] : 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXPER; ++i) {
+    for (int i = 0; i < MP; ++i) {
       const int c = lane + i * 64;
       if (c < C) {
         float v = rs * (g[i] - s1 - xh[i] * s2);
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, i
   }
   // reduce dgamma / dbeta over the block's 4 waves, then one atomic per channel per block
 #pragma unroll
-  for (int i = 0; i < LN_MAXPER; ++i) {
+  for (int i = 0; i < MP; ++i) {
     if (i * 64 < C) {
       red[0][wave][lane] = ag[i];
       red[1][wave][lane] = ab[i];

@@ -290,7 +290,9 @@ class Engine:
         if self.dense:      # every patch is a row, in patch order (the stem's gather walks `vis`; `inv` comes from mpmae_mask_gen_dense)
             self.vis.copy_(torch.arange(L, dtype=torch.int32, device=dev).repeat(N))
         # activity maps
-        if self.dense:
+        if self.dense and getattr(cfg, "use_orig_stem", False):
+            self.act_full, self.act = None, [None] * 4      # Conv2d k = s = patch / 8 without padding: every point exists (convnextv2.py:97-106)
+        elif self.dense:
             # The dense stem's 3x3 convolution is VALID (convnextv2.py:110: S - 2 points per side) and its depthwise k x k stride-k
             # convolution pads k // 2 (:117-121): in pixel-centred terms the outermost ring of convolution outputs does not exist and
             # contributes zero to the depthwise sum. That is exactly an inactive site of the sparse stem kernels: a STATIC activity map.
@@ -426,8 +428,12 @@ class Engine:
         P = self.params
         cfg, dims, D = self.cfg, self.cfg.dims, self.D
         C0 = dims[0]
-        k = P["encoder.initial_conv.0.kernel"]
-        add("stem.Wt", k, C0, 9 * cfg.in_chans, 1, C0)
+        if getattr(cfg, "use_orig_stem", False):      # ME layout [(kw*k + kh)*Cin + cin][C0] -> [C0][k*k*Cin]
+            k = P["encoder.stem_orig.0.kernel"]
+            add("stem.Wt", k, C0, cfg.stem_k * cfg.stem_k * cfg.in_chans, 1, C0)
+        else:
+            k = P["encoder.initial_conv.0.kernel"]
+            add("stem.Wt", k, C0, 9 * cfg.in_chans, 1, C0)
 
         def block_weights(prefix, Cc, sparse):
             H = 4 * Cc
@@ -1147,12 +1153,13 @@ class Engine:
         f = self.fwd_ops
         dims = cfg.dims
         C0, p, k = dims[0], self.p, cfg.stem_k
+        orig = self.orig_stem = bool(getattr(cfg, "use_orig_stem", False))
         # weight staging only feeds the first GEMM: on the side lane next to mask / activity / im2col (which only read the inputs)
         prep_side = self.lanes and bool(self.opt["prep_side"]) and not self.fp8
         # (prep_late: issued behind the activity ops instead, see below)
         prep_late = (prep_side and bool(self.opt["prep_late"]) and bool(self.opt["front_side"]) and self.track_activity
                      and bool(self.opt["stem_front"]) and bool(self.opt["stem_fused"]) and bool(self.opt["stem_im2col"]) and dt != F32 and p == 8
-                     and k == 1 and C0 % 8 == 0 and C0 <= 48 and cfg.in_chans <= 12)      # (= the conditions of the fused stem kernel below)
+                     and k == 1 and C0 % 8 == 0 and C0 <= 48 and cfg.in_chans <= 12 and not orig)      # (= the conditions of the fused stem kernel below)
         if not prep_late:
             self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max,
                      **(dict(lane=1, signal="prep_done") if prep_side else {}))
@@ -1180,13 +1187,24 @@ class Engine:
         if prep_late:
             self._op(f, "prep", lib.mpmae_prep_weights, dt, _p(self.prep_table), self.prep_n, self.prep_max, lane=1, signal="prep_done")
         wt = self.w["stem.Wt"]
-        self.stem_im2col = bool(self.opt["stem_im2col"])
-        self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"]))
+        self.stem_im2col = bool(self.opt["stem_im2col"]) or orig
+        self.stem_fused = (k == 1 and C0 % 8 == 0 and bool(self.opt["stem_fused"])) and not orig
         # one launch for the whole stem forward (bf16, patch 8): the convolution output never exists, and the im2col matrix of the weight
         # gradient is written from the kernel's own MFMA operand fragments (no mpmae_im2col3 launch at all)
         self.stem_front = (self.stem_fused and self.stem_im2col and dt != F32 and bool(self.opt["stem_front"]) and p == 8
                            and cfg.in_chans <= 12 and C0 <= 48 and wt["ld"] % 8 == 0)
-        if self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
+        if orig:
+            # use_orig_stem (convnextv2_sparse.py:99-110,202-203): ONE convolution k = s = patch / 8 + LN. The k x k pixels under every stage-0
+            # point are gathered into an operand matrix once per step (mpmae_gather_kxk); the convolution is a plain GEMM with the pooled
+            # activity map as row mask (bias only at active outputs), its weight gradient a plain TN product on the same matrix
+            self.ldk = _rup(k * k * cfg.in_chans, 8)
+            self.col = self._t(self.M[0] * self.ldk)
+            self._op(f, "stem:gather", lib.mpmae_gather_kxk, dt, _p(img), None if self.dense else _p(self.vis), _p(self.inv) if self.dense else None, _p(self.col), self.ldk, N, self.keep,
+                     self.grid, p, k, cfg.in_chans, cfg.img_size, kind="gather_kxk",
+                     nbytes=self.M[0] * self.ldk * (4 if dt == F32 else 2) + N * self.keep * p * p * cfg.in_chans * 4)
+            self._gemm(f, "stem:conv", "NONE", "STORE", A=self.col, B=wt["t"], bias=P["encoder.stem_orig.0.bias"], C=self.s0, M=self.M[0], N=C0,
+                       K=self.ldk, lda=self.ldk, ldb=wt["ld"], ldc=C0, act=self.act[0])
+        elif self.stem_im2col:     # materialise the 3x3 taps once per step: plain (fast) GEMMs forward and for the weight gradient
             self.ldk = _rup(9 * cfg.in_chans, 8)
             self.col = self._t(self.Mfull * self.ldk)
             if not self.stem_front:
@@ -1235,6 +1253,9 @@ class Engine:
                 f[-1][3]["wait"] = tuple(f[-1][3]["wait"]) + (("front_done",) if front_side else ("prep_done",))
         if self.stem_front:
             pass
+        elif orig:
+            self._op(f, "stem:ln", lib.mpmae_ln_fwd, dt, _p(self.s0), _p(self.s0hat), _p(self.rstd2), _p(self.x0),
+                     _p(P["encoder.stem_orig.1.ln.weight"]), _p(P["encoder.stem_orig.1.ln.bias"]), 0, 1e-6, self.M[0], C0, _p(self.act[0]))
         elif self.stem_fused:      # LN + GELU + 1x1 depthwise + LN in one row-wise pass (stemtail.cuh)
             a = _lib.StemTailArgs()
             a.x, a.out = self.c1.data_ptr(), self.x0.data_ptr()
@@ -1270,7 +1291,7 @@ class Engine:
                 dn["x"] = x
                 Ci = dims[i - 1]
                 wd = self.w[f"down{i - 1}.Wt"]
-                dn["grouped"] = (self.down_grouped and Ci % 8 == 0 and self.S[i - 1] % 2 == 0)
+                dn["grouped"] = (self.down_grouped and Ci % 8 == 0 and Ci <= 1024 and self.S[i - 1] % 2 == 0)      # (the grouped LayerNorm kernels: C <= 1024; huge has 1408 in front of stage 3)
                 if dn["grouped"]:
                     # LN writes its affine output straight into the [M_i][4*Ci] operand layout of the 2x2/2 convolution,
                     # which then is a plain GEMM (and its weight gradient a plain TN product)
@@ -1672,7 +1693,12 @@ class Engine:
         # stem
         C0, k = dims[0], cfg.stem_k
         dc1 = other[:self.Mfull * C0]
-        if self.stem_fused:
+        if self.orig_stem:
+            dc1 = other[:self.M[0] * C0]
+            self._op(b, "stem:ln.bwd", self._ln_bwd_fn, dt, _p(cur), 1, 1.0, _p(self.s0hat), _p(self.rstd2),
+                     _p(P["encoder.stem_orig.1.ln.weight"]), _p(P["encoder.stem_orig.1.ln.bias"]), 0, _p(dc1), 0,
+                     _p(Gd["encoder.stem_orig.1.ln.weight"]), _p(Gd["encoder.stem_orig.1.ln.bias"]), self.M[0], C0, _p(self.act[0]))
+        elif self.stem_fused:
             a = _lib.StemTailArgs()
             a.x, a.out = cur.data_ptr(), dc1.data_ptr()
             a.xhat1, a.rstd1, a.xhat2, a.rstd2 = (t.data_ptr() for t in (self.c1hat, self.rstd1, self.s0hat, self.rstd2))
@@ -1706,7 +1732,10 @@ class Engine:
                    _p(self.act_full))
         self._guard(b, dc1)
         if self.stem_im2col:
-            Kc = 9 * cfg.in_chans
+            Kc = (k * k if self.orig_stem else 9) * cfg.in_chans
+            Mc = self.M[0] if self.orig_stem else self.Mfull
+            kkey, bkey = (("encoder.stem_orig.0.kernel", "encoder.stem_orig.0.bias") if self.orig_stem
+                          else ("encoder.initial_conv.0.kernel", "encoder.initial_conv.0.bias"))
             self.dw_stem_pad = torch.zeros(C0 * self.ldk, dtype=torch.float32, device=self.device)
             # zeroed at the START of the backward: in the tail it sat on the critical path between the last data gradient
             # and AdamW (profiles/r01/timeline_final.txt)
@@ -1714,10 +1743,10 @@ class Engine:
             self._op(b, "stem:conv.dWpad.zero", lib.mpmae_memset_async, _p(self.dw_stem_pad), 0, C0 * self.ldk * 4,
                      **(dict(lane=1, signal="stem_pad_zero") if zs else {}))
             b.insert(0, b.pop())
-            self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", wait=("stem_pad_zero",) if zs else (), P=dc1, Q=self.col, M=self.Mfull, Nn=C0, Kk=self.ldk, ldp=C0,
-                        ldq=self.ldk, dW=self.dw_stem_pad, sn=self.ldk, sk=1, db=Gd["encoder.initial_conv.0.bias"])
+            self._wgrad(b, "stem:conv.wgrad", "NONE", "NONE", wait=("stem_pad_zero",) if zs else (), P=dc1, Q=self.col, M=Mc, Nn=C0, Kk=self.ldk, ldp=C0,
+                        ldq=self.ldk, dW=self.dw_stem_pad, sn=self.ldk, sk=1, db=Gd[bkey])
             # (C0, 9*Cin) padded row-major -> ME kernel layout (9, Cin, C0)
-            self._op(b, "stem:conv.dW.fold", lib.mpmae_strided_add, _p(Gd["encoder.initial_conv.0.kernel"]),
+            self._op(b, "stem:conv.dW.fold", lib.mpmae_strided_add, _p(Gd[kkey]),
                      _p(self.dw_stem_pad), C0, Kc, self.ldk, 1, C0)
         else:
             self._wgrad(b, "stem:conv.wgrad", "NONE", "IM2COL3", P=dc1, Q=self.inp["sentinel2"], M=self.Mfull, Nn=C0,

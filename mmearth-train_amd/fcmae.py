@@ -114,8 +114,6 @@ class FCMAE(nn.Module):
                  norm_pix_loss: bool = False, args: Namespace = None, loss_fn=None, sparse: bool = True,
                  device=None, dtype: str = "bf16"):
         super().__init__()
-        if getattr(args, "use_orig_stem", False):
-            raise NotImplementedError("use_orig_stem=True is not used by any reference recipe (TRAINING.md:39)")
         depths = depths or [3, 3, 9, 3]
         dims = dims or [96, 192, 384, 768]
         name = next((k for k, (d, c) in SIZES.items() if d == list(depths) and c == list(dims)), None)

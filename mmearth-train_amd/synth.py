@@ -22,15 +22,22 @@ def state_dict_spec(cfg: ModelCfg):
     C = cfg.dims
     k = cfg.stem_k
     add = spec.append
+    orig = bool(getattr(cfg, "use_orig_stem", False))
     if getattr(cfg, "sparse", True):
-        add(("encoder.initial_conv.0.kernel", (9, cfg.in_chans, C[0]), "w"))
-        add(("encoder.initial_conv.0.bias", (1, C[0]), "b"))
-        add(("encoder.initial_conv.1.ln.weight", (C[0],), "g"))
-        add(("encoder.initial_conv.1.ln.bias", (C[0],), "b"))
-        add(("encoder.stem.0.kernel", (k * k, C[0]), "w"))
-        add(("encoder.stem.0.bias", (1, C[0]), "b"))
-        add(("encoder.stem.1.ln.weight", (C[0],), "g"))
-        add(("encoder.stem.1.ln.bias", (C[0],), "b"))
+        if orig:      # convnextv2_sparse.py:99-110: MinkowskiConvolution k = s = patch / 8 (kernel (Cin, C0) when k = 1, else (k*k, Cin, C0)) + LN
+            add(("encoder.stem_orig.0.kernel", (cfg.in_chans, C[0]) if k == 1 else (k * k, cfg.in_chans, C[0]), "w"))
+            add(("encoder.stem_orig.0.bias", (1, C[0]), "b"))
+            add(("encoder.stem_orig.1.ln.weight", (C[0],), "g"))
+            add(("encoder.stem_orig.1.ln.bias", (C[0],), "b"))
+        else:
+            add(("encoder.initial_conv.0.kernel", (9, cfg.in_chans, C[0]), "w"))
+            add(("encoder.initial_conv.0.bias", (1, C[0]), "b"))
+            add(("encoder.initial_conv.1.ln.weight", (C[0],), "g"))
+            add(("encoder.initial_conv.1.ln.bias", (C[0],), "b"))
+            add(("encoder.stem.0.kernel", (k * k, C[0]), "w"))
+            add(("encoder.stem.0.bias", (1, C[0]), "b"))
+            add(("encoder.stem.1.ln.weight", (C[0],), "g"))
+            add(("encoder.stem.1.ln.bias", (C[0],), "b"))
         for i in range(3):
             p = f"encoder.downsample_layers.{i}"
             add((p + ".0.ln.weight", (C[i],), "g"))
@@ -53,14 +60,20 @@ def state_dict_spec(cfg: ModelCfg):
     else:
         # dense ConvNeXtV2 (models/convnextv2.py:97-155): nn.Conv2d / nn.Linear / norm_layers.LayerNorm, GRN layouts; `norm` and `head`
         # (:151-152) are part of its state dict but not of the pretraining graph (they never receive a gradient)
-        add(("encoder.initial_conv.0.weight", (C[0], cfg.in_chans, 3, 3), "w"))
-        add(("encoder.initial_conv.0.bias", (C[0],), "b"))
-        add(("encoder.initial_conv.1.weight", (C[0],), "g"))
-        add(("encoder.initial_conv.1.bias", (C[0],), "b"))
-        add(("encoder.stem.0.weight", (C[0], 1, k, k), "w"))
-        add(("encoder.stem.0.bias", (C[0],), "b"))
-        add(("encoder.stem.1.weight", (C[0],), "g"))
-        add(("encoder.stem.1.bias", (C[0],), "b"))
+        if orig:      # convnextv2.py:97-106: nn.Conv2d k = s = patch / 8 + channels-first LayerNorm
+            add(("encoder.stem_orig.0.weight", (C[0], cfg.in_chans, k, k), "w"))
+            add(("encoder.stem_orig.0.bias", (C[0],), "b"))
+            add(("encoder.stem_orig.1.weight", (C[0],), "g"))
+            add(("encoder.stem_orig.1.bias", (C[0],), "b"))
+        else:
+            add(("encoder.initial_conv.0.weight", (C[0], cfg.in_chans, 3, 3), "w"))
+            add(("encoder.initial_conv.0.bias", (C[0],), "b"))
+            add(("encoder.initial_conv.1.weight", (C[0],), "g"))
+            add(("encoder.initial_conv.1.bias", (C[0],), "b"))
+            add(("encoder.stem.0.weight", (C[0], 1, k, k), "w"))
+            add(("encoder.stem.0.bias", (C[0],), "b"))
+            add(("encoder.stem.1.weight", (C[0],), "g"))
+            add(("encoder.stem.1.bias", (C[0],), "b"))
         for i in range(3):
             p = f"encoder.downsample_layers.{i}"
             add((p + ".0.weight", (C[i],), "g"))
@@ -116,7 +129,7 @@ def state_dict_spec(cfg: ModelCfg):
 
 
 def _dense_conv_key(key):
-    return key == "encoder.initial_conv.0.weight" or (key.startswith("encoder.downsample_layers.") and key.endswith(".1.weight"))
+    return key in ("encoder.initial_conv.0.weight", "encoder.stem_orig.0.weight") or (key.startswith("encoder.downsample_layers.") and key.endswith(".1.weight"))
 
 
 def param_view(buf, key, shape):
@@ -137,12 +150,17 @@ def dense_aliases(cfg):
     """(engine-internal key, state-dict key, internal shape) for the dense encoder's stem and downsampling layers: the engine's launch
     program addresses them under the sparse encoder's names and layouts (same storage, see param_view)."""
     C, k = cfg.dims, cfg.stem_k
-    out = [("encoder.initial_conv.0.kernel", "encoder.initial_conv.0.weight", (9, cfg.in_chans, C[0])),
-           ("encoder.initial_conv.1.ln.weight", "encoder.initial_conv.1.weight", (C[0],)),
-           ("encoder.initial_conv.1.ln.bias", "encoder.initial_conv.1.bias", (C[0],)),
-           ("encoder.stem.0.kernel", "encoder.stem.0.weight", (k * k, C[0])),
-           ("encoder.stem.1.ln.weight", "encoder.stem.1.weight", (C[0],)),
-           ("encoder.stem.1.ln.bias", "encoder.stem.1.bias", (C[0],))]
+    if getattr(cfg, "use_orig_stem", False):
+        out = [("encoder.stem_orig.0.kernel", "encoder.stem_orig.0.weight", (k * k, cfg.in_chans, C[0])),
+               ("encoder.stem_orig.1.ln.weight", "encoder.stem_orig.1.weight", (C[0],)),
+               ("encoder.stem_orig.1.ln.bias", "encoder.stem_orig.1.bias", (C[0],))]
+    else:
+        out = [("encoder.initial_conv.0.kernel", "encoder.initial_conv.0.weight", (9, cfg.in_chans, C[0])),
+               ("encoder.initial_conv.1.ln.weight", "encoder.initial_conv.1.weight", (C[0],)),
+               ("encoder.initial_conv.1.ln.bias", "encoder.initial_conv.1.bias", (C[0],)),
+               ("encoder.stem.0.kernel", "encoder.stem.0.weight", (k * k, C[0])),
+               ("encoder.stem.1.ln.weight", "encoder.stem.1.weight", (C[0],)),
+               ("encoder.stem.1.ln.bias", "encoder.stem.1.bias", (C[0],))]
     for i in range(3):
         p = f"encoder.downsample_layers.{i}"
         out += [(p + ".0.ln.weight", p + ".0.weight", (C[i],)), (p + ".0.ln.bias", p + ".0.bias", (C[i],)),
@@ -155,6 +173,8 @@ def _fan_in(key, shape):
         return shape[0]
     if key.endswith("dwconv.weight"):
         return 49
+    if key == "encoder.stem_orig.0.kernel":
+        return shape[0] if len(shape) == 2 else shape[0] * shape[1]
     if key.endswith(".kernel"):
         return shape[0] * shape[1]
     n = 1

@@ -94,7 +94,7 @@ def sparse_block(sd, pre, x, act):
 
 
 def sparse_encoder(sd, imgs, mask, cfg, taps=None):
-    """SparseConvNeXtV2.forward (convnextv2_sparse.py:191-220), default stem.
+    """SparseConvNeXtV2.forward (convnextv2_sparse.py:191-220), default stem or use_orig_stem.
     imgs [N,Cin,S,S] (NOT modified), mask [N,L] -> dense [N,C3,grid,grid]."""
     L = mask.shape[1]
     scale = int(cfg.img_size // (L ** 0.5))
@@ -102,19 +102,29 @@ def sparse_encoder(sd, imgs, mask, cfg, taps=None):
     x = imgs * (1.0 - up)                                        # :197 (in place in the reference)
     act = (x.abs().sum(1, keepdim=True) != 0).type_as(x)         # to_sparse (:199)
     C = cfg.dims
-    # initial_conv (:113-119): 3x3 s1 + bias -> LN -> GELU
-    w = _me_conv_weight(sd["encoder.initial_conv.0.kernel"], 3)
-    x = (F.conv2d(x, w, padding=1) + sd["encoder.initial_conv.0.bias"].reshape(1, C[0], 1, 1)) * act
-    x = _ln_map(x, act, sd["encoder.initial_conv.1.ln.weight"], sd["encoder.initial_conv.1.ln.bias"])
-    x = F.gelu(x) * act
-    # stem (:121-130): depthwise k = s = patch/8 + bias -> LN
     k = cfg.stem_k
-    wd = _me_dw_weight(sd["encoder.stem.0.kernel"].reshape(k * k, C[0]), k)
-    x = F.conv2d(x, wd, stride=k, groups=C[0]) + sd["encoder.stem.0.bias"].reshape(1, C[0], 1, 1)
-    if k > 1:
-        act = F.max_pool2d(act, k)
-    x = x * act
-    x = _ln_map(x, act, sd["encoder.stem.1.ln.weight"], sd["encoder.stem.1.ln.bias"])
+    if getattr(cfg, "use_orig_stem", False):
+        # stem_orig (:99-110, forward :202-203): MinkowskiConvolution k = s = patch / 8, Cin -> C0, + bias at the active OUTPUT sites
+        # (k = 1: same sites; k > 1: a site is active iff any of its k x k children is) -> LN
+        w = _me_conv_weight(sd["encoder.stem_orig.0.kernel"], k)
+        x = F.conv2d(x, w, stride=k) + sd["encoder.stem_orig.0.bias"].reshape(1, C[0], 1, 1)
+        if k > 1:
+            act = F.max_pool2d(act, k)
+        x = x * act
+        x = _ln_map(x, act, sd["encoder.stem_orig.1.ln.weight"], sd["encoder.stem_orig.1.ln.bias"])
+    else:
+        # initial_conv (:113-119): 3x3 s1 + bias -> LN -> GELU
+        w = _me_conv_weight(sd["encoder.initial_conv.0.kernel"], 3)
+        x = (F.conv2d(x, w, padding=1) + sd["encoder.initial_conv.0.bias"].reshape(1, C[0], 1, 1)) * act
+        x = _ln_map(x, act, sd["encoder.initial_conv.1.ln.weight"], sd["encoder.initial_conv.1.ln.bias"])
+        x = F.gelu(x) * act
+        # stem (:121-130): depthwise k = s = patch/8 + bias -> LN
+        wd = _me_dw_weight(sd["encoder.stem.0.kernel"].reshape(k * k, C[0]), k)
+        x = F.conv2d(x, wd, stride=k, groups=C[0]) + sd["encoder.stem.0.bias"].reshape(1, C[0], 1, 1)
+        if k > 1:
+            act = F.max_pool2d(act, k)
+        x = x * act
+        x = _ln_map(x, act, sd["encoder.stem.1.ln.weight"], sd["encoder.stem.1.ln.bias"])
     if taps is not None:
         taps["stem_out"] = x
     for i in range(4):
@@ -154,10 +164,14 @@ def dense_encoder(sd, imgs, mask, cfg, taps=None):
     x = imgs * (1.0 - up)                                        # :190 (in place in the reference)
     C = cfg.dims
     k = cfg.stem_k
-    x = F.conv2d(x, sd["encoder.initial_conv.0.weight"], sd["encoder.initial_conv.0.bias"])
-    x = F.gelu(_ln_cf(x, sd["encoder.initial_conv.1.weight"], sd["encoder.initial_conv.1.bias"]))
-    x = F.conv2d(x, sd["encoder.stem.0.weight"], sd["encoder.stem.0.bias"], stride=k, padding=k // 2, groups=C[0])
-    x = _ln_cf(x, sd["encoder.stem.1.weight"], sd["encoder.stem.1.bias"])
+    if getattr(cfg, "use_orig_stem", False):      # convnextv2.py:97-106,193-194: Conv2d k = s = patch / 8 (no padding) -> channels-first LN
+        x = F.conv2d(x, sd["encoder.stem_orig.0.weight"], sd["encoder.stem_orig.0.bias"], stride=k)
+        x = _ln_cf(x, sd["encoder.stem_orig.1.weight"], sd["encoder.stem_orig.1.bias"])
+    else:
+        x = F.conv2d(x, sd["encoder.initial_conv.0.weight"], sd["encoder.initial_conv.0.bias"])
+        x = F.gelu(_ln_cf(x, sd["encoder.initial_conv.1.weight"], sd["encoder.initial_conv.1.bias"]))
+        x = F.conv2d(x, sd["encoder.stem.0.weight"], sd["encoder.stem.0.bias"], stride=k, padding=k // 2, groups=C[0])
+        x = _ln_cf(x, sd["encoder.stem.1.weight"], sd["encoder.stem.1.bias"])
     if taps is not None:
         taps["stem_out"] = x
     for i in range(4):

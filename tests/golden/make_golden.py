@@ -36,7 +36,7 @@ from tests.golden_cases import (CASES, GRAD_SLICES, case_cfg, case_data, checks,
 def run_reference(c, cfg, sd, inputs, noise_seed):
     from oracle.refharness.load_reference import load
     ref = load()
-    args = default_args(out_modalities=M.subset(c["subset"]), loss_aggr=c["aggr"])
+    args = default_args(out_modalities=M.subset(c["subset"]), loss_aggr=c["aggr"], use_orig_stem=c.get("orig_stem", False))
     loss_fn = (ref.custom_loss.UncertaintyWeightingStrategy(len(cfg.out_mods))
                if c["aggr"] == "uncertainty" else None)
     model = ref.fcmae.__dict__[c["model"]](

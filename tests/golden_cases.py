@@ -35,10 +35,20 @@ CASES = OrderedDict(
     # (tests/pretrain_test.py:17); its stem only lines up at patch 16 (convnextv2.py:108-124)
     allmod_atto_112_dense=dict(model="convnextv2_atto", img=112, patch=16, subset="all_mod", N=2,
                                norm_pix=True, aggr="uncertainty", wseed=18, iseed=28, nseed=38, sparse=False),
+    # use_orig_stem=True (convnextv2_sparse.py:99-110,202-203 / convnextv2.py:97-106): one convolution k = s = patch / 8 + LN instead of
+    # initial_conv + depthwise stem; k = 1 at patch 8 (ME kernel (Cin, C0)), k = 2 at patch 16, and the dense encoder's Conv2d form
+    allmod_atto_56_origstem=dict(model="convnextv2_atto", img=56, patch=8, subset="all_mod", N=2,
+                                 norm_pix=True, aggr="uncertainty", wseed=19, iseed=29, nseed=39, orig_stem=True, zero_pix=True),
+    allmod_atto_112_origstem=dict(model="convnextv2_atto", img=112, patch=16, subset="all_mod", N=2,
+                                  norm_pix=True, aggr="uncertainty", wseed=20, iseed=30, nseed=40, orig_stem=True, zero_pix=True),
+    allmod_atto_112_dense_origstem=dict(model="convnextv2_atto", img=112, patch=16, subset="all_mod", N=2,
+                                        norm_pix=True, aggr="uncertainty", wseed=21, iseed=31, nseed=41, sparse=False, orig_stem=True),
 )
 
 GRAD_SLICES = {
     "encoder.initial_conv.0.kernel": (slice(None), slice(None), slice(None, None, 4)),
+    "encoder.stem_orig.0.kernel": (Ellipsis, slice(None, None, 4)),
+    "encoder.stem_orig.0.weight": (slice(None, None, 4), slice(None)),
     "encoder.stages.2.3.grn.gamma": (slice(None), slice(None, None, 4)),
     "encoder.stages.0.1.dwconv.kernel": (slice(None), slice(None, None, 4)),
     "encoder.downsample_layers.1.1.kernel": (slice(None), slice(None, None, 8), slice(None, None, 8)),
@@ -57,7 +67,7 @@ GRAD_SLICES = {
 def case_cfg(c):
     return make_cfg(c["model"], c["img"], c["patch"], out_modalities=M.subset(c["subset"]),
                     norm_pix_loss=c["norm_pix"], loss_aggr=c["aggr"], decoder_depth=c.get("decoder_depth", 1),
-                    sparse=c.get("sparse", True))
+                    sparse=c.get("sparse", True), use_orig_stem=c.get("orig_stem", False))
 
 
 def case_data(c, cfg):

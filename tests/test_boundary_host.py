@@ -62,6 +62,28 @@ def test_init_reference_distributions(lib):
             assert (v == 1).all(), k
 
 
+def test_use_orig_stem_state_dict_layout():
+    """args.use_orig_stem=True (convnextv2_sparse.py:99-110 / convnextv2.py:97-106; the last constructor option that raised until round 5):
+    the encoder's stem tensors are `stem_orig.0.kernel` - (Cin, C0) at patch 8 where k = s = 1, (4, Cin, C0) at patch 16 - `.0.bias (1, C0)`
+    and `.1.ln.*`, and there is no initial_conv / stem; the dense encoder carries nn.Conv2d / LayerNorm names and shapes. (That these
+    are the reference's keys is pinned by tests/golden/make_golden.py, which loads them into the reference's own model with strict=True.)"""
+    from mmearth_train_amd import MODALITIES as MM
+    from mmearth_train_amd import fcmae
+    from mmearth_train_amd.config import default_args
+    from mmearth_train_amd.custom_loss import UncertaintyWeightingStrategy
+    args = default_args(out_modalities=MM.subset("all_mod"), use_orig_stem=True)
+    mk = lambda **kw: fcmae.convnextv2_atto(mask_ratio=0.6, decoder_depth=1, decoder_embed_dim=512, norm_pix_loss=True, args=args,
+                                            loss_fn=UncertaintyWeightingStrategy(12), device="cpu", **kw)
+    sd = mk(patch_size=8, img_size=56).state_dict()
+    assert tuple(sd["encoder.stem_orig.0.kernel"].shape) == (12, 40) and tuple(sd["encoder.stem_orig.0.bias"].shape) == (1, 40)
+    assert "encoder.stem_orig.1.ln.weight" in sd and not any(k.startswith(("encoder.initial_conv", "encoder.stem.")) for k in sd)
+    sd = mk(patch_size=16, img_size=112).state_dict()
+    assert tuple(sd["encoder.stem_orig.0.kernel"].shape) == (4, 12, 40)
+    sd = mk(patch_size=16, img_size=112, sparse=False).state_dict()
+    assert tuple(sd["encoder.stem_orig.0.weight"].shape) == (40, 12, 2, 2) and tuple(sd["encoder.stem_orig.1.weight"].shape) == (40,)
+    assert not any(k.startswith(("encoder.initial_conv", "encoder.stem.")) for k in sd)
+
+
 def test_dense_mode_state_dict_is_the_reference_layout_over_kernel_major_storage():
     """FCMAE(sparse=False) (fcmae.py:103-111): parameter names / shapes are those of the dense ConvNeXtV2 (convnextv2.py:97-155,
     incl. its unused `norm` / `head`), initialised as fcmae.py:157-178 leaves them; the convolution weights of the stem and the

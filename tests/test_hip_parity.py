@@ -45,7 +45,8 @@ def _rel(a, b):
 
 
 F32_CASES = ["allmod_atto_56", "s2_atto_56_bs4", "allmod_atto_56_unweighted", "pixmod_atto_56",
-             "allmod_atto_56_zeropix", "allmod_tiny_112", "allmod_atto_56_dec2", "allmod_atto_112_dense"]
+             "allmod_atto_56_zeropix", "allmod_tiny_112", "allmod_atto_56_dec2", "allmod_atto_112_dense",
+             "allmod_atto_56_origstem", "allmod_atto_112_origstem", "allmod_atto_112_dense_origstem"]      # (use_orig_stem=True, round 5)
 
 
 @pytest.mark.parametrize("name", F32_CASES)
@@ -103,11 +104,12 @@ def test_fp32_step_matches_oracle_and_golden(name):
 
 
 @pytest.mark.parametrize("model,img,patch", [("convnextv2_femto", 56, 8), ("convnextv2_pico", 56, 8), ("convnextv2_nano", 56, 8),
-                                             ("convnextv2_base", 56, 8), ("convnextv2_nano", 112, 16)])
+                                             ("convnextv2_base", 56, 8), ("convnextv2_nano", 112, 16),
+                                             ("convnextv2_large", 56, 8), ("convnextv2_huge", 56, 8)])      # (large / huge: round 5)
 def test_other_size_factories_run_on_the_hip_path(model, img, patch):
     """The size factories the reference exports besides atto / tiny (models/fcmae.py:459-496: femto 48..384, pico 64..512, nano 80..640
     with depth 8 at stage 2, base 128..1024 with 27 blocks at stage 2 - more than the persistent stage kernel's block table and deeper
-    than the backward scratch rings) as one full step at N = 2 against the oracle: fp32 mode to the fp32 bounds (loss 1e-4, every
+    than the backward scratch rings, large 192..1536, huge 352..2816 - widths none of the fused pointwise instantiations take) as one full step at N = 2 against the oracle: fp32 mode to the fp32 bounds (loss 1e-4, every
     parameter gradient 2e-4), bf16 mode to the stated bf16 bounds (losses 2e-2, total 1e-2, gradient cosine >= 0.99 / 0.999 flat)."""
     from mmearth_train_amd import MODALITIES as M
     from mmearth_train_amd.config import make_cfg
@@ -147,7 +149,8 @@ def test_other_size_factories_run_on_the_hip_path(model, img, patch):
 
 
 @pytest.mark.parametrize("name", ["allmod_atto_56", "allmod_tiny_112", "allmod_atto_56_zeropix", "allmod_atto_56_dec2",
-                                  "allmod_atto_112_dense"])
+                                  "allmod_atto_112_dense", "allmod_atto_56_origstem", "allmod_atto_112_origstem",
+                                  "allmod_atto_112_dense_origstem"])
 def test_bf16_step_within_stated_tolerance(name):
     c = CASES[name]
     cfg = case_cfg(c)

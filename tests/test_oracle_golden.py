@@ -13,7 +13,8 @@ from oracle import mpmae_ref as O
 from tests.golden_cases import CASES, GRAD_SLICES, case_cfg, case_data, checks, load_fixture, strided
 
 FAST = ["allmod_atto_56", "s2_atto_56_bs4", "allmod_atto_56_unweighted", "pixmod_atto_56",
-        "allmod_atto_56_zeropix", "allmod_atto_56_dec2", "allmod_atto_112_dense"]
+        "allmod_atto_56_zeropix", "allmod_atto_56_dec2", "allmod_atto_112_dense", "allmod_atto_56_origstem",
+        "allmod_atto_112_origstem", "allmod_atto_112_dense_origstem"]
 
 
 def _close(a, b, rtol, what):
