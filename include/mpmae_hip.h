@@ -88,6 +88,9 @@ typedef struct MpmaeWgradArgs {
   const int* vis; const int* inv; const uint8_t* act_src;
   int keep, L, S, Cseg, grid, H;
   float* ws; size_t ws_floats;       /* scratch for the per-split partial slabs */
+  const float* rowscale;             /* optional (NULL): [Nn] per-output-row factors applied by the second-stage fold, dW[n][:] += rowscale[n] * (...),
+                                        db[n] += rowscale[n] * (...): the per-modality scalars of the one-pass losses (mpmae_head_scale). bf16,
+                                        contiguous dW (sn == Kk, sk == 1), no prologues - otherwise the call fails */
 } MpmaeWgradArgs;
 
 typedef struct MpmaeDwArgs {
@@ -492,8 +495,18 @@ int mpmae_loss_pix_cont_rows(int dt, const void* dev_args, int count, int N, int
 /* Gradient twin (same band walk, no statistics): d pred of every record, zeros at patches that were not counted. */
 int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
                                  mpmae_stream_t stream);
+/* One-pass form (round 5): the forward of mpmae_loss_pix_cont_rows that ALSO writes args->dpred WITHOUT the per-modality scalar coef
+ * (mask * 2 / count * (pred - normalised target) at counted patches, zero elsewhere; fcmae.py:366-403 differentiated). The scalar -
+ * known only after mpmae_loss_finalize - is applied by the consumers: mpmae_head_scale scales the heads' staged transposed weights per
+ * modality segment (data gradient) and fills MpmaeWgradArgs.rowscale (weight / bias gradient). mpmae_loss_pix_cat_waves(bwd = 2) is the
+ * categorical twin (softmax - onehot at masked, labelled pixels). */
+int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
+                                   mpmae_stream_t stream);
+/* B [D][ldb] (staged transposed head weights, storage type dt): column k *= coef[col_mod[k]] in place; rowscale[k] = coef[col_mod[k]]. */
+int mpmae_head_scale(int dt, void* B, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale,
+                     mpmae_stream_t stream);
 /* Categorical pixel losses, wave-per-patch form (forward bwd = 0 / gradient bwd = 1): same records, outputs and partial layout as
- * mpmae_loss_multi(kind 1). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and
+ * mpmae_loss_multi(kind 1); bwd = 2: forward + UNSCALED gradient in one pass (mpmae_loss_pix_cont_rows_fused). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and
  * coff % 4 == 0 (vector accesses); 16 * max_pk elements of LDS. */
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk,
                              mpmae_stream_t stream);

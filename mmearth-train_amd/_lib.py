@@ -41,7 +41,7 @@ class WgradArgs(C.Structure):
                 ("vis", c_void_p), ("inv", c_void_p), ("act_src", c_void_p),
                 ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
                 ("H", c_int),
-                ("ws", c_void_p), ("ws_floats", c_size_t)]
+                ("ws", c_void_p), ("ws_floats", c_size_t), ("rowscale", c_void_p)]
 
 
 class DwArgs(C.Structure):
@@ -215,6 +215,8 @@ SYMBOLS = {
     "mpmae_loss_multi": [c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_bwd": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mpmae_loss_pix_cont_rows_fused": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mpmae_head_scale": [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],

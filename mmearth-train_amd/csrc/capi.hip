@@ -29,6 +29,14 @@ void launch_reduce(int mode, const float* part, int P, int W, float* out, float*
   else LAUNCH(reduce_partials_kernel<2>, g, dim3(256), 0, st, part, P, W, out, out2, a, b, c, d);
 }
 
+void launch_reduce_rowscale(const float* part, int P, int W, float* out, float* out2, int nk, int Kk, const float* rs, hipStream_t st) {
+  int R = P / 16;
+  if (R < 1) R = 1;
+  if (R > 32) R = 32;
+  if (g_opt[MPMAE_OPT_DET] > 0) R = 1;
+  LAUNCH(reduce_partials_rowscale_kernel, dim3(cdiv(W, 64), R), dim3(256), 0, st, part, P, W, out, out2, nk, Kk, rs);
+}
+
 // ------------------------------------------------------------------------------------------
 // Library options (mpmae_set_option): explicit, process-wide A/B switches of kernel selection. They replace environment
 // variables read inside the library; defaults are the measured-best choices.
@@ -834,6 +842,7 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
 }
 
 static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  if (bwd < 0 || bwd > 2) return (int)hipErrorInvalidValue;
   if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)maxC * (p * H + 4) * 4;
   const int nvec = maxC * p * (H / 4), npv = maxC * p * p / 4;
@@ -844,7 +853,7 @@ static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int co
     static size_t cur = 48 * 1024; \
     if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cont_rows_kernel<TT, MV, MP, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
     LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP, BW>), dim3(N, count), dim3(512), lds, S_(s), tab); } while (0)
-#define LPR2(TT, MV, MP) do { if (bwd) LPR(TT, MV, MP, true); else LPR(TT, MV, MP, false); } while (0)
+#define LPR2(TT, MV, MP) do { if (bwd == 1) LPR(TT, MV, MP, 1); else if (bwd == 2) LPR(TT, MV, MP, 2); else LPR(TT, MV, MP, 0); } while (0)
   if (mv <= 3 && mp <= 3) { if (dt == 0) LPR2(float, 3, 3); else LPR2(bf16_t, 3, 3); }
   else { if (dt == 0) LPR2(float, 12, 12); else LPR2(bf16_t, 12, 12); }
 #undef LPR2
@@ -860,8 +869,12 @@ int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N,
   return loss_pix_cont_rows_impl(dt, 1, dev_args, count, N, maxC, p, H, s);
 }
 
+int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  return loss_pix_cont_rows_impl(dt, 2, dev_args, count, N, maxC, p, H, s);
+}
+
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {
-  if (!dev_args || count < 1 || N < 1 || max_pk < 4 || (max_pk & 3)) return (int)hipErrorInvalidValue;
+  if (!dev_args || count < 1 || N < 1 || max_pk < 4 || (max_pk & 3) || bwd < 0 || bwd > 2) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)16 * max_pk * (dt == 0 ? 4 : 2);
   if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
   const auto* tab = (const MpmaePixCatArgs*)dev_args;
@@ -869,8 +882,8 @@ int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, i
     static size_t cur = 48 * 1024; \
     if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cat_waves_kernel<TT, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
     LAUNCH((loss_pix_cat_waves_kernel<TT, BW>), dim3(N, count), dim3(1024), lds, S_(s), tab, max_pk); } while (0)
-  if (dt == 0) { if (bwd) LCW(float, true); else LCW(float, false); }
-  else { if (bwd) LCW(bf16_t, true); else LCW(bf16_t, false); }
+  if (dt == 0) { if (bwd == 1) LCW(float, 1); else if (bwd == 2) LCW(float, 2); else LCW(float, 0); }
+  else { if (bwd == 1) LCW(bf16_t, 1); else if (bwd == 2) LCW(bf16_t, 2); else LCW(bf16_t, 0); }
 #undef LCW
   RET();
 }
@@ -945,6 +958,14 @@ int mpmae_gather_kxk(int dt, const float* img, const int* vis, const int* inv, v
   const int g = grid1d((long long)rows * ldo, 256, 8192);
   if (dt == 0) LAUNCH(gather_kxk_kernel<float>, dim3(g), dim3(256), 0, S_(s), img, vis, inv, (float*)out, ldo, keep, grid, p, k, Cseg, H, rows);
   else LAUNCH(gather_kxk_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), img, vis, inv, (bf16_t*)out, ldo, keep, grid, p, k, Cseg, H, rows);
+  RET();
+}
+
+int mpmae_head_scale(int dt, void* B, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale, mpmae_stream_t s) {
+  if (!B || !col_mod || !coef || !rowscale || D < 1 || W < 1 || ldb < W) return (int)hipErrorInvalidValue;
+  const int g = grid1d((long long)D * W, 256, 2048);
+  if (dt == 0) LAUNCH(head_scale_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)B, ldb, D, W, col_mod, coef, rowscale);
+  else LAUNCH(head_scale_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)B, ldb, D, W, col_mod, coef, rowscale);
   RET();
 }
 

@@ -62,5 +62,6 @@ static inline int grid1d(long long total, int per_block = 256, int cap = 16384) 
 
 // second stage of the two-stage reductions (reduce_partials_kernel in misc.cuh; defined in capi.hip)
 void launch_reduce(int mode, const float* part, int P, int W, float* out, float* out2, int a, int b, int c, int d, hipStream_t st);
+void launch_reduce_rowscale(const float* part, int P, int W, float* out, float* out2, int nk, int Kk, const float* rs, hipStream_t st);
 extern int g_opt[MPMAE_OPT_COUNT_];      // library options (mpmae_set_option; capi.hip)
 int ps_num_cus();                        // (capi_rs.hip)

@@ -266,6 +266,8 @@ static int launch_wgrad(int ppro, int qpro, const WgradP& a, int splits, hipStre
 
 int mpmae_wgrad(int dt, int ppro, int qpro, const MpmaeWgradArgs* args, int splits, mpmae_stream_t s) {
   if (!args || splits < 1) return (int)hipErrorInvalidValue;
+  // rowscale (one-pass losses): folded by the second stage of the bf16 kernels only, contiguous dW
+  if (args->rowscale && (args->sn != args->Kk || args->sk != 1 || !wgrad_fast_ok(dt, ppro, qpro, *args))) return (int)hipErrorInvalidValue;
   if (wgrad_fast_ok(dt, ppro, qpro, *args)) return launch_wgrad_fast(*args, S_(s), qpro == PRO_GRN);
   WgradP a = *args;
   const size_t per = (size_t)a.Nn * a.Kk + a.Nn;
@@ -583,7 +585,9 @@ static int launch_wgrad_tn3(WgradP a, bool swap, hipStream_t st) {
   if (swap) LAUNCH((gemm_tn3_kernel<true>), g, dim3(256), TN3_LDS, st, a, splits);
   else LAUNCH((gemm_tn3_kernel<false>), g, dim3(256), TN3_LDS, st, a, splits);
   const int nk = a.Nn * a.Kk;
-  if (a.sn == a.Kk && a.sk == 1) {
+  if (a.rowscale) {                              // (checked by mpmae_wgrad: contiguous dW)
+    launch_reduce_rowscale(a.ws, splits, nk + a.Nn, a.dW, a.db, nk, a.Kk, a.rowscale, st);
+  } else if (a.sn == a.Kk && a.sk == 1) {
     launch_reduce(3, a.ws, splits, nk + a.Nn, a.dW, a.db, nk, 0, 0, 0, st);
   } else {
     launch_reduce(1, a.ws, splits, nk + a.Nn, a.dW, nullptr, a.Kk, a.sn, a.sk, nk, st);
@@ -622,7 +626,9 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st, bool qgrn) {
   else if (nt == 5) launch_tn2<5, 5>(a, swap, splits, st, qgrn);
   else launch_tn2<4, 4>(a, swap, splits, st, qgrn);
   const int nk = a.Nn * a.Kk;
-  if (a.sn == a.Kk && a.sk == 1) {               // contiguous dW: weights and bias fold in one launch
+  if (a.rowscale) {
+    launch_reduce_rowscale(a.ws, splits, nk + a.Nn, a.dW, a.db, nk, a.Kk, a.rowscale, st);
+  } else if (a.sn == a.Kk && a.sk == 1) {               // contiguous dW: weights and bias fold in one launch
     launch_reduce(3, a.ws, splits, nk + a.Nn, a.dW, a.db, nk, 0, 0, 0, st);
   } else {
     launch_reduce(1, a.ws, splits, nk + a.Nn, a.dW, nullptr, a.Kk, a.sn, a.sk, nk, st);
@@ -647,6 +653,11 @@ static int launch_wgrad_fast(WgradP a, hipStream_t st, bool qgrn) {
   splits = cdiv(a.M, rps);
   dim3 g(cdiv(a.Nn, 128), cdiv(a.Kk, 128), splits);
   LAUNCH(gemm_tn_bf16_kernel, g, dim3(256), 0, st, a);
+  if (a.rowscale) {                              // (contiguous dW, checked by mpmae_wgrad)
+    launch_reduce_rowscale(a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Nn * a.Kk, a.Kk, a.rowscale, st);
+    if (a.db) launch_reduce_rowscale(a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, nullptr, a.db, 0, a.Kk, a.rowscale, st);
+    return launch_status();
+  }
   launch_reduce(1, a.ws, splits, a.Nn * a.Kk, a.dW, nullptr, a.Kk, a.sn, a.sk, 0, st);
   if (a.db) launch_reduce(0, a.ws + (size_t)splits * a.Nn * a.Kk, splits, a.Nn, a.db, nullptr, 0, 0, 0, 0, st);
   return launch_status();

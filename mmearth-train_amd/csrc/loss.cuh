@@ -292,8 +292,14 @@ __global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_multi_kernel(co
 // grid = (N, modalities); block = 512; dynamic LDS = max_C * (p*H + 4) * 4 bytes. MAXV / MAXP: float4 of the band per thread /
 // 4-element prediction vectors per lane and patch (3 / 3 at 56/8 with C <= 12, 11 / 12 at 112/16).
 // ---------------------------------------------------------------------------------
-template <typename T, int MAXV, int MAXP, bool BWD = false>
+// MODE 0: forward; 1: gradient pass (second walk over predictions and targets); 2 (round 5, "one-pass losses"): forward that ALSO writes the
+// gradient WITHOUT its per-modality scalar, d pred / coef = mask * 2 / count * (pred - normalised target) at counted patches, zero elsewhere -
+// everything but coef = loss_scale * dL_i / count_i (known only after the batch-wide finalisation) exists here already. The scalar is folded
+// into the consumers instead: the heads' data-gradient GEMM reads weights scaled per modality segment, their weight-gradient fold scales its
+// rows (mpmae_head_scale, MpmaeWgradArgs.rowscale): the second pass over 35 MB of predictions and 80 MB of targets leaves the step.
+template <typename T, int MAXV, int MAXP, int MODE = 0>
 __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP* __restrict__ tab) {
+  constexpr bool BWD = MODE == 1, FUSED = MODE == 2;
   const PixContP q = tab[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float lpc_band[];
   __shared__ float part[8][2];
@@ -404,6 +410,16 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       }
       if (mk == 0.f) {
         if (lane == 0) { q.patch_l[b] = 0.f; q.patch_cnt[b] = 0.f; q.patch_mean[b] = 0.f; q.patch_rstd[b] = 1.f; }
+        if constexpr (FUSED) {                                   // a visible patch carries no gradient
+          T* dp = reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff;
+#pragma unroll
+          for (int u = 0; u < MAXP; ++u) {
+            const int v = lane + 64 * u;
+            if (v >= npv) continue;
+            if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(dp + 4 * v) = make_float4(0.f, 0.f, 0.f, 0.f);
+            else *reinterpret_cast<uint2*>(dp + 4 * v) = make_uint2(0u, 0u);
+          }
+        }
         continue;
       }
       // the patch's prediction slice: contiguous, 4 elements per lane and load, all in flight before the statistics
@@ -464,6 +480,30 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
         q.patch_cnt[b] = cnt; q.patch_mean[b] = mean; q.patch_rstd[b] = rstd;
       }
       if (counted) { as += qv; ac += 1.f; }
+      if constexpr (FUSED) {
+        T* dp = reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff;
+        const float k = mk * 2.f / cnt;
+#pragma unroll
+        for (int u = 0; u < MAXP; ++u) {
+          const int v = lane + 64 * u;
+          if (v >= npv) continue;
+          float o[4] = {0.f, 0.f, 0.f, 0.f};
+          if (counted) {
+            int o4[4];
+            if constexpr (PRE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o4[e] = offq[u][e];
+            } else pred_off(u, o4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = pv[u][e] - (bp[o4[e]] - mean) * rstd;
+              o[e] = isnan(d * d) ? 0.f : k * d;
+            }
+          }
+          if constexpr (std::is_same<T, float>::value) *reinterpret_cast<float4*>(dp + 4 * v) = make_float4(o[0], o[1], o[2], o[3]);
+          else *reinterpret_cast<uint2*>(dp + 4 * v) = make_uint2(f2bf2(o[0], o[1]), f2bf2(o[2], o[3]));
+        }
+      }
     }
   }
   if constexpr (BWD) return;
@@ -570,8 +610,10 @@ __global__ __launch_bounds__(BWD ? 256 : 1024) void loss_pix_cat_multi_kernel(co
 // every lane then takes its pixels' K logits from LDS (log-sum-exp, cross entropy); the gradient is written back into the slot and
 // leaves as contiguous vectors. grid = (N, modalities); block = 1024 (16 waves); dynamic LDS = 16 * slot_elems * sizeof(T).
 // ---------------------------------------------------------------------------------
-template <typename T, bool BWD>
+// MODE 0 forward / 1 gradient / 2 forward + UNSCALED gradient softmax - onehot (see loss_pix_cont_rows_kernel)
+template <typename T, int MODE>
 __global__ __launch_bounds__(1024) void loss_pix_cat_waves_kernel(const PixCatP* __restrict__ tab, int slot_elems) {
+  constexpr bool BWD = MODE == 1, FUSED = MODE == 2, WR = MODE != 0;
   const PixCatP q = tab[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) unsigned char lcw_smem[];
   __shared__ float part[16][2];
@@ -579,14 +621,14 @@ __global__ __launch_bounds__(1024) void loss_pix_cat_waves_kernel(const PixCatP*
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   T* st = reinterpret_cast<T*>(lcw_smem) + (size_t)wave * slot_elems;
   const int p = q.p, K = q.K, PP = p * p, PK = PP * K, nv = PK >> 2;
-  const float kk = BWD ? q.coef[0] : 0.f;
+  const float kk = BWD ? q.coef[0] : 1.f;
   float se = 0.f, cnt = 0.f;
   for (int l = wave; l < q.L; l += 16) {
     const int b = n * q.L + l;
     const T* pred = reinterpret_cast<const T*>(q.pred) + (size_t)b * q.ld + q.coff;
-    T* dp = BWD ? reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff : nullptr;
+    T* dp = WR ? reinterpret_cast<T*>(q.dpred) + (size_t)b * q.ld + q.coff : nullptr;
     if (q.mask[b] != 1.f) {
-      if constexpr (BWD) {
+      if constexpr (WR) {
         V4 z4;
         if constexpr (std::is_same<T, float>::value) z4 = make_float4(0.f, 0.f, 0.f, 0.f); else z4 = make_uint2(0u, 0u);
         for (int v = lane; v < nv; v += 64) *reinterpret_cast<V4*>(dp + 4 * v) = z4;
@@ -610,16 +652,19 @@ __global__ __launch_bounds__(1024) void loss_pix_cat_waves_kernel(const PixCatP*
 #pragma unroll
       for (int c = 0; c < 16; ++c) sm += c < K ? __expf(z[c] - mx) : 0.f;
       const float lse = mx + __logf(sm);
-      if constexpr (BWD) {
+      if constexpr (WR) {
 #pragma unroll
         for (int c = 0; c < 16; ++c)
           if (c < K) stf<T>(st + pix * K + c, t != -1 ? kk * (__expf(z[c] - lse) - (c == t ? 1.f : 0.f)) : 0.f);
-      } else if (t != -1) {
-        se += lse - zt;
-        cnt += 1.f;
+      }
+      if constexpr (!BWD) {
+        if (t != -1) {
+          se += lse - zt;
+          cnt += 1.f;
+        }
       }
     }
-    if constexpr (BWD) {
+    if constexpr (WR) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       for (int v = lane; v < nv; v += 64) *reinterpret_cast<V4*>(dp + 4 * v) = *reinterpret_cast<const V4*>(st + 4 * v);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // the slot is reused by this wave's next patch

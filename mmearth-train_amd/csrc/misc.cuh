@@ -384,6 +384,47 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
   else atomicAdd(dst, s);
 }
 
+// MODE 3 with a per-output-row scale (one-pass losses, loss.cuh): e < nk -> out[e] += rs[e / Kk] * sum, else out2[e - nk] += rs[e - nk] * sum
+__global__ __launch_bounds__(256) void reduce_partials_rowscale_kernel(const float* __restrict__ part, int P, int W, float* __restrict__ out,
+                                                                       float* __restrict__ out2, int nk, int Kk, const float* __restrict__ rs) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col;
+  const int chunk = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+  float s = 0.f;
+  if (e < W) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || e >= W) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  float* dst;
+  if (e < nk) { if (!out) return; dst = out + e; s *= rs[e / Kk]; }
+  else { if (!out2) return; dst = out2 + (e - nk); s *= rs[e - nk]; }
+  if (gridDim.y == 1) *dst += s;
+  else atomicAdd(dst, s);
+}
+
+// One-pass losses: the per-modality gradient scalars coef[t] (mpmae_loss_finalize) applied where the unscaled loss gradient is consumed.
+// B [D][ldb] is the staged, transposed head weight (rows = decoder channels, columns = prediction columns): column k is multiplied by
+// coef[col_mod[k]] in place (the data-gradient GEMM then computes sum_t coef_t dpred_t W_t); rs[k] = the same scalar per prediction
+// column = per ROW of the heads' weight gradient (MpmaeWgradArgs.rowscale).
+template <typename T>
+__global__ __launch_bounds__(256) void head_scale_kernel(T* __restrict__ B, int ldb, int D, int W, const uint8_t* __restrict__ col_mod,
+                                                         const float* __restrict__ coef, float* __restrict__ rs) {
+  const int total = D * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / W, k = i - r * W;
+    const float c = coef[col_mod[k]];
+    T* q = B + (size_t)r * ldb + k;
+    stf<T>(q, ldf<T>(q) * c);
+    if (r == 0) rs[k] = c;
+  }
+}
+
 // Mode-2 second stage (depthwise taps + bias) for a GROUP of problems of one shape: blockIdx.z = problem, pointers from the table.
 struct ReduceGroupP { int count, pad; const float* part[12]; float* out[12]; float* out2[12]; };
 __global__ __launch_bounds__(256) void reduce_partials_group2_kernel(const ReduceGroupP r, int P, int W, int a, int b, int c, int d) {

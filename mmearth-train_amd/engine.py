@@ -73,6 +73,7 @@ ENGINE_OPTIONS = dict(
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
+    loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
 
@@ -1414,10 +1415,27 @@ class Engine:
                 self._op(f, f"loss:{om.name}", lib.mpmae_loss_img, dt, 0, C.byref(a))
         # one launch per loss KIND instead of one per modality (12 small latency-bound kernels -> 3)
         self.loss_multi = bool(self.opt["loss_multi"])
+        self.loss_onepass = False
         if self.loss_multi:
             while f and f[-1][0].startswith("loss:"):
                 f.pop()
             self._loss_tabs = {}
+            # one-pass pixel losses: bf16, both pixel kinds on their row-band / wave kernels (conditions repeated from below), merged heads
+            # (one data-gradient GEMM over all pixel heads, one contiguous weight gradient: the scalars become column / row scales)
+            cont_m = [om for om in cfg.out_mods if om.kind == "pix_cont"]
+            cat_m = [om for om in cfg.out_mods if om.kind == "pix_cat"]
+            mc_ = max([om.chans for om in cont_m], default=0)
+            mk_ = max([om.chans for om in cat_m], default=0)
+            ldp0 = self.pred_pix.shape[1] if cfg.pix_mods else 0
+            cont_ok = (not cont_m) or (bool(self.opt["loss_rows"]) and cfg.img_size % 4 == 0 and (self.p * self.p) % 4 == 0
+                                       and mc_ * (self.p * cfg.img_size + 4) * 4 <= 150 * 1024
+                                       and -(-(mc_ * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(mc_ * self.p * self.p // 4) // 64) <= 12)
+            cat_ok = (not cat_m) or (bool(self.opt["loss_rows"]) and mk_ <= 16 and ldp0 % 4 == 0
+                                     and all(self.head_cols[om.name] % 4 == 0 for om in cat_m) and (self.p * self.p * mk_) % 4 == 0
+                                     and 16 * self.p * self.p * mk_ * 4 <= 150 * 1024)
+            onepass = self.loss_onepass = (bool(self.opt["loss_onepass"]) and dt == BF16 and bool(cfg.pix_mods) and cont_ok and cat_ok
+                                           and bool(self.heads_merged.get("pix")) and self.D % 8 == 0
+                                           and bool(self.opt["loss_rows_bwd"]))
             for kind_id, kind, typ in ((0, "pix_cont", _lib.PixContArgs), (1, "pix_cat", _lib.PixCatArgs), (2, "img", None)):
                 mods = [om for om in cfg.out_mods if (om.kind == kind if typ else om.kind.startswith("img"))]
                 if not mods:
@@ -1432,9 +1450,9 @@ class Engine:
                         # the kernel's per-thread vector counts (loss_pix_cont_rows_impl: mv, mp <= 12), else mpmae_loss_multi
                         and -(-(maxc * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(maxc * self.p * self.p // 4) // 64) <= 12):
                     # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
-                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows, dt, _p(tab), len(mods), N, maxc,
-                             self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
                     self._cont_rows = maxc
+                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
+                             dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
                     continue
                 ldp_ = self.pred_pix.shape[1] if cfg.pix_mods else 0
                 cat_waves = (kind == "pix_cat" and bool(self.opt["loss_rows"]) and maxc <= 16 and ldp_ % 4 == 0
@@ -1443,7 +1461,7 @@ class Engine:
                 if kind == "pix_cat":
                     self._cat_waves = cat_waves
                 if cat_waves:      # wave per patch, logits staged through LDS with contiguous vector accesses (loss.cuh)
-                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cat_waves, dt, 0, _p(tab), len(mods), N,
+                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cat_waves, dt, 2 if onepass else 0, _p(tab), len(mods), N,
                              self.p * self.p * maxc, kind=f"loss_{kind}_fwd")
                     continue
                 self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_multi, dt, 0, kind_id, _p(tab), len(mods), N,
@@ -1533,9 +1551,25 @@ class Engine:
         dims = cfg.dims
         y = self.dec_out
         # loss gradients w.r.t. predictions
+        if self.loss_onepass:
+            # one-pass losses: the pixel losses' gradient already exists WITHOUT its per-modality scalar (written by the forward kernels);
+            # the scalars - final after the loss finalisation in front of this program - go into the staged transposed head weights (column
+            # segments: the data-gradient GEMM) and into `head_rs`, the row scales of the heads' weight-gradient fold
+            cm = torch.zeros(self.Wpix, dtype=torch.uint8)
+            for t, om in enumerate(cfg.out_mods):
+                if om.kind.startswith("pix"):
+                    c0 = self.head_cols[om.name]
+                    cm[c0:c0 + om.head_out] = t
+            self.head_col_mod = cm.to(self.device)
+            self.head_rs = torch.zeros(self.Wpix, dtype=torch.float32, device=self.device)
+            wt_ = self.w["head.pixT"]
+            self._op(b, "head:scale", lib.mpmae_head_scale, dt, _p(wt_["t"]), wt_["ld"], D, self.Wpix, _p(self.head_col_mod), _p(self.coef),
+                     _p(self.head_rs), kind="head_scale", nbytes=2 * D * self.Wpix * 2)
         if self.loss_multi:
             # (the categorical losses on the side lane next to the continuous ones, forward and gradient: 4.99 vs 4.97 ms, not kept)
             for kind, (kind_id, tab, cnt) in self._loss_tabs.items():
+                if self.loss_onepass and kind in ("pix_cont", "pix_cat"):
+                    continue
                 if kind == "pix_cont" and getattr(self, "_cont_rows", 0) and bool(self.opt["loss_rows_bwd"]):
                     self._op(b, f"dloss:{kind}[{cnt}]", lib.mpmae_loss_pix_cont_rows_bwd, dt, _p(tab), cnt, N, self._cont_rows,
                              self.p, cfg.img_size, kind=f"loss_{kind}_bwd")
@@ -1556,7 +1590,7 @@ class Engine:
             else:
                 self._op(b, f"dloss:{om.name}", lib.mpmae_loss_img, dt, 1, C.byref(a))
         # the last reader of the static input buffers (targets, mask noise -> mask): everything after it may overlap the next input stage
-        last_dl = max((i for i, op in enumerate(b) if op[0].startswith("dloss:")), default=None)
+        last_dl = max((i for i, op in enumerate(b) if op[0].startswith(("dloss:", "head:scale"))), default=None)
         self._inputs_free_key = None
         if last_dl is not None:
             if b[last_dl][3]["signal"] is None:
@@ -1572,7 +1606,7 @@ class Engine:
             m0 = cfg.pix_mods[0]        # all pixel heads at once: dW [Wpix, D] and db [Wpix] are contiguous (see _build_params)
             self._side_wgrad(b, "head:pix.wgrad", "NONE", "NONE", [], P=self.dpred_pix, Q=y, M=N * L, Nn=self.Wpix, Kk=D,
                              ldp=ldp, ldq=D, dW=Gd[f"pred_dict.{m0.name}.weight"], sn=D, sk=1,
-                             db=Gd[f"pred_dict.{m0.name}.bias"])
+                             db=Gd[f"pred_dict.{m0.name}.bias"], **(dict(rowscale=self.head_rs) if self.loss_onepass else {}))
         else:
           for om in cfg.pix_mods:
             pv = self.dpred_pix.view(-1)[self.head_cols[om.name]:]
