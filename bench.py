@@ -61,6 +61,11 @@ def build_parser():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--block-mode", default=None, choices=[None, "fused", "mat"], help="override the per-block program policy")
     ap.add_argument("--profile-ops", action="store_true", help="print the per-kernel-kind time table to stderr")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the multi-rank path (no GPU, no kernels): the N ranks are spawned exactly as for a real run, "
+                         "rendezvous over gloo, build the REAL launch program and gradient-bucket plan on the host, run the real StepRunner "
+                         "(segment order, bucketed all-reduce, loss slot, 1/world fold) over stand-in launches and print the bench line in its "
+                         "real shape with \"dry_run\": true - what a first 2/4/8-GPU run can fail on besides the kernels themselves")
     return ap
 
 
@@ -246,13 +251,110 @@ def _free_port():
         return sk.getsockname()[1]
 
 
-def _spawn_ranks(a):
+class _DryEngine:
+    """Stand-in for Engine in `--dry-run`: the real engine's static plan (offsets, flat buffers, backward op names, options) with the launch
+    methods replaced by host arithmetic - every backward segment adds (rank + 1) * step into the slice of the flat gradient buffer its
+    bucket covers, so the all-reduced buffer is checkable (sum over ranks) after every step."""
+
+    def __init__(self, real, rank, buckets):
+        self.real, self.rank, self.k, self.buckets = real, rank, 0, buckets
+        for name in ("device", "n_params", "offsets", "gflat", "gflat_ext", "pflat", "mflat", "vflat", "total", "bwd_ops", "opt", "hp"):
+            setattr(self, name, getattr(real, name))
+        self._scale, self._hp = 1.0, (0.0, 0, 1.0)
+
+    def forward(self):
+        self.k += 1
+        self.total.fill_(float(self.k))
+
+    def finalize_loss(self, st, dlv, scale):
+        self._scale = scale
+
+    def _stream(self):
+        return None
+
+    def _run(self, ops, st):
+        from mmearth_train_amd.dist import split_bwd_segments
+        segs = split_bwd_segments(self.bwd_ops)
+        names = [o[0] for o in ops]
+        for i, sg in enumerate(segs):
+            if sg and sg[0][0] == names[0]:
+                lo, hi = self.buckets[i]
+                self.gflat[lo:hi] += self._scale * (self.rank + 1) * self.k
+
+    def set_hyper(self, lr, t, grad_scale=1.0):
+        self._hp = (lr, t, grad_scale)
+
+    def launch_adamw(self, wd, note=True, guard_loss=None):
+        self.pflat -= self._hp[0] * self._hp[2] * self.gflat
+
+    def note_optimizer_launch(self):
+        pass
+
+
+def dry_run(a):
+    """`bench.py --gpus N --dry-run`: see the flag's help. Exit code 0 and ONE JSON line on rank 0 when spawn, rendezvous, bucket plan,
+    exchange and line assembly all work; the gradients of every step are checked against the closed form on every rank."""
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        _spawn_ranks(a, need_gpus=False)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        print(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        mdist.init(backend="gloo")
+    batch = min(a.batch, 2)                       # host memory: the plan does not depend on the batch size
+    cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
+    real = Engine(cfg, batch, dtype=a.dtype, device="cpu")
+    buckets = mdist.plan_buckets(real.offsets, real.n_params)
+    eng = _DryEngine(real, rank, buckets)
+    trainer = mdist.StepRunner(eng, world_size=world, lr=1e-4, mode="eager")
+    assert (trainer.buckets == buckets and len(trainer.segments) == 4) if world > 1 else True
+    for _ in range(a.warmup):
+        trainer.step()
+    if world > 1:
+        mdist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        real.gflat.zero_()
+        trainer.step()
+        # every rank's segment added (rank + 1) * k: after the exchange the buffer holds k * sum(rank + 1) wherever a bucket covers it
+        want = float(eng.k) * sum(r + 1 for r in range(world))
+        assert torch.allclose(real.gflat, torch.full_like(real.gflat, want)), (rank, float(real.gflat[0]), want)
+    if world > 1:
+        mdist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        import torch.distributed as tdist
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        tdist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = mdist.max_over_ranks(elapsed)
+    if rank == 0:
+        out = dict(metric="pretrain images/sec (12x56x56 S2, bs256/GPU)" if a.img == 56 else "pretrain images/sec", dry_run=True,
+                   value=round(batch * world * a.steps / elapsed, 1), unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                   ms_per_step=round(elapsed / a.steps * 1e3, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=a.dtype, data="synthetic (dry run: no kernels, host stand-ins for the launches)",
+                   config=dict(workload=f"{a.subset} {a.model.replace('convnextv2_', '')} {a.img}x{a.img} patch{a.patch} DRY RUN over gloo",
+                               per_gpu_batch=batch, global_batch=batch * world, parallelism=f"dp{world}", graph="eager",
+                               buckets=[hi - lo for lo, hi in buckets], fold_loss=bool(trainer.fold_loss)),
+                   roofline=None, vendor_kernels_per_step=0.0, per_rank_ms_per_step=[round(t / a.steps * 1e3, 4) for t in per_rank],
+                   exposed_comm_tail_ms=0.0)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        mdist.barrier()
+        mdist.shutdown()
+
+
+def _spawn_ranks(a, need_gpus=True):
     """`python bench.py --gpus N` outside a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run,
     rendezvous on 127.0.0.1, like the reference's `torch.distributed.launch --nproc_per_node=N main_pretrain.py`,
     /root/reference/TRAINING.md:18-42) and pass their exit code on. Fails loudly when the node has fewer GPUs."""
     import subprocess
     have = torch.cuda.device_count()
-    if have < a.gpus:
+    if need_gpus and have < a.gpus:
         print(f"bench.py: --gpus {a.gpus} requested but this node exposes {have} GPU(s)", file=sys.stderr, flush=True)
         sys.exit(2)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -263,6 +365,8 @@ def _spawn_ranks(a):
 
 def main():
     a = parse()
+    if a.dry_run:
+        return dry_run(a)
     if a.cpu_baseline_only:
         cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
         print(json.dumps(cpu_baseline(cfg, a.cpu_batch, a.cpu_steps, threads=a.cpu_baseline_only)), flush=True)

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -177,3 +178,34 @@ def test_fcmae_module_state_dict_layout_cpu(lib):
               "weight_decay", "use_mixed", "sparse", "distributed", "no_ffcv", "output_dir", "auto_resume", "save_ckpt",
               "save_ckpt_freq", "save_ckpt_num", "seed", "device"]:
         assert f in flags, f
+
+
+@pytest.mark.parametrize("launcher,n", [("self", 2), ("driver", 4)])
+def test_bench_multi_rank_dry_run_over_gloo(launcher, n):
+    """everything of a first N > 1 run that is not a kernel, rehearsed on the CPU - `bench.py --gpus N --dry-run` spawns
+    (or is spawned as, the way the driver does it) N ranks, rendezvous on 127.0.0.1 over gloo, builds the REAL launch program and bucket
+    plan, runs the real StepRunner over stand-in launches (every step's all-reduced gradient buffer is checked against its closed form on
+    every rank, the loss slot folded into the first bucket) and prints ONE line in the real bench shape."""
+    import json
+    import socket
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    args = ["--gpus", str(n), "--dry-run", "--steps", "2", "--warmup", "1"]
+    if launcher == "self":
+        cmd = [sys.executable, bench] + args
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), bench] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == n and d["config"]["parallelism"] == f"dp{n}" and d["scaling"] == "weak"
+    assert len(d["per_rank_ms_per_step"]) == n and "exposed_comm_tail_ms" in d and d["steps"] == 2
+    assert sum(d["config"]["buckets"]) == 7580674 and d["config"]["fold_loss"] is True
+    for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
+        assert k in d, k
