@@ -182,6 +182,9 @@ typedef struct MpmaeRsArgs {
    * data-gradient chain reads those gradients, so a training step folds the slabs of a whole stage on its weight-gradient lane.
    * `ws` must then stay untouched until that call has run. */
   MpmaeFoldDesc* defer_fold;
+  /* Optional (which = 0, C = 160 / 320): A already IS the LayerNorm output xn (stored by mpmae_dwln_fwd) - no LayerNorm here, x-hat / rstd / xn
+   * are not written: h = A W1^T + b1 and the GELU^2 column sums only. */
+  int ln_done;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t stream);
@@ -384,6 +387,10 @@ enum MpmaeOption {
   MPMAE_OPT_RSC_ATOMIC,   /* default 0: largest row-block count of a WIDE fused pointwise launch (mpmae_rs which = 0 / 1) whose GRN column statistics are added straight into s0 / s1 with hardware float atomics instead of slab rows + a second-stage fold launch (0 = never) */
   MPMAE_OPT_SK,   /* default 0 (measured SLOWER than whole tiles in round 5: 51-56 vs 37-41 us at N = 512, K = 2048 - each workgroup pays two pipeline fills, a 128 KB publish and a 128 KB fix-up read serially, one workgroup per CU hides none of it; csrc/gemm_sk.cuh). 1: the stream-K NT kernel of gemm_sk.cuh (128 x 256 tiles cut into 64-deep K iterations, every CU takes the same number of iterations, partial tiles fixed up through write-through fp32 slots) for plain bf16 products (no prologue, epilogue = bias / residual / row mask) with K >= 1024, K % 64 == 0, N >= 256, M >= 2048 when the caller passes MpmaeGemmArgs.sk_flags: the dense decoder's pwconv2 and pwconv1 data gradient, the heads' data gradient, the stage-3 pwconv2 / pwconv1 data gradient. 2 = also K >= 512 (decoder pwconv1 / pwconv2.dgrad, pixel heads). 0 = whole-tile kernels */
   MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical; -1 = the pre-round-4 behaviour of the wide pointwise kernels everywhere (one shared LDS statistics row, float atomics between the waves) for A/B: by default a row per wave is used wherever it does not cost a resident workgroup per CU */
+  MPMAE_OPT_RSC1,   /* default 1: the WIDE fused pointwise kernels (mpmae_rs which = 0 / 1) at C = 160 / 320 in their one-shot form (csrc/rsc1.cuh: the workgroup's whole weight slice global -> LDS by DMA at the top, one barrier, no chunk loop); value = row tiles per wave (1 or 2); 0 = the chunk-streaming kernels of rsc.cuh */
+  MPMAE_OPT_RSC1_CPS,   /* default 0 = automatic (128 at C = 160, 64 at C = 320: a 40 KB slice, three workgroups per CU): output columns per workgroup of the one-shot wide kernels (64, or 128 at C = 160) */
+  MPMAE_OPT_RSC1_WGS,   /* default 0 = 3 per CU: target workgroup count of the one-shot wide kernels (a workgroup walks ceil(tiles / (target / column slices)) row tiles with its weight slice resident) */
+  MPMAE_OPT_RSC1_ATOMIC,   /* default 100: the one-shot wide kernels add their column statistics straight into s0 / s1 with float atomics (no slab rows, no fold launch) when they run at most this many workgroup rows (0 = never; MPMAE_OPT_DET > 0 = never) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

@@ -80,6 +80,10 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC_ATOMIC */ 0,
     /* MPMAE_OPT_SK */ 0,
     /* MPMAE_OPT_DET */ 0,
+    /* MPMAE_OPT_RSC1 */ 1,
+    /* MPMAE_OPT_RSC1_CPS */ 0,
+    /* MPMAE_OPT_RSC1_WGS */ 0,
+    /* MPMAE_OPT_RSC1_ATOMIC */ 100,
 };
 
 int mpmae_set_option(int option, int value) {

@@ -3,6 +3,7 @@
 #include "capi_common.h"
 #include "rs.cuh"
 #include "rsc.cuh"
+#include "rsc1.cuh"
 #include "ps.cuh"
 
 // ------------------------------------------------------------------------------------------
@@ -40,6 +41,54 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     const int det = g_opt[MPMAE_OPT_DET];      // (-1: the shared row + LDS atomics everywhere, for A/B)
     p.perwave = (det > 0 || (det == 0 && (cap / lds4 == cap / lds1 || cap / lds1 > 4))) ? 1 : 0;
     const size_t lds = p.perwave ? lds4 : lds1;
+    if constexpr (KC == 160 || KC == 320) {
+      // one-shot form (rsc1.cuh): a workgroup keeps its weight slice (DMA, once) and walks row tiles; every operand requested in one burst
+      const int rt1 = g_opt[MPMAE_OPT_RSC1];
+      if (rt1 > 0) {
+        const int rtv = (rt1 >= 2 && !(KC == 320 && which == 0 && !a.ln_done)) ? 2 : 1;      // (LayerNorm mode at C = 320 with two row tiles per wave spills)
+        const int ntiles = cdiv(a.M, 64 * rtv);
+        // measured (tools/probes/rs1_probe.py, incl. the fold): C = 160: which 0 24.0 (slice 128) / 27.4 (64) vs 29.9 us chunked, which 1 25.7 (128) / 19.1 (64) vs
+        // 23.8; C = 320: which 0 25.3 vs 30.8, which 1 18.7 vs 22.5; without the fold launch (atomics) 22.5 / 16.4 at C = 320
+        const int cpsv = g_opt[MPMAE_OPT_RSC1_CPS] > 0 ? g_opt[MPMAE_OPT_RSC1_CPS] : ((KC == 160 && which == 0) ? 128 : 64);
+        if (cpsv != 64 && !(KC == 160 && cpsv == 128)) return (int)hipErrorInvalidValue;
+        const int ny = HN / cpsv;
+        const int wgs = g_opt[MPMAE_OPT_RSC1_WGS] > 0 ? g_opt[MPMAE_OPT_RSC1_WGS] : 3 * ps_num_cus();
+        const int gxmax = wgs / ny > 0 ? wgs / ny : 1;
+        const int tpw = cdiv(ntiles, gxmax), gx = cdiv(ntiles, tpw);
+        const size_t lds1s = (size_t)cpsv * KC * 2 + (size_t)4 * 2 * cpsv * 4 + (size_t)2 * KC * 4;
+        const size_t need1 = (size_t)gx * HN * (which == 1 ? 2 : 1);
+        // few workgroup rows (38-76 here, 76-304 row blocks in the chunked kernels): the column statistics go straight into s0 / s1 with
+        // no-return float atomics - no slab, no fold launch (not in the reproducible mode)
+        const int atmax = g_opt[MPMAE_OPT_DET] > 0 ? 0 : (g_opt[MPMAE_OPT_RSC_ATOMIC] > g_opt[MPMAE_OPT_RSC1_ATOMIC] ? g_opt[MPMAE_OPT_RSC_ATOMIC] : g_opt[MPMAE_OPT_RSC1_ATOMIC]);
+        const bool at1 = gx <= atmax && a.s0 && (which == 0 || a.s1);
+        if (at1) { p.s0a = a.s0; p.s1a = a.s1; }
+        if ((!at1 && (!a.ws || a.ws_floats < need1)) || lds1s > 160 * 1024 - 512) return (int)hipErrorInvalidValue;
+        p.perwave = 1;
+        dim3 g1(gx, ny);
+#define RSC_WIDE1(MODE_, RT_, CPS_) do { \
+          static size_t cur = 64 * 1024; \
+          if (lds1s > cur) { if (hipFuncSetAttribute((const void*)rsc_wide1_kernel<KC, MODE_, RT_, CPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1s) != hipSuccess) return (int)hipGetLastError(); cur = lds1s; } \
+          LAUNCH((rsc_wide1_kernel<KC, MODE_, RT_, CPS_>), g1, dim3(256), lds1s, st, p, ntiles); } while (0)
+#define RSC_WIDE1_M(MODE_) do { \
+          if constexpr (KC == 160) { if (cpsv == 128) { if (rtv == 2) RSC_WIDE1(MODE_, 2, 128); else RSC_WIDE1(MODE_, 1, 128); } \
+                                     else { if (rtv == 2) RSC_WIDE1(MODE_, 2, 64); else RSC_WIDE1(MODE_, 1, 64); } } \
+          else { if (rtv == 2) RSC_WIDE1(MODE_, 2, 64); else RSC_WIDE1(MODE_, 1, 64); } } while (0)
+        if (which == 0) { if (a.ln_done) RSC_WIDE1_M(2); else RSC_WIDE1_M(0); }
+        else RSC_WIDE1_M(1);
+#undef RSC_WIDE1_M
+#undef RSC_WIDE1
+        if (!at1) {
+          if (which == 0) launch_reduce(0, a.ws, gx, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+          else if (a.s1 == a.s0 + HN) launch_reduce(0, a.ws, gx, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
+          else {
+            const long long delta = a.s1 - a.s0;
+            if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+            launch_reduce(1, a.ws, gx, 2 * HN, a.s0, nullptr, HN, (int)delta, 1, 0, st);
+          }
+        }
+        return launch_status();
+      }
+    }
     const size_t need = (size_t)rowblocks * HN * (which == 1 ? 2 : 1);
     // MPMAE_OPT_RSC_ATOMIC = largest row-block count whose statistics are accumulated with atomics instead of slab + fold launch
     const bool at = rowblocks <= g_opt[MPMAE_OPT_RSC_ATOMIC] && a.s0 && (which == 0 || a.s1);

@@ -60,7 +60,7 @@ def eng():
     stem = next(i for i, n_ in enumerate(names) if n_.startswith("stem:"))
     e._run(e.fwd_ops[:stem], e._stream())        # prep, mask, activity maps
     torch.cuda.synchronize()
-    e.test_inputs = inputs
+    e.test_inputs, e.test_noise = inputs, noise
     return e
 
 
@@ -248,11 +248,23 @@ def test_depthwise7_weight_gradient_group_matches_single_launches(eng, count):
             assert _rel(dw, dw0) < 1e-5 and _rel(db, db0) < 1e-5, (name, _rel(dw, dw0), _rel(db, db0))
 
 
-def test_loss_kernels_forward_and_backward_match_oracle_autograd(eng):
+@pytest.mark.parametrize("onepass", [1, 0])
+def test_loss_kernels_forward_and_backward_match_oracle_autograd(eng, onepass):
     """One launch per loss kind (mpmae_loss_multi) on random bf16 predictions; the oracle's loss functions on the
-    SAME bf16-rounded predictions give the values, and their autograd the prediction gradients."""
+    SAME bf16-rounded predictions give the values, and their autograd the prediction gradients. onepass = 1: the default program (the
+    forward kernels also write the unscaled pixel gradients); 0: the separate gradient kernels (engine option loss_onepass = 0)."""
     from oracle import mpmae_ref as O
     e, lib, cfg = eng, eng.lib, eng.cfg
+    if not onepass:
+        from mmearth_train_amd.engine import Engine
+        e2 = Engine(cfg, e.N, dtype="bf16", device=DEV, options=dict(ps=0, loss_onepass=0))
+        e2.load_state_dict(OrderedDict((k, v.detach().float().cpu().clone()) for k, v in e.params.items()))
+        e2.set_inputs(e.test_inputs, e.test_noise)
+        e2.test_inputs = e.test_inputs
+        stem = next(i for i, op in enumerate(e2.fwd_ops) if op[0].startswith("stem:"))
+        e2._run(e2.fwd_ops[:stem], e2._stream())
+        e = e2
+    assert bool(e.loss_onepass) == bool(onepass)
     torch.manual_seed(77)
     e.pred_pix.copy_((torch.randn(e.pred_pix.shape, device=DEV) * 1.5).to(bf))
     e.pred_img.zero_()
@@ -274,16 +286,24 @@ def test_loss_kernels_forward_and_backward_match_oracle_autograd(eng):
     assert abs(e.total.item() - oloss.item()) <= 2e-5 * abs(oloss.item())
     # backward: d total / d pred
     oloss.backward()
-    e.dpred_pix.fill_(7.0)
-    e.dpred_img.fill_(7.0)
+    if e.loss_onepass:
+        # one-pass program (round 5): the forward kernels above already wrote the pixel gradients WITHOUT their per-modality scalar
+        # (the 7.0 fill below must not touch them); the scalar is e.coef[t] after the finalisation - applied here on the host, in the
+        # step by mpmae_head_scale / the weight-gradient fold
+        e.dpred_img.fill_(7.0)
+    else:
+        e.dpred_pix.fill_(7.0)
+        e.dpred_img.fill_(7.0)
     e.finalize_loss(e._stream(), True, 1.0)
     e._run([o for o in e.bwd_ops if o[0].startswith("dloss:")], e._stream())
     torch.cuda.synchronize()
     N, L, g = e.N, e.L, e.grid
-    for om in cfg.out_mods:
+    for t, om in enumerate(cfg.out_mods):
         c = e.head_cols[om.name]
         if om.kind.startswith("pix"):
             got = e.dpred_pix[:, c:c + om.head_out].reshape(N, L, om.head_out).permute(0, 2, 1).reshape(N, om.head_out, g, g)
+            if e.loss_onepass:
+                got = got.float() * e.coef[t]
         else:
             got = e.dpred_img[:, c:c + om.head_out]
         ref = preds[om.name].grad.to(DEV)
@@ -640,7 +660,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N):
 @pytest.mark.parametrize("opts", ["DW=6", "DW=5", "DW=4", "DW=3", "TN=1", "TN3_BLOCKS=0", "TN3_BLOCKS=256", "RSC_SMALL=0", "RSC_PF=0,RSC_SMALL=0",
                                   "RSC_N40=1,RSC_N80=0", "NT_GLDS=0", "NT_GLDS64=0,NT_BK32=0", "CS_SPLIT=0", "DWW=6", "DWW=5", "FOLD_GROUP=1", "RSC_W5=0", "BLASLT=0", "NT5=1", "RSC_ATOMIC=320",
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
-                                  "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "grouped_epi=1",
+                                  "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "loss_onepass=0", "grouped_epi=1",
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
                                   "img_side=0,prep_side=0", "front_side=0,zero_side=0", "prep_late=0", "proj_compact=0", "z_free=0", "wgrad_late=0", "hr_maxc=80", "ring=2,dz_ring=2", "tail_main=0", "act_in_stem=0", "ps=3"])
 def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
