@@ -391,6 +391,8 @@ enum MpmaeOption {
   MPMAE_OPT_RSC1_CPS,   /* default 0 = automatic (128 at C = 160, 64 at C = 320: a 40 KB slice, three workgroups per CU): output columns per workgroup of the one-shot wide kernels (64, or 128 at C = 160) */
   MPMAE_OPT_RSC1_WGS,   /* default 0 = 3 per CU: target workgroup count of the one-shot wide kernels (a workgroup walks ceil(tiles / (target / column slices)) row tiles with its weight slice resident) */
   MPMAE_OPT_RSC1_ATOMIC,   /* default 100: the one-shot wide kernels add their column statistics straight into s0 / s1 with float atomics (no slab rows, no fold launch) when they run at most this many workgroup rows (0 = never; MPMAE_OPT_DET > 0 = never) */
+  MPMAE_OPT_RSP,   /* default 1: the fused pointwise kernels at C = 40 / 80 in their persistent burst-load form (csrc/rsp.cuh: weights resident in LDS, a workgroup walks row tiles, every operand of the next tile requested under the arithmetic of the current one); value = row tiles of 16 rows per wave (1 or 2); 0 = the chunk-streaming kernels of rsc.cuh */
+  MPMAE_OPT_RSP_WGS,   /* default 0 = 3 per CU (which 0) / 2 per CU (which 1): workgroup count of the persistent burst-load kernels */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

@@ -4,6 +4,7 @@
 #include "rs.cuh"
 #include "rsc.cuh"
 #include "rsc1.cuh"
+#include "rsp.cuh"
 #include "ps.cuh"
 
 // ------------------------------------------------------------------------------------------
@@ -41,6 +42,35 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
     const int det = g_opt[MPMAE_OPT_DET];      // (-1: the shared row + LDS atomics everywhere, for A/B)
     p.perwave = (det > 0 || (det == 0 && (cap / lds4 == cap / lds1 || cap / lds1 > 4))) ? 1 : 0;
     const size_t lds = p.perwave ? lds4 : lds1;
+    if constexpr (KC == 40 || KC == 80) {
+      // persistent burst-load form (rsp.cuh): resident weights, every operand of the next row tile requested under this tile's arithmetic
+      const int rp = g_opt[MPMAE_OPT_RSP];
+      if (rp > 0) {
+        const int rtv = (rp >= 2 && which == 0) ? 2 : 1;      // (which 1 with two row tiles per wave: > 256 VGPRs)
+        const int ntiles = cdiv(a.M, 64 * rtv), ny = HN / 160;
+        constexpr int KPv = ((KC + 31) / 32) * 32;
+        const size_t ldsp = (size_t)160 * (KPv + RSC_PAD) * 2 + (size_t)(2 * KPv + 160) * 4 + (size_t)4 * 2 * 160 * 4;
+        // (tools/probes/rs1_probe.py small: which 0 best at 3 workgroups per CU - 43.5 / 29.0 us at C = 40 / 80 against 50.6 / 33.6 chunked -, which 1 at 2: 42.1 / 29.3 against 56.0 / 36.8)
+        const int wgs = g_opt[MPMAE_OPT_RSP_WGS] > 0 ? g_opt[MPMAE_OPT_RSP_WGS] : (which == 0 ? 3 : 2) * ps_num_cus();
+        int gx = wgs / ny > 0 ? wgs / ny : 1;
+        if (gx > ntiles) gx = ntiles;
+        const size_t needp = (size_t)gx * HN * (which == 1 ? 2 : 1);
+        if (!a.ws || a.ws_floats < needp || HN % 160) return (int)hipErrorInvalidValue;
+        dim3 gp(gx, ny);
+#define RSP_WIDE(MODE_, RT_) LAUNCH((rsp_wide_kernel<KC, MODE_, RT_>), gp, dim3(256), ldsp, st, p, ntiles)
+        if (which == 0) { if (rtv == 2) RSP_WIDE(0, 2); else RSP_WIDE(0, 1); }
+        else { if (rtv == 2) RSP_WIDE(1, 2); else RSP_WIDE(1, 1); }
+#undef RSP_WIDE
+        if (which == 0) launch_reduce(0, a.ws, gx, HN, a.s0, nullptr, 0, 0, 0, 0, st);
+        else if (a.s1 == a.s0 + HN) launch_reduce(0, a.ws, gx, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
+        else {
+          const long long delta = a.s1 - a.s0;
+          if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+          launch_reduce(1, a.ws, gx, 2 * HN, a.s0, nullptr, HN, (int)delta, 1, 0, st);
+        }
+        return launch_status();
+      }
+    }
     if constexpr (KC == 160 || KC == 320) {
       // one-shot form (rsc1.cuh): a workgroup keeps its weight slice (DMA, once) and walks row tiles; every operand requested in one burst
       const int rt1 = g_opt[MPMAE_OPT_RSC1];

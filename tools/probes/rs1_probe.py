@@ -68,6 +68,21 @@ def run(M, Cc, which, opts, reps=60):
 
 
 def main():
+    small = len(sys.argv) > 1 and sys.argv[1] == "small"
+    if small:      # the persistent burst-load kernels (rsp.cuh) at the stage-0 / stage-1 shapes
+        for (M, Cc) in ((311296, 40), (77824, 80)):
+            for which in (0, 1):
+                t0, ref = run(M, Cc, which, dict(RSP=0), reps=30)
+                print(f"M={M} C={Cc} which={which}: chunked {t0:6.1f} us (incl. fold)")
+                for o in (dict(RSP=1), dict(RSP=2), dict(RSP=1, RSP_WGS=512), dict(RSP=1, RSP_WGS=768), dict(RSP=1, RSP_WGS=1536), dict(RSP=1, RSP_WGS=2048),
+                          dict(RSP=2, RSP_WGS=512), dict(RSP=2, RSP_WGS=768), dict(RSP=2, RSP_WGS=1536)):
+                    t, got = run(M, Cc, which, o, reps=30)
+                    errs = []
+                    for g, r in zip(got, ref):
+                        den = r.float().abs().max().item() + 1e-30
+                        errs.append((g.float() - r.float()).abs().max().item() / den)
+                    print(f"    {str(o):44s} {t:6.1f} us   max rel diff vs chunked: " + " ".join(f"{e:.1e}" for e in errs))
+        return
     for (M, Cc) in ((19456, 160), (4864, 320)):
         for which in (0, 1):
             t0, ref = run(M, Cc, which, dict(RSC1=0))
