@@ -393,6 +393,9 @@ enum MpmaeOption {
   MPMAE_OPT_RSC1_ATOMIC,   /* default 100: the one-shot wide kernels add their column statistics straight into s0 / s1 with float atomics (no slab rows, no fold launch) when they run at most this many workgroup rows (0 = never; MPMAE_OPT_DET > 0 = never) */
   MPMAE_OPT_RSP,   /* default 1: the fused pointwise kernels at C = 40 / 80 in their persistent burst-load form (csrc/rsp.cuh: weights resident in LDS, a workgroup walks row tiles, every operand of the next tile requested under the arithmetic of the current one); value = row tiles of 16 rows per wave (1 or 2); 0 = the chunk-streaming kernels of rsc.cuh */
   MPMAE_OPT_RSP_WGS,   /* default 0 = 3 per CU (which 0) / 2 per CU (which 1): workgroup count of the persistent burst-load kernels */
+  MPMAE_OPT_RSP_NWV,   /* default 0 = automatic (8 for which = 5 at C = 80, else 4): waves per workgroup of the persistent NARROW kernels (one 16-row tile per wave) */
+  MPMAE_OPT_RSP_NWGS,   /* default 0 = as many as fit a CU's LDS, at most 2 per CU: workgroup count of the persistent NARROW kernels */
+  MPMAE_OPT_RSP_NARROW,   /* default 2: which NARROW launches take the persistent burst-load kernels: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80 (measured: only which 5 at C = 40 gains, 88.6 -> 70 us) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

@@ -86,6 +86,9 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSC1_ATOMIC */ 100,
     /* MPMAE_OPT_RSP */ 1,
     /* MPMAE_OPT_RSP_WGS */ 0,
+    /* MPMAE_OPT_RSP_NWV */ 0,
+    /* MPMAE_OPT_RSP_NWGS */ 0,
+    /* MPMAE_OPT_RSP_NARROW */ 2,
 };
 
 int mpmae_set_option(int option, int value) {

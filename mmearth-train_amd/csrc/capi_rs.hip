@@ -166,6 +166,39 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       if (((uintptr_t)a.fin_sum | (uintptr_t)a.fin_gamma) & 15) return (int)hipErrorInvalidValue;
     }
     if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
+    if constexpr (KC == 40 || KC == 80) {
+      // persistent burst-load form (rsp.cuh): which 4 without h recomputation, which 5 with dz recomputation, single GRN group
+      const int rp = g_opt[MPMAE_OPT_RSP];
+      // measured (tools/probes/rsp_narrow_probe.py, profiles/r05/rsp_narrow_probe.txt): only which 5 at C = 40 gains (88.6 -> 70 us at 2 workgroups per CU);
+      // which 4 ties at C = 40 (36 us = 4.2 TB/s: HBM + GELU, not latency) and both lose at C = 80 (28 vs 25, 52 vs 43 us: 55-127 KB of resident weights
+      // leave one or two workgroups per CU). MPMAE_OPT_RSP_NARROW: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80
+      const int nbit = (KC == 80 ? 4 : 1) << (which == 5 ? 1 : 0);
+      if (rp > 0 && (g_opt[MPMAE_OPT_RSP_NARROW] & nbit) && pf && ((which == 4 && !dzr) || (which == 5 && dzr))) {
+        const int nwv = g_opt[MPMAE_OPT_RSP_NWV] > 0 ? g_opt[MPMAE_OPT_RSP_NWV] : ((KC == 80 && which == 5) ? 8 : 4);
+        if (nwv != 4 && nwv != 8) return (int)hipErrorInvalidValue;
+        const int ntiles = cdiv(a.M, 16 * nwv);
+        constexpr int NPv = ((KC + 15) / 16) * 16, KP2v = ((KC + 31) / 32) * 32;
+        const size_t ldsn = ((size_t)NPv * (HN + RSC_PAD) + (which == 5 ? (size_t)HN * (KP2v + RSC_PAD) : 0)) * 2 + (size_t)(2 * HN + NPv + 8) * 4 +
+                            (which == 5 ? (size_t)nwv * 2 * NPv * 4 : 0);
+        const int wgs = g_opt[MPMAE_OPT_RSP_NWGS] > 0 ? g_opt[MPMAE_OPT_RSP_NWGS] : (int)((160 * 1024) / ldsn > 2 ? 2 : (160 * 1024) / ldsn) * ps_num_cus();
+        const int gx = ntiles < wgs ? ntiles : wgs;
+        if (ldsn > 160 * 1024 - 512 || (which == 5 && (!a.ws || a.ws_floats < (size_t)gx * 2 * KC))) return (int)hipErrorInvalidValue;
+#define RSP_NARROW(MODE_, NWV_) do { \
+          static size_t cur = 64 * 1024; \
+          if (ldsn > cur) { if (hipFuncSetAttribute((const void*)rsp_narrow_kernel<KC, MODE_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn) != hipSuccess) return (int)hipGetLastError(); cur = ldsn; } \
+          LAUNCH((rsp_narrow_kernel<KC, MODE_, NWV_>), dim3(gx), dim3(64 * NWV_), ldsn, st, p, ntiles); } while (0)
+        if (which == 4) { if (nwv == 8) RSP_NARROW(0, 8); else RSP_NARROW(0, 4); }
+        else {
+          if (nwv == 8) RSP_NARROW(1, 8); else RSP_NARROW(1, 4);
+          const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
+          if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+          if (a.defer_fold) *a.defer_fold = MpmaeFoldDesc{a.ws, gx, 2 * KC, a.s0, KC, (int)delta, 1};
+          else launch_reduce(1, a.ws, gx, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+        }
+#undef RSP_NARROW
+        return launch_status();
+      }
+    }
 #define RSC_NARROW_W(MODE_, PF_, NWV_) do { \
       static size_t cur = 64 * 1024; \
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \

@@ -230,3 +230,290 @@ __global__ __launch_bounds__(256) void rsp_wide_kernel(const RsP p, int ntiles) 
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// rsp_narrow: N = C outputs, K = H = 4C; single GRN group (batch-global sparse GRN). NWV waves per workgroup, one 16-row tile per wave.
+//   MODE 0: z = gelu(h) * scale + beta (stored if p.xn), out = x + z W2^T + b2
+//   MODE 1: dz = dout W2 RECOMPUTED per 32-column group (p.D rows as MFMA operand, W2^T resident), dh = (dz * scale + coef * gelu(h)) * gelu'(h)
+//           (stored to p.A), dd = LayerNorm-backward(dh W1), dgamma / dbeta partials -> one slab row per workgroup
+// Resident in LDS: W [NP][HN + 8] (W2 / W1^T), MODE 1 also W2^T [HN][KP2 + 8]; scale | beta-or-coef [2][HN]; bias / LayerNorm gamma [NP].
+// Optional folded GRN finalisation (p.fin_sum), once per workgroup: see rsc_narrow.
+// grid = GX; block = 64 NWV
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int KC, int MODE, int NWV>
+__global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int ntiles) {
+  using T = bf16_t;
+  constexpr int NTH = 64 * NWV, HN = 4 * KC, KSH = HN / 32, LDW = HN + RSC_PAD, VPR = HN / 8;
+  constexpr int NT = (KC + 15) / 16, NP = NT * 16;
+  constexpr bool PAD = NP != KC, BW = MODE == 1;
+  constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8;
+  static_assert(KC % 8 == 0 && HN % 32 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
+  bf16_t* Wc = reinterpret_cast<bf16_t*>(rsc_smem);                                        // [NP][LDW]
+  bf16_t* W2c = Wc + (size_t)NP * LDW;                                                      // [HN][LDW2] (MODE 1)
+  float* vec = reinterpret_cast<float*>(rsc_smem + ((size_t)NP * LDW + (BW ? (size_t)HN * LDW2 : 0)) * sizeof(bf16_t));   // [2][HN]
+  float* cv = vec + 2 * HN;                                                                  // [NP]: b2 (MODE 0) / LayerNorm gamma (MODE 1), zero beyond KC
+  float* fsh = cv + NP;                                                                      // [8] block-reduction scratch
+  float* red = fsh + 8;                                                                      // [NWV][2][NP] (MODE 1)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  // ---- per-tile operands (registers), requested one tile ahead
+  uint4 hraw[KSH], draw[BW ? KS2 : 1];
+  uint2 xraw[NT];                        // MODE 0: residual x; MODE 1: x-hat (row lr, columns j * 16 + lg * 4 ..)
+  float rsl = 0.f;
+  uint8_t abl = 1;
+  auto request = [&](int tile) {
+    const int rowc = min(tile * (16 * NWV) + wave * 16 + lr, p.M - 1);
+    abl = *(p.act ? p.act + rowc : reinterpret_cast<const uint8_t*>(p.W));
+    const bf16_t* hp = BW ? p.A2 : p.A;
+#pragma unroll
+    for (int s = 0; s < KSH; ++s) hraw[s] = *reinterpret_cast<const uint4*>(hp + (size_t)rowc * HN + s * 32 + lg * 8);
+    if (BW) {
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) draw[s2] = *reinterpret_cast<const uint4*>(p.D + (size_t)rowc * KC + min(s2 * 32 + lg * 8, KC - 8));
+      rsl = p.rstd[rowc];
+    }
+    const bf16_t* xp = BW ? p.xhat : (p.R ? p.R : p.W);
+    const size_t xo = (BW || p.R) ? (size_t)rowc * KC : 0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xraw[j] = *reinterpret_cast<const uint2*>(xp + xo + min(j * 16 + lg * 4, KC - 4));
+  };
+  request(blockIdx.x);
+
+  // ---- resident operands
+  for (int v = tid; v < NP * VPR; v += NTH) {
+    const int n = v / VPR, k = (v - n * VPR) * 8;
+    *reinterpret_cast<uint4*>(Wc + n * LDW + k) = and4(*reinterpret_cast<const uint4*>(p.W + (size_t)min(n, KC - 1) * p.ldw + k), !PAD || n < KC);
+  }
+  if (BW) {
+    for (int v = tid; v < HN * VPR2; v += NTH) {
+      const int n = v / VPR2, k = (v - n * VPR2) * 8;
+      *reinterpret_cast<uint4*>(W2c + n * LDW2 + k) = and4(*reinterpret_cast<const uint4*>(p.W2 + (size_t)n * p.ldw2 + min(k, KC - 8)), k < KC);
+    }
+  }
+  for (int i = tid; i < NP; i += NTH) {
+    const float* src = BW ? p.lng : (p.bias ? p.bias : p.v1);
+    const float v = src[min(i, KC - 1)];
+    cv[i] = (i < KC && (BW || p.bias)) ? v : 0.f;
+  }
+  if (!p.fin_sum) {
+    for (int i = tid; i < HN / 4; i += NTH) {
+      reinterpret_cast<float4*>(vec)[i] = reinterpret_cast<const float4*>(p.v0)[i];
+      reinterpret_cast<float4*>(vec + HN)[i] = reinterpret_cast<const float4*>(p.v1)[i];
+    }
+  } else if (!BW) {                                 // grn_fwd_finalize_kernel (rows.cuh), same summation order
+    constexpr int NJ = (HN + NTH - 1) / NTH;
+    float fs[NJ], fg[NJ], fb[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+      const int jc = min(tid + NTH * u, HN - 1);
+      fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fb[u] = p.v1[jc];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) { fs[u] = sqrtf(fs[u]); s += (tid + NTH * u < HN) ? fs[u] : 0.f; }
+    s = wave_sum(s);
+    if (lane == 0) fsh[wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) tot += fsh[w];
+    const float ainv = 1.f / (tot / HN + p.fin_eps);
+    const bool pub = blockIdx.x == 0;
+    if (pub && tid == 0) p.fin_ainv[0] = ainv;
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+      const int j = tid + NTH * u;
+      if (j < HN) {
+        const float gx = fs[u], sc = 1.f + fg[u] * (gx * ainv);
+        vec[j] = sc;
+        vec[HN + j] = fb[u];
+        if (pub) { p.fin_gx[j] = gx; p.fin_out[j] = sc; }
+      }
+    }
+  } else {                                          // grn_bwd_finalize_kernel
+    constexpr int NJ = (HN + NTH - 1) / NTH;
+    float fs[NJ], fg[NJ], fx[NJ], f0[NJ], fv[NJ];
+    const float* s0p = p.fin_sum0 ? p.fin_sum0 : p.fin_sum;
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+      const int jc = min(tid + NTH * u, HN - 1);
+      fs[u] = p.fin_sum[jc]; fg[u] = p.fin_gamma[jc]; fx[u] = p.fin_gx[jc]; f0[u] = s0p[jc]; fv[u] = p.v0[jc];
+    }
+    const float ainv = p.fin_ainv[0];
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) s += (tid + NTH * u < HN) ? fg[u] * fs[u] * fx[u] : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) fsh[wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) tot += fsh[w];
+    const float T2 = tot * ainv * ainv / HN;
+    const bool pub = blockIdx.x == 0;
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) {
+      const int j = tid + NTH * u;
+      if (j < HN) {
+        const float gx = fx[u], s1 = fs[u];
+        const float dGx = fg[u] * s1 * ainv - T2;
+        const float cf = (gx > 0.f) ? dGx / gx : 0.f;
+        vec[j] = fv[u];
+        vec[HN + j] = cf;
+        if (pub) {
+          if (p.fin_out) p.fin_out[j] = cf;
+          atomicAdd(p.fin_dgamma + j, gx * ainv * s1);
+          atomicAdd(p.fin_dbeta + j, f0[u]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  float cg[BW ? NT : 1][4][2];                     // MODE 1: this lane's dgamma / dbeta partials over every tile of the workgroup
+#pragma unroll
+  for (int j = 0; j < (BW ? NT : 1); ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { cg[j][r][0] = 0.f; cg[j][r][1] = 0.f; }
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    asm volatile("" ::: "memory");                   // (no loop-invariant hoisting of the LDS vector reads)
+    const int row = tile * (16 * NWV) + wave * 16 + lr;
+    const bool inb = row < p.M;
+    const bool live = inb && (p.act ? abl != 0 : true);
+    // this tile's operands out of the request registers (the next request overwrites them)
+    uint4 hc[KSH];
+    bf16x8_t df[BW ? KS2 : 1];
+    uint2 xc[NT];
+    const float rs = (BW && inb) ? rsl : 0.f;
+#pragma unroll
+    for (int s = 0; s < KSH; ++s) hc[s] = and4(hraw[s], inb);
+    if (BW) {
+#pragma unroll
+      for (int s2 = 0; s2 < KS2; ++s2) df[s2] = __builtin_bit_cast(bf16x8_t, and4(draw[s2], inb && s2 * 32 + lg * 8 < KC));
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) xc[j] = and2(xraw[j], inb && (!PAD || j * 16 + lg * 4 < KC) && (BW || p.R != nullptr));
+    if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);       // the next tile's operands travel under this tile's arithmetic
+
+    f32x4_t acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KSH; ++s) {
+      asm volatile("" ::: "memory");                 // (LDS reads of one k-step at a time)
+      const int k = s * 32 + lg * 8;
+      const float4 sa = *reinterpret_cast<const float4*>(vec + k), sb = *reinterpret_cast<const float4*>(vec + k + 4);
+      const float4 ta = *reinterpret_cast<const float4*>(vec + HN + k), tb = *reinterpret_cast<const float4*>(vec + HN + k + 4);
+      const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+      const float tc[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+      float z[8];
+      if (!BW) {
+        float a[8], ga[8];
+        unpack8(hc[s], a);
+        gelu_n<T, 8>(a, ga);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = live ? ga[e] * sc[e] + tc[e] : 0.f;                 // GRN(gelu(h))
+      } else {
+        // dz [row lr][s*32 + lg*8 + e], e = t*4 + r, from the tile pair (t = 0, 1) of this 32-column group
+        f32x4_t d2[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          d2[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s2 = 0; s2 < KS2; ++s2) {
+            const bf16x8_t wf2 = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(
+                W2c + (s * 32 + (lr >> 2) * 8 + t * 4 + (lr & 3)) * LDW2 + s2 * 32 + lg * 8));
+            d2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2, df[s2], d2[t], 0, 0, 0);
+          }
+        }
+        float a[8], h[8], gl[8], dg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = bf2f(f2bf(d2[e >> 2][e & 3]));                    // the value the unfused path stored
+        unpack8(hc[s], h);
+        gelu_both_n<T, 8>(h, gl, dg);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) z[e] = (a[e] * sc[e] + tc[e] * gl[e]) * dg[e];                 // dh
+      }
+      const bf16x8_t af = pack_bf16x8(z);
+      if (inb) {
+        bf16_t* dst = BW ? const_cast<bf16_t*>(p.A) : p.xn;
+        if (dst) *reinterpret_cast<uint4*>(dst + (size_t)row * HN + k) = __builtin_bit_cast(uint4, af);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Wc + (j * 16 + lr) * LDW + s * 32 + lg * 8));
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af, acc[j], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: lane holds row m = lr, columns n = j*16 + lg*4 + r
+    if (!BW) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        const bool nin = !PAD || n4 < KC;
+        const float4 b4 = *reinterpret_cast<const float4*>(cv + n4);
+        float x[4], o[4];
+        unpack4(xc[j], x);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = live ? acc[j][r] + bb[r] + x[r] : 0.f;
+        if (inb && nin) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+      }
+    } else {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        float xh[4];
+        unpack4(xc[j], xh);
+        const float4 g = *reinterpret_cast<const float4*>(cv + n4);
+        const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float dxn = live ? bf2f(f2bf(acc[j][r])) : 0.f;      // bf16 like the unfused path
+          cg[BW ? j : 0][r][0] += dxn * xh[r];
+          cg[BW ? j : 0][r][1] += dxn;
+          const float gq = dxn * gg[r];
+          acc[j][r] = gq;
+          s1 += gq;
+          s2 += gq * xh[r];
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      s1 /= KC; s2 /= KC;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n4 = j * 16 + lg * 4;
+        float xh[4], o[4];
+        unpack4(xc[j], xh);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = live ? rs * (acc[j][r] - s1 - xh[r] * s2) : 0.f;
+        if (inb && (!PAD || n4 < KC)) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+      }
+    }
+  }
+  if (BW) {
+    float* redw = red + (size_t)wave * 2 * NP;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ga = sum16(cg[BW ? j : 0][r][0]), gb = sum16(cg[BW ? j : 0][r][1]);
+        if (lr == 0) { redw[j * 16 + lg * 4 + r] = ga; redw[NP + j * 16 + lg * 4 + r] = gb; }
+      }
+    __syncthreads();
+    for (int i = tid; i < KC; i += NTH) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) { a += red[(size_t)w * 2 * NP + i]; b += red[(size_t)w * 2 * NP + NP + i]; }
+      p.ws[((size_t)blockIdx.x * 2 + 0) * KC + i] = a;
+      p.ws[((size_t)blockIdx.x * 2 + 1) * KC + i] = b;
+    }
+  }
+}
