@@ -89,6 +89,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSP_NWV */ 0,
     /* MPMAE_OPT_RSP_NWGS */ 0,
     /* MPMAE_OPT_RSP_NARROW */ 2,
+    /* MPMAE_OPT_RSN3 */ 5,
 };
 
 int mpmae_set_option(int option, int value) {

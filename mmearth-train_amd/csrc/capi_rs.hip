@@ -5,6 +5,7 @@
 #include "rsc.cuh"
 #include "rsc1.cuh"
 #include "rsp.cuh"
+#include "rsn3.cuh"
 #include "ps.cuh"
 
 // ------------------------------------------------------------------------------------------
@@ -166,6 +167,29 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       if (((uintptr_t)a.fin_sum | (uintptr_t)a.fin_gamma) & 15) return (int)hipErrorInvalidValue;
     }
     if (which == 5 && (!a.ws || a.ws_floats < (size_t)rowblocks * 2 * KC)) return (int)hipErrorInvalidValue;
+    if constexpr (KC == 160) {
+      // ring-pipelined backward (rsn3.cuh): weight slabs by DMA into a three-slot ring, rows two chunks ahead, one bare barrier per chunk
+      const int r3 = g_opt[MPMAE_OPT_RSN3];
+      if (r3 > 0 && which == 5 && pf && !dzr) {
+        // (two K-groups per row tile - half as long a dependent chain per wave, 126 KB of ring: measured SLOWER, 42.5 vs 32.0 us, and the 640-thread
+        //  instantiation spills; the kernel keeps the template parameter, the launcher does not offer it)
+        const int nkg = 1, nrt = r3 == 4 ? 4 : 5;
+        const int rb3 = cdiv(a.M, 16 * nrt);
+        const size_t lds3 = (size_t)3 * nkg * KC * 64 * 2 + (size_t)(2 * KC + 2 * HN + 8 + KC) * 4;
+        if (!a.ws || a.ws_floats < (size_t)rb3 * 2 * KC) return (int)hipErrorInvalidValue;
+#define RSN3(NRT_, NKG_) do { \
+          static bool attr = false; \
+          if (!attr) { if (hipFuncSetAttribute((const void*)rsn3_bwd_kernel<KC, NRT_, NKG_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess) return (int)hipGetLastError(); attr = true; } \
+          LAUNCH((rsn3_bwd_kernel<KC, NRT_, NKG_>), dim3(rb3), dim3(64 * NRT_ * NKG_), lds3, st, p); } while (0)
+        if (nrt == 5) RSN3(5, 1); else RSN3(4, 1);
+#undef RSN3
+        const long long delta = a.s1 - a.s0;
+        if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+        if (a.defer_fold) *a.defer_fold = MpmaeFoldDesc{a.ws, rb3, 2 * KC, a.s0, KC, (int)delta, 1};
+        else launch_reduce(1, a.ws, rb3, 2 * KC, a.s0, nullptr, KC, (int)delta, 1, 0, st);
+        return launch_status();
+      }
+    }
     if constexpr (KC == 40 || KC == 80) {
       // persistent burst-load form (rsp.cuh): which 4 without h recomputation, which 5 with dz recomputation, single GRN group
       const int rp = g_opt[MPMAE_OPT_RSP];

@@ -21,7 +21,7 @@ def st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def run(M, Cc, which, opts, zfree, reps=30):
+def run(M, Cc, which, opts, zfree, reps=30, dzr=True):
     H = 4 * Cc
     torch.manual_seed(M + Cc + which)
     ws = torch.empty(16 << 20, dtype=torch.float32, device=dev)
@@ -52,10 +52,13 @@ def run(M, Cc, which, opts, zfree, reps=30):
         dh, dd = torch.zeros(M, H, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf)
         g = torch.zeros(2 * Cc, device=dev)
         coef, dgam, dbet = torch.zeros(H, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
-        kw = dict(A=dh, A2=h, W=W1T, ldw=H, v0=scale, out=dd, xhat=xhat, rstd=rstd, lng=lng, act=act, s0=g, s1=g[Cc:], dz_dout=dout, dz_w2t=W2T,
-                  dz_ldw2=Cc, fin_sum=S1, fin_sum0=S0, fin_gamma=gamma, fin_gx=Gx, fin_ainv=Ainv, fin_out=coef, fin_dgamma=dgam, fin_dbeta=dbet)
+        dzsrc = (torch.randn(M, H, device=dev) * 0.1).to(bf) * live
+        if not dzr:
+            dh.copy_(dzsrc)
+        kw = dict(A=dh, A2=h, W=W1T, ldw=H, v0=scale, out=dd, xhat=xhat, rstd=rstd, lng=lng, act=act, s0=g, s1=g[Cc:],
+                  **(dict(dz_dout=dout, dz_w2t=W2T, dz_ldw2=Cc) if dzr else {}), fin_sum=S1, fin_sum0=S0, fin_gamma=gamma, fin_gx=Gx, fin_ainv=Ainv, fin_out=coef, fin_dgamma=dgam, fin_dbeta=dbet)
         outs = lambda: [dd.clone(), dh.clone(), g.clone(), coef.clone(), dgam.clone(), dbet.clone()]
-        zero = lambda: (g.zero_(), dgam.zero_(), dbet.zero_())
+        zero = lambda: (g.zero_(), dgam.zero_(), dbet.zero_(), None if dzr else dh.copy_(dzsrc))
     a = L.RsArgs()
     for k, v in kw.items():
         setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
@@ -84,6 +87,18 @@ def run(M, Cc, which, opts, zfree, reps=30):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "ring":      # the ring-pipelined backward kernel (rsn3.cuh) at the stage-2 shape
+        for M in (19456, 1000, 76):
+            t0, ref = run(M, 160, 5, dict(RSN3=0), False, dzr=False)
+            print(f"M={M} C=160 which=5 (dz materialised): rsc_narrow {t0:6.1f} us (incl. fold)")
+            for o in (dict(RSN3=4), dict(RSN3=5)):
+                t, got = run(M, 160, 5, o, False, dzr=False)
+                errs = []
+                for g_, r in zip(got, ref):
+                    den = r.float().abs().max().item() + 1e-30
+                    errs.append((g_.float() - r.float()).abs().max().item() / den)
+                print(f"    {str(o):30s} {t:6.1f} us   max rel diff: " + " ".join(f"{e:.1e}" for e in errs))
+        return
     for (M, Cc, zfree) in ((311296, 40, True), (77824, 80, False), (1000, 40, False), (333, 80, True)):
         for which in (4, 5):
             t0, ref = run(M, Cc, which, dict(RSP=0), zfree)
