@@ -440,6 +440,13 @@ int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G
 int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv,
                            const float* gamma, int G, int H, float* coef, float* dgamma,
                            float* dbeta, mpmae_stream_t stream);
+/* GRN backward statistics FROM the pwconv2 weight gradient (round 5; sparse_norm_layers.py:24-33 differentiated, convnextv2_sparse.py:52-54):
+ * with T = dout^T gelu(h) [C][H] and dbt = sum_rows dout [C] (both fp32, produced by mpmae_wgrad with a GELU-only operand prologue into
+ * zero-initialised scratch) and W2s the staged pwconv2 weights [C][ldw] (storage type dt):
+ *   S0[j] += sum_c W2s[c][j] dbt[c];   S1[j] += sum_c W2s[c][j] T[c][j];   dW2[c][j] += scale[j] T[c][j] + beta[j] dbt[c];   db2[c] += dbt[c]
+ * - the statistics that mpmae_rs(which = 1, out = NULL) computes with a second pass over dout and h. */
+int mpmae_grn_stats_from_wgrad(int dt, const float* T, const float* dbt, const void* W2s, int ldw, const float* scale, const float* beta,
+                               float* dW2, float* db2, float* S0, float* S1, int C, int H, mpmae_stream_t stream);
 /* element-wise GRN application z = gelu(h)*(1+gamma*Nx) + beta and its backward
  * dh = (dz*(1+gamma*Nx) + coef*gelu(h)) * gelu'(h) (in place over dz), and the column statistics
  * they need (mode 0: s0 += sum gelu(h)^2; mode 1: s0 += sum dz, s1 += sum dz*gelu(h)), per group

@@ -278,6 +278,14 @@ int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, co
   RET();
 }
 
+int mpmae_grn_stats_from_wgrad(int dt, const float* T, const float* dbt, const void* W2s, int ldw, const float* scale, const float* beta,
+                               float* dW2, float* db2, float* S0, float* S1, int C, int H, mpmae_stream_t s) {
+  if (!T || !dbt || !W2s || !scale || !beta || !dW2 || !db2 || !S0 || !S1 || C < 1 || H < 1 || ldw < H) return (int)hipErrorInvalidValue;
+  if (dt == 0) LAUNCH(grn_stats_from_wgrad_kernel<float>, dim3(cdiv(H, 256)), dim3(256), 0, S_(s), T, dbt, (const float*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
+  else LAUNCH(grn_stats_from_wgrad_kernel<bf16_t>, dim3(cdiv(H, 256)), dim3(256), 0, S_(s), T, dbt, (const bf16_t*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
+  RET();
+}
+
 // ------------------------------------------------------------------------------------------
 static size_t dw_lds_bytes(int CC, bool wgrad) {
   size_t b = (size_t)DW_HP * CC * sizeof(float) + (DW_HP + 4) * sizeof(int);

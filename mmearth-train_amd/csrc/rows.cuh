@@ -163,6 +163,37 @@ static __global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const floa
     scale[(size_t)g * H + j] = 1.f + gamma[j] * (Gx[(size_t)g * H + j] * ainv);
 }
 
+// GRN backward statistics FROM the pwconv2 weight gradient (round 5). With z = g * scale + beta, g = gelu(h), and dz = dout W2:
+//   S0[j] = sum_m dz[m][j]          = sum_c W2[c][j] * db2[c],          db2 = sum_m dout[m][:]   (the bias gradient)
+//   S1[j] = sum_m dz[m][j] g[m][j]  = sum_c W2[c][j] * T[c][j],         T   = dout^T g           (the weight gradient before the GRN affine)
+//   dW2[c][j] = scale[j] T[c][j] + beta[j] db2[c]
+// so where dz is never materialised (C = 40 / 80: the fused backward kernel recomputes it) the statistics pass over dout and h - a second
+// read of the block's widest tensor whose only products are these two H-vectors - is the weight-gradient product itself: mpmae_wgrad runs
+// with a GELU-only operand prologue into T / db2 (zero-initialised scratch), this kernel turns them into the statistics AND the parameter
+// gradients. One thread per column j; W2s = the bf16 weights the forward and the data gradient multiply with ([C][ldw], k = j).
+template <typename T>
+static __global__ __launch_bounds__(256) void grn_stats_from_wgrad_kernel(const float* __restrict__ Tm, const float* __restrict__ dbt,
+                                                                        const T* __restrict__ W2s, int ldw, const float* __restrict__ scale,
+                                                                        const float* __restrict__ beta, float* __restrict__ dW2,
+                                                                        float* __restrict__ db2, float* __restrict__ S0,
+                                                                        float* __restrict__ S1, int C, int H) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < H) {
+    const float sc = scale[j], bt = beta[j];
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float t = Tm[(size_t)c * H + j], d = dbt[c], w = ldf<T>(W2s + (size_t)c * ldw + j);
+      s0 += w * d;
+      s1 += w * t;
+      dW2[(size_t)c * H + j] += sc * t + bt * d;
+    }
+    S0[j] += s0;
+    S1[j] += s1;
+  }
+  if (blockIdx.x == 0) for (int c = threadIdx.x; c < C; c += 256) db2[c] += dbt[c];
+}
+
+
 // The statistics of this thread's columns are loaded up front (all loads in flight at once) and kept in registers: written as two
 // loops over j with the float atomics inside, every iteration exposed one global-load latency (the atomics pin the loads behind
 // them) and the kernel took 26 us for the decoder's 2 MB of statistics.

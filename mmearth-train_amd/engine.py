@@ -73,6 +73,7 @@ ENGINE_OPTIONS = dict(
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
+    stats_wgrad=0,          # (measured SLOWER, 3.76 vs 3.66 ms: the transpose-read weight gradient + its fold on the main lane cost more than the statistics pass they replace; parity-tested, off) blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient (T = dout^T gelu(h) into scratch on the MAIN lane, then mpmae_grn_stats_from_wgrad) instead of a statistics-only pass over dout and h (mpmae_rs which = 1, out = NULL): one read of the block's widest tensor less per block; implies z_free for those blocks
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
@@ -360,7 +361,9 @@ class Engine:
         # persistent stage kernels: PS_NG accumulator copies of each statistics vector (same arena: zeroed once per step)
         self.PS_NG = 4
         ps_blocks = [blk for blk in self.blocks if self._ps_ok(blk["stage"])]
-        self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks), dtype=f32, device=dev)
+        sw_blocks = [blk for blk in self.blocks if blk["sparse"] and blk["C"] <= int(self.opt["dzr_maxc"]) and bool(self.opt["stats_wgrad"]) and self.dt == BF16]
+        sw_floats = sum(-(-(b["C"] * b["H"] + b["C"]) // 64) * 64 for b in sw_blocks)
+        self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks) + sw_floats, dtype=f32, device=dev)
         off = 0
         for blk in self.blocks + self.decs:
             G, H = blk["G"], blk["H"]
@@ -371,6 +374,10 @@ class Engine:
             for nm in ("G2", "S0", "S1"):
                 blk["ps_" + nm] = self.stats[off:off + self.PS_NG * blk["H"]]
                 off += self.PS_NG * blk["H"]
+        for blk in sw_blocks:        # scratch of the weight-gradient-derived statistics (same arena: zeroed once per step)
+            blk["Tw2"] = self.stats[off:off + blk["C"] * blk["H"]]
+            blk["dbt"] = self.stats[off + blk["C"] * blk["H"]:off + blk["C"] * blk["H"] + blk["C"]]
+            off += -(-(blk["C"] * blk["H"] + blk["C"]) // 64) * 64
         self.loss_acc = torch.zeros(T, N, 2, dtype=f32, device=dev)      # per-sample {sum, count} partials
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
@@ -922,6 +929,11 @@ class Engine:
         # z_free: z is never written - pw2's weight gradient (mpmae_wgrad with the GRN prologue on Q = h) rebuilds it slab by slab
         blk["z_free"] = (rs_n == "fused" and G == 1 and bool(self.opt["z_free"])
                          and Cc % 8 == 0 and Cc <= int(self.opt["z_free_maxc"]) and blk["sparse"])
+        # statistics from the weight gradient (stats_wgrad): the blocks whose backward recomputes dz; z is then never needed (T = dout^T gelu(h))
+        blk["sw"] = ("Tw2" in blk and rs and rs_n == "fused" and Cc <= int(self.opt["dzr_maxc"]) and fold and self.dz_recompute and G == 1
+                     and Cc % 8 == 0 and self.lanes)
+        if blk["sw"]:
+            blk["z_free"] = True
         if rs_n == "fused":   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
             fin = dict(fin_sum=blk["G2"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"], fin_ainv=blk["Ainv"],
                        fin_out=blk["scale"], fin_eps=eps) if fold else {}   # GRN finalisation folded into the prologue
@@ -963,7 +975,22 @@ class Engine:
         # pw1.dgrad kernel recomputes dz = dout W2 chunk by chunk (MpmaeRsArgs.dz_*)
         dzr = (rs and rs_n == "fused" and Cc <= int(self.opt["dzr_maxc"]) and blk.get("grn_fold", False)
                and self.dz_recompute)
-        if rs:
+        sw = bool(blk.get("sw")) and dzr
+        if sw:
+            # T = dout^T gelu(h) and db2 into zeroed scratch (GELU-only operand prologue = the GRN prologue with scale 1, beta 0), in order on
+            # the main lane; then statistics + parameter gradients from T (mpmae_grn_stats_from_wgrad)
+            if not hasattr(self, "_sw_ones"):
+                self._sw_ones, self._sw_zeros = {}, {}
+            if H not in self._sw_ones:
+                self._sw_ones[H] = torch.ones(H, dtype=torch.float32, device=self.device)
+                self._sw_zeros[H] = torch.zeros(H, dtype=torch.float32, device=self.device)
+            self._wgrad(lst, tag + ":pw2.wgrad(T)", "NONE", "GRN", P=dout, Q=blk["h"], qp0=self._sw_ones[H], qp1=self._sw_zeros[H], M=M, Nn=Cc, Kk=H,
+                        ldp=Cc, ldq=H, dW=blk["Tw2"], sn=H, sk=1, db=blk["dbt"])
+            w2s = self.w[tag + ".W2"]
+            self._op(lst, tag + ":grn.stats(T)", lib.mpmae_grn_stats_from_wgrad, dt, _p(blk["Tw2"]), _p(blk["dbt"]), _p(w2s["t"]), w2s["ld"],
+                     _p(blk["scale"]), _p(P[nm["gb"]]), _p(Gd[nm["w2"]]), _p(Gd[nm["b2"]]), _p(blk["S0"]), _p(blk["S1"]), Cc, H,
+                     kind="grn_stats_wgrad", nbytes=3 * Cc * H * 4)
+        elif rs:
             self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + (1 if dzr else 2) * M * H) * esz, 2 * M * Cc * H, A=dout,
                      W=w2t["t"], ldw=w2t["ld"], out=None if dzr else dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
         elif blk["sparse"] or self.grouped_epi:
@@ -987,7 +1014,9 @@ class Engine:
             w2_args.update(Q=blk["h"], qp0=blk["scale"], qp1=P[nm["gb"]])
             w2_qpro = "GRN"
         grouped = self._group_ok(blk, w2_qpro)
-        if grouped:
+        if sw:
+            pass                     # (pwconv2's weight gradient is already out: it produced the statistics)
+        elif grouped:
             self._group_add(lst, tag + ":pw2.wgrad", [dout], **w2_args)
         elif not late_w2 and not late_all:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
@@ -1045,10 +1074,10 @@ class Engine:
             self._gemm(lst, tag + ":pw1.dgrad", "NONE", "STORE", A=dz, B=w1t["t"], C=dxn, M=M, N=Cc, K=H, lda=H,
                        ldb=w1t["ld"], ldc=Cc)
         self._guard(lst, dd)
-        if late_w2 and not grouped:
+        if late_w2 and not grouped and not sw:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
         w1_args = dict(P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        if grouped:
+        if grouped or (sw and self._group_ok(blk, "NONE")):
             self._group_add(lst, tag + ":pw1.wgrad", [dz], **w1_args)
         elif not late_all:
             if self.lanes and int(self.opt["tail_main"]) >= 2 and tag == "encoder.stages.0.0":
@@ -1060,7 +1089,7 @@ class Engine:
                      _p(P[nm["ln_w"]]), _p(P[nm["ln_b"]]), 0, _p(dd), 0, _p(Gd[nm["ln_w"]]), _p(Gd[nm["ln_b"]]), M, Cc,
                      _p(act), kind="ln_bwd", nbytes=3 * M * Cc * esz)
             self._guard(lst, dd)
-        if late_all and not grouped:
+        if late_all and not grouped and not sw:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
             self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
         self._dw_bwd(lst, blk, dd, dout, dx)
