@@ -437,27 +437,48 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
         for (int j = 0; j < NTL1; ++j) {
           const int nc = nb0 + j * 16 + lg * 4;
           const float bb[4] = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
-          float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
             const int row = m * 16 + lr;
-            float o[4], gl[4];
+            float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = lv[m] ? acc[j][m][r] + bb[r] : 0.f;
-            const uint2 hp = pack_bf16x4(o);
-            if (row < R) *reinterpret_cast<uint2*>(hg + (size_t)row * H + nc) = hp;
-            unpack4(hp, o);                               // the backward (and the row-streaming path) see the stored bf16 value
-            gelu_n<T, 4>(o, gl);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cs[r] += gl[r] * gl[r];
-            *reinterpret_cast<uint2*>(HA + row * LDH + nc) = pack_bf16x4(gl);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float s = sum16(cs[r]);
-            if (lr == 0) csum[nc + r] = s;
+            *reinterpret_cast<uint2*>(HA + row * LDH + nc) = pack_bf16x4(o);      // h, staged: stored and turned into g = gelu(h) by the pass below
           }
         }
+      }
+    }
+    __syncthreads();
+    // ---- P4b: h leaves for global memory in whole 16-byte row pieces (a thread = 8 columns of every NRG-th row: consecutive lanes write
+    // consecutive bytes). Stored straight from the accumulators - 8 bytes per lane, 32 contiguous bytes per row and instruction - the h
+    // stores were 10 k of pw1's 27 k cycles per block (stage 2: 317 -> 267 us with the stores removed, profiles/r05/ps_stamps.txt).
+    // g = gelu(h) replaces h in HA; its squared column sums fold over the row groups through the (dead) xn rows of XA.
+    {
+      T* hg = reinterpret_cast<T*>(B.h) + rowbase * H;
+      const int cc = tid % K::NCC, rg = tid / K::NCC;
+      float* part = reinterpret_cast<float*>(smem + K::OFF_XA);              // [NRG][H]
+      static_assert(K::NRG * H * 4 <= K::XA_B, "column-sum partials fit the xn rows");
+      if (rg < K::NRG) {
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int m = rg; m < R; m += K::NRG) {
+          const uint4 hv = *reinterpret_cast<const uint4*>(HA + m * LDH + cc * 8);
+          *reinterpret_cast<uint4*>(hg + (size_t)m * H + cc * 8) = hv;
+          float h8[8], g8[8];
+          unpack8(hv, h8);                                                  // the backward (and the row-streaming path) see the stored bf16 value
+          gelu_n<T, 8>(h8, g8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[e] += g8[e] * g8[e];
+          *reinterpret_cast<uint4*>(HA + m * LDH + cc * 8) = __builtin_bit_cast(uint4, pack_bf16x8(g8));
+        }
+        *reinterpret_cast<float4*>(part + rg * H + cc * 8) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(part + rg * H + cc * 8 + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+      }
+      __syncthreads();
+      for (int j = tid; j < H; j += NTHR) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < K::NRG; ++q) a += part[q * H + j];
+        csum[j] = a;
       }
     }
     __syncthreads();
@@ -571,9 +592,8 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
           for (int r = 0; r < 4; ++r) o[r] = lvm ? acc[j][m][r] + bb[r] + x[r] : 0.f;
           if (row < R) {
             const uint2 pk = pack_bf16x4(o);
-            *reinterpret_cast<uint2*>(outg + (size_t)row * C + nc) = pk;
             float of[4];
-            unpack4(pk, of);
+            unpack4(pk, of);                              // (the bf16 value; it leaves for global memory in 16-byte pieces behind the block's last barrier)
             *reinterpret_cast<float4*>(XF + row * C + nc) = make_float4(of[0], of[1], of[2], of[3]);
           }
         }
@@ -583,6 +603,14 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     if (wave + 8 * (NTW - 1) < NT2) tail(std::integral_constant<int, NTW>{});
     else tail(std::integral_constant<int, (NTW > 1 ? NTW - 1 : 1)>{});
     __syncthreads();
+    {      // out: XF (exact bf16 values in fp32) -> global, whole 16-byte row pieces (like h in P4b)
+      T* outg = reinterpret_cast<T*>(B.out) + rowbase * C;
+      for (int i = tid; i < R * (C / 8); i += NTHR) {
+        const float4 a0 = *reinterpret_cast<const float4*>(XF + i * 8), a1 = *reinterpret_cast<const float4*>(XF + i * 8 + 4);
+        const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        *reinterpret_cast<uint4*>(outg + (size_t)i * 8) = __builtin_bit_cast(uint4, pack_bf16x8(v));
+      }
+    }
     PS_STAMP(7);
   }
   grid_exit(a.sync, nwg);
