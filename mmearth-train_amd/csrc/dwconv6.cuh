@@ -98,9 +98,29 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   f32x2_t b2 = {0.f, 0.f};
   if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
 
+  // the patch lookup, residual rows and activity bytes of the NEXT slot are requested before the taps of the current one: as
+  // `lookup -> wait -> tile; add / act -> wait` at the top of every iteration they were two dependent round trips per slot
+  // (tools/isa_chain.py: GL W(vm0) inside the slot loop; 2-4 slots per wave)
+  int patchN = 0;
+  uint32_t addN[S];
+  uint8_t liveN[S];
+  auto fetch = [&](int slot_) {
+    const int nk_ = n * p.g.keep + min(slot_, p.g.keep - 1);
+    patchN = *(p.g.vis ? p.g.vis + nk_ : reinterpret_cast<const int*>(p.w));
+    const size_t r0_ = (size_t)nk_ * (S * S) + ox;
+#pragma unroll
+    for (int o = 0; o < S; ++o) {
+      // optional operands through a pointer select (unconditional loads; a branch here parks a wait in front of the tap loop)
+      const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (r0_ + o * S) * C + c : reinterpret_cast<const T*>(p.w));
+      const uint8_t lv = *(p.act ? p.act + r0_ + o * S : reinterpret_cast<const uint8_t*>(p.w));
+      addN[o] = ar & add_m;                                   // opaque masks (see opaque_mask): a ternary on `add` is turned back
+      liveN[o] = (uint8_t)((lv & act_m) | (~act_m & 1u));     // into a branch around the load by the optimizer
+    }
+  };
+  if (wave * 2 + sub < p.g.keep) fetch(wave * 2 + sub);
   for (int slot = wave * 2 + sub; slot < p.g.keep; slot += NW * 2) {
     const int nk = n * p.g.keep + slot;
-    const int patch = p.g.vis ? p.g.vis[nk] : slot;
+    const int patch = p.g.vis ? patchN : slot;
     const int py = patch / p.g.grid, px = patch - py * p.g.grid;
     const T* tile = map + ((size_t)(py * S) * MS + px * S + ox) * CW + 2 * cp;     // halo origin + this lane's column
     const size_t r0 = (size_t)nk * (S * S) + ox;
@@ -108,14 +128,8 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
     uint32_t addraw[S];
     uint8_t live[S];
 #pragma unroll
-    for (int o = 0; o < S; ++o) {
-      // optional operands through a pointer select (unconditional loads; a branch here parks a wait in front of the tap loop)
-      const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (r0 + o * S) * C + c : reinterpret_cast<const T*>(p.w));
-      const uint8_t lv = *(p.act ? p.act + r0 + o * S : reinterpret_cast<const uint8_t*>(p.w));
-      addraw[o] = ar & add_m;                                   // opaque masks (see opaque_mask): a ternary on `add` is turned back
-      live[o] = (uint8_t)((lv & act_m) | (~act_m & 1u));        // into a branch around the load by the optimizer
-      acc[o] = b2;
-    }
+    for (int o = 0; o < S; ++o) { addraw[o] = addN[o]; live[o] = liveN[o]; acc[o] = b2; }
+    if (slot + NW * 2 < p.g.keep) fetch(slot + NW * 2);
 #pragma unroll 1
     for (int kx = 0; kx < 7; ++kx) {
       f32x2_t w7[7];
@@ -293,10 +307,12 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
   f32x2_t b2 = {0.f, 0.f};
   if (p.bias) { b2.x = p.bias[c]; b2.y = p.bias[c + 1]; }
   uint32_t addraw[G];
-  f32x2_t acc[G];
+  uint8_t actb[G];                   // activity bytes of the output rows: requested HERE with the residual rows - loaded in the store loop
+  f32x2_t acc[G];                    // (`live = !act || act[row]` per output) they were G dependent round trips at the end of the kernel
 #pragma unroll
   for (int o = 0; o < G; ++o) {
     const uint32_t ar = *reinterpret_cast<const uint32_t*>(add ? add + (size_t)max(rows[o], 0) * C + c : reinterpret_cast<const T*>(p.w));
+    actb[o] = *(p.act ? p.act + max(rows[o], 0) : reinterpret_cast<const uint8_t*>(p.w));
     addraw[o] = ar & add_m & (rows[o] >= 0 ? 0xffffffffu : 0u);   // unconditional load (pointer select + opaque mask)
     acc[o] = b2;
   }
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256) void dwconv7_v6s1_kernel(const DwP p) {
 #pragma unroll
   for (int o = 0; o < G; ++o) {
     if (rows[o] < 0) continue;
-    const bool live = !p.act || p.act[rows[o]];
+    const bool live = !p.act || actb[o] != 0;
     const f32x2_t r = acc[o] + bf2x2_to_f2(addraw[o]);
     *reinterpret_cast<uint32_t*>(out + (size_t)rows[o] * C + c) = live ? f2bf2(r.x, r.y) : 0u;
   }
