@@ -118,7 +118,7 @@ def family_of(kind):
 
 
 FAMILY_SYMBOLS = {
-    "rs": ("rsc_wide_kernel", "rsc_narrow_kernel"),
+    "rs": ("rsc_wide_kernel", "rsc_wide1_kernel", "rsp_wide_kernel", "rsc_narrow_kernel", "rsp_narrow_kernel", "rsn3_bwd_kernel"),
     "wgrad": ("gemm_tn2_kernel", "gemm_tn3_kernel", "gemm_tng_kernel", "gemm_tn_bf16_kernel"),
     "dwconv7": ("dwconv7_mfma_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
     "dwconv7_wgrad": ("dwconv7_wgrad_mfma_kernel", "dwconv7_wgrad_mfma4_kernel", "dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
@@ -465,6 +465,18 @@ def main():
         avg_ms = dom["ms"] / dom["n"]
         avg_bytes = dom["bytes"] / dom["n"]
         avg_flops = dom["flops"] / dom["n"]
+        # `algorithmic_bytes` follows SURVEY 8(d): layer-granular - every pointwise layer of a block reads its input and writes its output once,
+        # x3 for forward + backward: 60 M C bytes per block in bf16 (20 M C forward, 40 M C backward). The launch program's own count
+        # (every tensor an op must read or write, saved x-hat / xn / statistics operands included) stays as `must_move_bytes`.
+        must_move = avg_bytes
+        if dom_kind == "rs":
+            tot_b = 0
+            for blk in eng.blocks:
+                if blk.get("rs"):
+                    fwd_rs = not eng._ps_ok(blk["stage"])            # the persistent stage kernel is its own family
+                    tot_b += (20 if fwd_rs else 0) * blk["M"] * blk["C"] + 40 * blk["M"] * blk["C"]
+            if tot_b:
+                avg_bytes = tot_b / max(dom["n"] // 3, 1)
         mfma_bound = avg_flops / MFMA_PEAK_TFS / 1e12 > avg_bytes / HBM_PEAK_GBS / 1e9
         achieved = (avg_flops / (avg_ms * 1e-3) / 1e12 if mfma_bound else avg_bytes / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0
         if a.profile_ops:
@@ -493,7 +505,7 @@ def main():
                     kernel_symbols=list(FAMILY_SYMBOLS.get(dom_kind, ())),
                     achieved=round(achieved, 1), peak=peak, unit="TFLOP/s" if mfma_bound else "GB/s",
                     frac=round(achieved / peak, 4), traffic=traffic,
-                    algorithmic_bytes=int(avg_bytes), algorithmic_flops=int(avg_flops),
+                    algorithmic_bytes=int(avg_bytes), must_move_bytes=int(must_move), algorithmic_flops=int(avg_flops),
                     kernel_avg_us=round(avg_ms * 1e3, 2), kernel_launches_per_step=ops_per_step,
                     kernel_share_of_step=round(dom["ms"] / tot, 3),
                     timing="live: HIP events around every C-ABI call of the family in an eager pass (an op = its kernel + the folds it launches)")
@@ -506,6 +518,9 @@ def main():
                                      frac=round(ach_step / peak, 4), share_of_kernel_time=in_step[dom_kind]["share_of_kernel_time"],
                                      source=fam_src))
             roof["frac"] = round(min(achieved, ach_step) / peak, 4)
+            if "mfma_util" in in_step[dom_kind]:      # stand-alone MFMA utilisation of the family (tools/mfma_util.py: a --pmc pass of this workload)
+                roof["mfma_util"] = in_step[dom_kind]["mfma_util"]
+                roof["mfma_flop_frac"] = in_step[dom_kind]["mfma_flop_frac"]
         if traffic is not None:
             roof["traffic_source"] = (f"{os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       f"passes; commit {pmc_doc.get('meta', {}).get('commit', 'n/a')})")

@@ -14,7 +14,7 @@ import sys
 # weight-gradient GEMMs and wgrad_group_fold belong to "wgrad"; reduce_partials<2> / group2 to "dwconv7_wgrad"; reduce_partials<0> (GRN
 # column statistics) and <1> (LayerNorm gamma / beta partials) are launched by the fused pointwise entry points: "rs".
 FAMILIES = collections.OrderedDict([
-    ("rs", r"rsc_wide_kernel|rsc_narrow_kernel|rs_kernel|reduce_partials_kernel<0>|reduce_partials_kernel<1>"),
+    ("rs", r"rsc_wide_kernel|rsc_wide1_kernel|rsp_wide_kernel|rsc_narrow_kernel|rsp_narrow_kernel|rsn3_bwd_kernel|rs_kernel|reduce_partials_kernel<0>|reduce_partials_kernel<1>"),
     ("wgrad", r"gemm_tn2_kernel|gemm_tn3_kernel|gemm_tng_kernel|gemm_tng48_kernel|gemm_tn_bf16_kernel|wgrad_kernel|wgrad_group_fold_kernel|reduce_partials_kernel<3>"),
     ("dwconv7", r"dwconv7_mfma_kernel|dwconv7_v6_kernel|dwconv7_v6s1_kernel|dwconv7_v5_kernel"),
     ("dwconv7_wgrad", r"dwconv7_wgrad|reduce_partials_kernel<2>|reduce_partials_group2_kernel"),
@@ -54,6 +54,13 @@ def main():
         d["launches_per_step"] = round(d["launches_per_step"], 2)
         d["share_of_kernel_time"] = round(d["us_per_step"] / total, 4)
         d["kernels"] = {k: [round(v[0], 1), round(v[1], 2)] for k, v in sorted(d["kernels"].items(), key=lambda kv: -kv[1][0])}
+    mf = os.environ.get("MPMAE_MFMA_JSON")
+    if mf and os.path.exists(mf):      # MFMA utilisation per family (tools/mfma_util.py, a separate --pmc pass of the same workload)
+        md = json.load(open(mf)).get("families", {})
+        for k, d in fam.items():
+            if k in md:
+                d["mfma_util"] = md[k]["mfma_util"]
+                d["mfma_flop_frac"] = md[k]["mfma_flop_frac"]
     out = dict(note="in-step kernel time per family (rocprofv3 --kernel-trace, both lanes live; folds charged to their producers)",
                meta=dict(commit=os.environ.get("MPMAE_COMMIT", "n/a"), bench_args=" ".join(sys.argv[3:]), steps=n, launches_per_step=common,
                          step_wall_us=round(wall, 1), kernel_time_us=round(total, 1)),
