@@ -358,7 +358,7 @@ enum MpmaeOption {
   MPMAE_OPT_DW6_T4,   /* default 320: ... S = 4 */
   MPMAE_OPT_DW6_T2,   /* default 320: ... S = 2 */
   MPMAE_OPT_DW6_GC,   /* default 1: 1: compile-time patch-grid side (7) in the packed depthwise */
-  MPMAE_OPT_DW,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 3..5 = earlier generations (fp32 mode, odd shapes) */
+  MPMAE_OPT_DW,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = positional-tile / generic kernels (dwconv3.cuh, dwconv.cuh: S = 1 in fp32 mode, odd shapes). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
   MPMAE_OPT_DWW_S1_NB,   /* default 0: persistent workgroups of the S = 1 depthwise weight gradient (0 = one per sample) */
   MPMAE_OPT_DWW_NB,   /* default 128: persistent workgroups of the depthwise weight gradient */
   MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 6 = packed kernel for S >= 2; 5 = per-sample LDS-map kernels */

@@ -7,7 +7,6 @@
 #include "dwconv.cuh"
 #include "misc.cuh"
 #include "loss.cuh"
-#include "dwconv2.cuh"
 #include "dwconv3.cuh"
 #include "rows2.cuh"
 #include "dwconv6.cuh"
@@ -293,43 +292,6 @@ static size_t dw_lds_bytes(int CC, bool wgrad) {
   return b;
 }
 
-template <typename T>
-static void launch_dw_v2(const MpmaeDwArgs& a, hipStream_t st) {
-  const bool c40 = (a.C % 40 == 0);
-  const int cc = c40 ? 40 : 32;
-  dim3 g(a.g.N * a.tiles_side * a.tiles_side, cdiv(a.C, cc));
-  if (c40) LAUNCH((dwconv7_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
-  else LAUNCH((dwconv7_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
-}
-
-template <typename T>
-static void launch_dwwg_v2(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
-  const bool c40 = (a.C % 40 == 0);
-  const int cc = c40 ? 40 : 32;
-  dim3 g(nblocks, cdiv(a.C, cc));
-  if (c40) LAUNCH((dwconv7_wgrad_v2_kernel<T, 40>), g, dim3(320), 0, st, a);
-  else LAUNCH((dwconv7_wgrad_v2_kernel<T, 32>), g, dim3(256), 0, st, a);
-}
-
-template <typename T, int S>
-static void launch_dw_v4(const MpmaeDwArgs& a, hipStream_t st) {
-  using D = Dw4<S>;
-  const int chunks = a.C / D::CW;
-  int nw = 1;
-  for (int d = 8; d >= 1; --d) if (chunks % d == 0) { nw = d; break; }
-  const size_t lds = ((D::HP + 3) & ~3) * sizeof(int) +
-                     (size_t)nw * (D::HP * D::CW * sizeof(T) + (S > 1 ? 49 * D::CW * sizeof(float) : 0));
-  dim3 g(a.g.N * a.g.keep, chunks / nw);
-  LAUNCH((dwconv7_v4_kernel<T, S>), g, dim3(64 * nw), lds, st, a);
-}
-
-template <typename T, int S>
-static void launch_dwwg_v4(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
-  using D = Dw4<S>;
-  dim3 g(nblocks, a.C / D::CW);
-  LAUNCH((dwconv7_wgrad_v4_kernel<T, S>), g, dim3(64), 0, st, a);
-}
-
 // v5 (one sample's whole map in LDS): returns false when the map does not fit / the attribute cannot be raised
 template <typename T, int S>
 static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
@@ -480,13 +442,6 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 #undef DW5
     if (ok) RET();
   }
-  if (dw_v4_ok(a->C, a->g.S)) {
-#define DW4(TT) do { switch (a->g.S) { case 8: launch_dw_v4<TT, 8>(*a, S_(s)); break; case 4: launch_dw_v4<TT, 4>(*a, S_(s)); break; \
-                                      case 2: launch_dw_v4<TT, 2>(*a, S_(s)); break; default: launch_dw_v4<TT, 1>(*a, S_(s)); } } while (0)
-    if (dt == 0) DW4(float); else DW4(bf16_t);
-#undef DW4
-    RET();
-  }
   if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
     const int chunks = a->C / 8;
     const int nw = chunks <= 8 ? chunks : (chunks % 5 == 0 ? 5 : 8);      // waves per block sharing the tables
@@ -495,10 +450,6 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
     dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(chunks, nw));
     if (dt == 0) LAUNCH(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), *a);
     else LAUNCH(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), *a);
-    RET();
-  }
-  if ((a->C & 7) == 0) {
-    if (dt == 0) launch_dw_v2<float>(*a, S_(s)); else launch_dw_v2<bf16_t>(*a, S_(s));
     RET();
   }
   const size_t lds = dw_lds_bytes(a->CC, false);
@@ -614,19 +565,6 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
       RET();
     }
   }
-  if (dw_v4_ok(a->C, a->g.S)) {
-    const size_t per = (size_t)50 * a->C;
-    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    const int npatches = a->g.N * a->g.keep;
-    if (nblocks > npatches) nblocks = npatches;
-    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
-#define DWW4(TT) do { switch (a->g.S) { case 8: launch_dwwg_v4<TT, 8>(*a, nblocks, S_(s)); break; case 4: launch_dwwg_v4<TT, 4>(*a, nblocks, S_(s)); break; \
-                                       case 2: launch_dwwg_v4<TT, 2>(*a, nblocks, S_(s)); break; default: launch_dwwg_v4<TT, 1>(*a, nblocks, S_(s)); } } while (0)
-    if (dt == 0) DWW4(float); else DWW4(bf16_t);
-#undef DWW4
-    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
-    RET();
-  }
   if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
@@ -635,15 +573,6 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     dim3 g(nblocks, a->C / 8);
     if (dt == 0) LAUNCH(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
     else LAUNCH(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
-    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
-    RET();
-  }
-  if ((a->C & 7) == 0) {
-    const size_t per = (size_t)50 * a->C;
-    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
-    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
-    if (dt == 0) launch_dwwg_v2<float>(*a, nblocks, S_(s)); else launch_dwwg_v2<bf16_t>(*a, nblocks, S_(s));
     launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }

@@ -9,7 +9,7 @@
 //   channel cw of the chunk, S outputs (oy) per lane — the v4 inner loop, reading the shared map.
 // 49 x CW weights sit in LDS as fp32.
 #pragma once
-#include "dwconv4.cuh"
+#include "dwconv.cuh"
 
 template <typename T, int S> struct Dw5 {
   static constexpr int CW = 64 / S;
