@@ -788,7 +788,8 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
   RET();
 }
 
-static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s, int split = 0) {
+  const int gx = split ? N * (H / p) : N;
   if (bwd < 0 || bwd > 2) return (int)hipErrorInvalidValue;
   if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)maxC * (p * H + 4) * 4;
@@ -799,7 +800,7 @@ static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int co
 #define LPR(TT, MV, MP, BW) do { \
     static size_t cur = 48 * 1024; \
     if (lds > cur) { if (hipFuncSetAttribute((const void*)loss_pix_cont_rows_kernel<TT, MV, MP, BW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
-    LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP, BW>), dim3(N, count), dim3(512), lds, S_(s), tab); } while (0)
+    LAUNCH((loss_pix_cont_rows_kernel<TT, MV, MP, BW>), dim3(gx, count), dim3(512), lds, S_(s), tab, split); } while (0)
 #define LPR2(TT, MV, MP) do { if (bwd == 1) LPR(TT, MV, MP, 1); else if (bwd == 2) LPR(TT, MV, MP, 2); else LPR(TT, MV, MP, 0); } while (0)
   if (mv <= 3 && mp <= 3) { if (dt == 0) LPR2(float, 3, 3); else LPR2(bf16_t, 3, 3); }
   else { if (dt == 0) LPR2(float, 12, 12); else LPR2(bf16_t, 12, 12); }
@@ -818,6 +819,11 @@ int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N,
 
 int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
   return loss_pix_cont_rows_impl(dt, 2, dev_args, count, N, maxC, p, H, s);
+}
+
+int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  if (mode != 0 && mode != 2) return (int)hipErrorInvalidValue;
+  return loss_pix_cont_rows_impl(dt, mode, dev_args, count, N, maxC, p, H, s, 1);
 }
 
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {

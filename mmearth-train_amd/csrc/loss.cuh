@@ -298,12 +298,16 @@ __global__ __launch_bounds__(BWD ? 256 : 512) void loss_pix_cont_multi_kernel(co
 // into the consumers instead: the heads' data-gradient GEMM reads weights scaled per modality segment, their weight-gradient fold scales its
 // rows (mpmae_head_scale, MpmaeWgradArgs.rowscale): the second pass over 35 MB of predictions and 80 MB of targets leaves the step.
 template <typename T, int MAXV, int MAXP, int MODE = 0>
-__global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP* __restrict__ tab) {
+__global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP* __restrict__ tab, int split) {
+  // split (round 5): a workgroup is one PATCH ROW of a sample (grid.x = N * grid) instead of a sample walking its rows: the 7 serial rows of a
+  // sample - band -> barrier -> mask -> prediction slice -> barrier, ~5 us each, on one workgroup per CU for the 12-channel modality - become 7
+  // independent workgroups; the {sum, count} partial goes to slot n * grid + row (the finalisation folds N * grid slots in a fixed order).
   constexpr bool BWD = MODE == 1, FUSED = MODE == 2;
   const PixContP q = tab[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float lpc_band[];
   __shared__ float part[8][2];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = split ? blockIdx.x / q.grid : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int py_begin = split ? blockIdx.x - n * q.grid : 0, py_end = split ? py_begin + 1 : q.grid;
   const int p = q.p, C = q.C, H = q.H, G = q.grid, PP = p * p, J = PP * C;
   const int H4 = H >> 2, CP = p * H + 4, nvec = C * p * H4, npv = J >> 2;
   const float* tg_n = q.target + (size_t)n * C * H * H;
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       pre[i] = *reinterpret_cast<const float4*>(tg_n + ((size_t)c * H + py * p + ph) * H + x4 * 4);
     }
   };
-  prefetch(0);
+  prefetch(py_begin);
   // band offsets of this lane's elements, once per workgroup (no integer division in the row loop): planar order for the target
   // statistics (8 consecutive lanes = one image row of the patch: conflict-free), prediction order for the squared error
   // (only while the tables fit the register file: the 112/16 variant computes them in the loop)
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
     for (int u = 0; u < MAXP; ++u) pred_off(u, offq[u]);
   }
   float as = 0.f, ac = 0.f;
-  for (int py = 0; py < G; ++py) {
+  for (int py = py_begin; py < py_end; ++py) {
     __syncthreads();                                            // every wave is done with the previous band
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -358,7 +362,7 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       }
     }
     __syncthreads();
-    if (py + 1 < G) prefetch(py + 1);
+    if (py + 1 < py_end) prefetch(py + 1);
     for (int px = wave; px < G; px += 8) {
       const int b = n * q.L + py * G + px;
       const float mk = q.mask[b];
@@ -512,8 +516,8 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
   if (tid == 0) {
     float ts = 0.f, tc = 0.f;
     for (int w = 0; w < 8; ++w) { ts += part[w][0]; tc += part[w][1]; }       // fixed order: deterministic
-    q.acc[2 * n] = ts;
-    q.acc[2 * n + 1] = tc;
+    q.acc[2 * blockIdx.x] = ts;                                               // (split: slot n * grid + row)
+    q.acc[2 * blockIdx.x + 1] = tc;
   }
 }
 

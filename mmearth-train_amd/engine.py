@@ -74,6 +74,7 @@ ENGINE_OPTIONS = dict(
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
     stats_wgrad=0,          # (measured SLOWER, 3.76 vs 3.66 ms: the transpose-read weight gradient + its fold on the main lane cost more than the statistics pass they replace; parity-tested, off) blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient (T = dout^T gelu(h) into scratch on the MAIN lane, then mpmae_grn_stats_from_wgrad) instead of a statistics-only pass over dout and h (mpmae_rs which = 1, out = NULL): one read of the block's widest tensor less per block; implies z_free for those blocks
+    loss_rowsplit=0,        # (measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times; tested, off) continuous pixel losses: one workgroup per PATCH ROW of a sample (mpmae_loss_pix_cont_rows_split) instead of one per sample walking its 7 rows; the {sum, count} partials get N * grid slots per modality
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
@@ -378,7 +379,10 @@ class Engine:
             blk["Tw2"] = self.stats[off:off + blk["C"] * blk["H"]]
             blk["dbt"] = self.stats[off + blk["C"] * blk["H"]:off + blk["C"] * blk["H"] + blk["C"]]
             off += -(-(blk["C"] * blk["H"] + blk["C"]) // 64) * 64
-        self.loss_acc = torch.zeros(T, N, 2, dtype=f32, device=dev)      # per-sample {sum, count} partials
+        # per-sample {sum, count} partials; with the row-split continuous losses N * grid slots per modality (slot n * grid + row; the kernels that
+        # write one partial per sample use the first N slots, the rest stay zero: the finalisation folds all of them in a fixed order)
+        self.loss_slots = N * (self.grid if (bool(self.opt["loss_rowsplit"]) and bool(self.opt["loss_rows"]) and bool(self.opt["loss_multi"])) else 1)
+        self.loss_acc = torch.zeros(T, self.loss_slots, 2, dtype=f32, device=dev)
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
         self.total = torch.zeros(1, dtype=f32, device=dev)
@@ -1480,8 +1484,12 @@ class Engine:
                         and -(-(maxc * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(maxc * self.p * self.p // 4) // 64) <= 12):
                     # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
                     self._cont_rows = maxc
-                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
-                             dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                    if self.loss_slots > N:
+                        self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_split, dt, 2 if onepass else 0, _p(tab), len(mods), N, maxc,
+                                 self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                    else:
+                        self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
+                                 dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
                     continue
                 ldp_ = self.pred_pix.shape[1] if cfg.pix_mods else 0
                 cat_waves = (kind == "pix_cat" and bool(self.opt["loss_rows"]) and maxc <= 16 and ldp_ % 4 == 0
@@ -1534,7 +1542,7 @@ class Engine:
         """12 per-modality losses, uncertainty weighting, total, backward coefficients
         (and, with_dlogvars, d total / d log_vars accumulated into the gradient buffer)."""
         a = self._fin_args
-        err = self.lib.mpmae_loss_finalize_guarded(a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6],
+        err = self.lib.mpmae_loss_finalize_guarded(a[0], self.loss_slots, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6],
                                                    a[7] if with_dlogvars else None, *self._err_words(), stream)
         _lib.check(err, "loss_finalize")
 
@@ -2086,7 +2094,7 @@ class Engine:
             w = tuple(getattr(self, "_fwd_join_keys", ())) if (zs or not dlv) else ()
             m = dict(lane=0, wait=w + (("grads_zero",) if dlv and zs else ()), signal=None)
             return ("loss.finalize", lib.mpmae_loss_finalize_guarded,
-                    (a[0], self.N, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None) + tuple(self._err_words()), m)
+                    (a[0], self.loss_slots, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None) + tuple(self._err_words()), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
         # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane
