@@ -440,6 +440,14 @@ int mpmae_grn_fwd_finalize(const float* G2, const float* gamma, float eps, int G
 int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, const float* Ainv,
                            const float* gamma, int G, int H, float* coef, float* dgamma,
                            float* dbeta, mpmae_stream_t stream);
+/* mpmae_grn_fwd_finalize + mpmae_grn_apply, and mpmae_grn_bwd_finalize + mpmae_grn_bwd_apply, as ONE launch each (round 5; single GRN group):
+ * every workgroup recomputes the H-vector from the column sums in its prologue, workgroup 0 publishes Gx / Ainv / scale (coef, and adds the
+ * GRN gamma / beta gradients). Same outputs as the two-launch forms. */
+int mpmae_grn_apply_fin(int dt, const void* h, void* z, const float* G2, const float* gamma, const float* beta, float eps, int M, int H,
+                        const uint8_t* act, float* Gx, float* Ainv, float* scale, mpmae_stream_t stream);
+int mpmae_grn_bwd_apply_fin(int dt, void* dz, const void* h, const float* scale, const float* S0, const float* S1, const float* Gx,
+                            const float* Ainv, const float* gamma, int M, int H, float* coef, float* dgamma, float* dbeta,
+                            mpmae_stream_t stream);
 /* GRN backward statistics FROM the pwconv2 weight gradient (round 5; sparse_norm_layers.py:24-33 differentiated, convnextv2_sparse.py:52-54):
  * with T = dout^T gelu(h) [C][H] and dbt = sum_rows dout [C] (both fp32, produced by mpmae_wgrad with a GELU-only operand prologue into
  * zero-initialised scratch) and W2s the staged pwconv2 weights [C][ldw] (storage type dt):

@@ -184,6 +184,10 @@ SYMBOLS = {
     "mpmae_grn_fwd_finalize": [c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_grn_bwd_finalize": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                                c_void_p, c_void_p, c_void_p],
+    "mpmae_grn_apply_fin": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                            c_void_p, c_void_p],
+    "mpmae_grn_bwd_apply_fin": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_grn_stats_from_wgrad": [c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                    c_int, c_int, c_void_p],
     "mpmae_grn_apply": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p],

@@ -541,6 +541,114 @@ __global__ __launch_bounds__(256) void grn_bwd_apply_kernel(T* __restrict__ dz, 
   }
 }
 
+// The two element-wise GRN passes with their FINALISATION in the prologue (round 5; single GRN group - the batch-global sparse GRN - at the
+// widths whose pointwise products run on the tiled GEMMs, C = 320 / 384): every workgroup recomputes the H-vector from the column sums
+// (grn_fwd_finalize_kernel / grn_bwd_finalize_kernel of rows.cuh, same summation order) into LDS, workgroup 0 publishes it (and adds the GRN
+// gamma / beta gradients): one 7-us launch less per block and direction on the main lane.
+template <typename T>
+__global__ __launch_bounds__(256) void grn_apply_fin_kernel(const T* __restrict__ h, T* __restrict__ z, const float* __restrict__ G2,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            int M, int H, const uint8_t* __restrict__ act, float* __restrict__ Gx,
+                                                            float* __restrict__ Ainv, float* __restrict__ scale) {
+  extern __shared__ float gaf_smem[];             // [2][H]: scale | beta
+  __shared__ float red[4];
+  float* sc = gaf_smem;
+  float* bt = gaf_smem + H;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const float v = sqrtf(G2[j]);
+    sc[j] = v;
+    bt[j] = beta[j];
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float A = (red[0] + red[1] + red[2] + red[3]) / H;
+  const float ainv = 1.f / (A + eps);
+  const bool pub = blockIdx.x == 0;
+  if (pub && threadIdx.x == 0) Ainv[0] = ainv;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const float gx = sc[j], v = 1.f + gamma[j] * (gx * ainv);
+    sc[j] = v;
+    if (pub) { Gx[j] = gx; scale[j] = v; }
+  }
+  __syncthreads();
+  const size_t nvec = (size_t)M * H / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / H, j = e - (size_t)m * H;
+    float v[8];
+    ld8<T>(h + e, v);
+    const uint8_t lv = *(act ? act + m : reinterpret_cast<const uint8_t*>(h));
+    const bool live = !act || lv;
+    const float4 s0 = *reinterpret_cast<const float4*>(sc + j), s1 = *reinterpret_cast<const float4*>(sc + j + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(bt + j), b1 = *reinterpret_cast<const float4*>(bt + j + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float bev[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float r = gelu_t<T>(v[q]) * scv[q] + bev[q];
+      v[q] = live ? r : 0.f;
+    }
+    st8<T>(z + e, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void grn_bwd_apply_fin_kernel(T* __restrict__ dz, const T* __restrict__ h, const float* __restrict__ scale,
+                                                                const float* __restrict__ S0, const float* __restrict__ S1,
+                                                                const float* __restrict__ Gx, const float* __restrict__ Ainv,
+                                                                const float* __restrict__ gamma, int M, int H, float* __restrict__ coef,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float gaf_smem[];             // [2][H]: scale | coef
+  __shared__ float red[4];
+  float* sc = gaf_smem;
+  float* cf = gaf_smem + H;
+  const float ainv = Ainv[0];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    sc[j] = scale[j];
+    s += gamma[j] * S1[j] * Gx[j];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  const float T2 = (red[0] + red[1] + red[2] + red[3]) * ainv * ainv / H;
+  const bool pub = blockIdx.x == 0;
+  for (int j = threadIdx.x; j < H; j += 256) {
+    const float gx = Gx[j], s1 = S1[j];
+    const float dGx = gamma[j] * s1 * ainv - T2;
+    const float c = (gx > 0.f) ? dGx / gx : 0.f;
+    cf[j] = c;
+    if (pub) {
+      coef[j] = c;
+      atomicAdd(dgamma + j, gx * ainv * s1);
+      atomicAdd(dbeta + j, S0[j]);
+    }
+  }
+  __syncthreads();
+  const size_t nvec = (size_t)M * H / 8;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 8;
+    const int m = e / H, j = e - (size_t)m * H;
+    float d[8], hv[8];
+    ld8<T>(dz + e, d);
+    ld8<T>(h + e, hv);
+    const float4 s0 = *reinterpret_cast<const float4*>(sc + j), s1 = *reinterpret_cast<const float4*>(sc + j + 4);
+    const float4 c0 = *reinterpret_cast<const float4*>(cf + j), c1 = *reinterpret_cast<const float4*>(cf + j + 4);
+    const float scv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float cov[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float g, dg;
+      gelu_both_t<T>(hv[q], g, dg);
+      d[q] = (d[q] * scv[q] + cov[q] * g) * dg;
+    }
+    st8<T>(dz + e, d);
+  }
+}
+
 // column statistics over row groups: mode 0: s0[g,j] += sum gelu(h)^2
 //                                   mode 1: s0[g,j] += sum dz ; s1[g,j] += sum dz*gelu(h)
 // grid = (ceil(H/64), row chunks); block 256 = 64 columns x 4 row lanes

@@ -74,6 +74,7 @@ ENGINE_OPTIONS = dict(
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
     stats_wgrad=0,          # (measured SLOWER, 3.76 vs 3.66 ms: the transpose-read weight gradient + its fold on the main lane cost more than the statistics pass they replace; parity-tested, off) blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient (T = dout^T gelu(h) into scratch on the MAIN lane, then mpmae_grn_stats_from_wgrad) instead of a statistics-only pass over dout and h (mpmae_rs which = 1, out = NULL): one read of the block's widest tensor less per block; implies z_free for those blocks
+    grn_apply_fin=1,        # unfused sparse blocks (C = 320: tiled GEMMs + element-wise GRN passes): the GRN finalisation runs in the prologue of the element-wise pass (mpmae_grn_apply_fin / _bwd_apply_fin) - two launches fewer per block on the main lane
     loss_rowsplit=0,        # (measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times; tested, off) continuous pixel losses: one workgroup per PATCH ROW of a sample (mpmae_loss_pix_cont_rows_split) instead of one per sample walking its 7 rows; the {sum, count} partials get N * grid slots per modality
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
@@ -927,6 +928,10 @@ class Engine:
             self._op(lst, tag + ":grn.group", lib.mpmae_grn_group_fwd, dt, _p(blk["h"]), _p(blk["z"]), _p(P[nm["gg"]]),
                      _p(P[nm["gb"]]), eps, M, H, rpg, _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]),
                      kind="grn_group_fwd", nbytes=2 * M * H * esz)
+        afin = blk["afin"] = (not fold and not gg and rs_n != "fused" and G == 1 and blk["sparse"] and bool(self.opt["grn_apply_fin"])
+                              and not self._mx_block(blk) and H % 8 == 0 and H <= 8192)
+        if gg or afin:
+            pass
         elif not fold:
             self._op(lst, tag + ":grn", lib.mpmae_grn_fwd_finalize, _p(blk["G2"]), _p(P[nm["gg"]]), eps, G, H,
                      _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]))
@@ -949,7 +954,10 @@ class Engine:
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
                      v1=P[nm["gb"]], out=blk["out"], xn=None if blk["z_free"] else blk["z"], R=x, act=act, rpg=0, **fin, **hkw)
             return blk["out"]
-        if not gg:
+        if afin:
+            self._op(lst, tag + ":grn+apply", lib.mpmae_grn_apply_fin, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["G2"]), _p(P[nm["gg"]]), _p(P[nm["gb"]]),
+                     eps, M, H, _p(act), _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]), kind="grn_apply", nbytes=2 * M * H * esz)
+        elif not gg:
             self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                      _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
         if self._mx_block(blk):
@@ -1043,11 +1051,16 @@ class Engine:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         fold = blk.get("grn_fold", False)
-        if not fold and not gg:
+        afin = bool(blk.get("afin")) and rs_n != "fused" and not gg
+        if not fold and not gg and not afin:
             self._op(lst, tag + ":grn.bwd", lib.mpmae_grn_bwd_finalize, _p(blk["S0"]), _p(blk["S1"]), _p(blk["Gx"]),
                      _p(blk["Ainv"]), _p(P[nm["gg"]]), G, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]))
         rsc = rs_n == "fused"
-        if not rsc and not gg:
+        if afin:
+            self._op(lst, tag + ":grn.bwd+bapply", lib.mpmae_grn_bwd_apply_fin, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]), _p(blk["S0"]), _p(blk["S1"]),
+                     _p(blk["Gx"]), _p(blk["Ainv"]), _p(P[nm["gg"]]), M, H, _p(blk["coef"]), _p(Gd[nm["gg"]]), _p(Gd[nm["gb"]]),
+                     kind="grn_bwd_apply", nbytes=3 * M * H * esz)
+        elif not rsc and not gg:
             self._op(lst, tag + ":grn.bapply", lib.mpmae_grn_bwd_apply, dt, _p(dz), _p(blk["h"]), _p(blk["scale"]),
                      _p(blk["coef"]), M, H, rpg, kind="grn_bwd_apply", nbytes=3 * M * H * esz)
         if rsc:  # dh (written over dz) in the operand prologue, pwconv1 data gradient, LayerNorm backward
