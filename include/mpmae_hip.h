@@ -533,9 +533,10 @@ int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int 
 /* B [D][ldb] (staged transposed head weights, storage type dt): column k *= coef[col_mod[k]] in place; rowscale[k] = coef[col_mod[k]]. */
 int mpmae_head_scale(int dt, void* B, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale,
                      mpmae_stream_t stream);
-/* Row-split form (round 5) of mpmae_loss_pix_cont_rows (mode 0) / _fused (mode 2): one workgroup per PATCH ROW of a sample; every record's
- * `acc` must hold N * (H / p) {sum, count} slots (slot n * grid + row) and the finalisation is called with that many. */
-int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H,
+/* Row-split form (round 5) of mpmae_loss_pix_cont_rows (mode 0) / _fused (mode 2): `parts` workgroups per sample, each walking
+ * ceil(grid / parts) patch rows; every record's `acc` must hold N * parts {sum, count} slots (slot n * parts + part) and the finalisation
+ * is called with that many. */
+int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, int parts,
                                    mpmae_stream_t stream);
 /* Categorical pixel losses, wave-per-patch form (forward bwd = 0 / gradient bwd = 1): same records, outputs and partial layout as
  * mpmae_loss_multi(kind 1); bwd = 2: forward + UNSCALED gradient in one pass (mpmae_loss_pix_cont_rows_fused). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and

@@ -222,7 +222,7 @@ SYMBOLS = {
     "mpmae_loss_pix_cont_rows": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_bwd": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_fused": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "mpmae_loss_pix_cont_rows_split": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "mpmae_loss_pix_cont_rows_split": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_head_scale": [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

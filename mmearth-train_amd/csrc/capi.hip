@@ -789,7 +789,7 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
 }
 
 static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s, int split = 0) {
-  const int gx = split ? N * (H / p) : N;
+  const int gx = split > 1 ? N * split : N;
   if (bwd < 0 || bwd > 2) return (int)hipErrorInvalidValue;
   if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)maxC * (p * H + 4) * 4;
@@ -821,9 +821,9 @@ int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int 
   return loss_pix_cont_rows_impl(dt, 2, dev_args, count, N, maxC, p, H, s);
 }
 
-int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
-  if (mode != 0 && mode != 2) return (int)hipErrorInvalidValue;
-  return loss_pix_cont_rows_impl(dt, mode, dev_args, count, N, maxC, p, H, s, 1);
+int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, int parts, mpmae_stream_t s) {
+  if ((mode != 0 && mode != 2) || parts < 1 || parts > H / p) return (int)hipErrorInvalidValue;
+  return loss_pix_cont_rows_impl(dt, mode, dev_args, count, N, maxC, p, H, s, parts);
 }
 
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {

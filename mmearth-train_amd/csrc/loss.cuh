@@ -306,8 +306,10 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
   const PixContP q = tab[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float lpc_band[];
   __shared__ float part[8][2];
-  const int n = split ? blockIdx.x / q.grid : blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int py_begin = split ? blockIdx.x - n * q.grid : 0, py_end = split ? py_begin + 1 : q.grid;
+  // (split = number of row groups per sample: 0 / 1 = the whole sample, grid = one row per workgroup)
+  const int parts = split > 1 ? split : 1, rpp = (q.grid + parts - 1) / parts;
+  const int n = blockIdx.x / parts, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int py_begin = (blockIdx.x - n * parts) * rpp, py_end = min(q.grid, py_begin + rpp);
   const int p = q.p, C = q.C, H = q.H, G = q.grid, PP = p * p, J = PP * C;
   const int H4 = H >> 2, CP = p * H + 4, nvec = C * p * H4, npv = J >> 2;
   const float* tg_n = q.target + (size_t)n * C * H * H;
@@ -320,7 +322,7 @@ __global__ __launch_bounds__(512) void loss_pix_cont_rows_kernel(const PixContP*
       pre[i] = *reinterpret_cast<const float4*>(tg_n + ((size_t)c * H + py * p + ph) * H + x4 * 4);
     }
   };
-  prefetch(py_begin);
+  prefetch(min(py_begin, q.grid - 1));
   // band offsets of this lane's elements, once per workgroup (no integer division in the row loop): planar order for the target
   // statistics (8 consecutive lanes = one image row of the patch: conflict-free), prediction order for the squared error
   // (only while the tables fit the register file: the 112/16 variant computes them in the loop)

@@ -75,7 +75,7 @@ ENGINE_OPTIONS = dict(
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
     stats_wgrad=0,          # (measured SLOWER, 3.76 vs 3.66 ms: the transpose-read weight gradient + its fold on the main lane cost more than the statistics pass they replace; parity-tested, off) blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient (T = dout^T gelu(h) into scratch on the MAIN lane, then mpmae_grn_stats_from_wgrad) instead of a statistics-only pass over dout and h (mpmae_rs which = 1, out = NULL): one read of the block's widest tensor less per block; implies z_free for those blocks
     grn_apply_fin=1,        # unfused sparse blocks (C = 320: tiled GEMMs + element-wise GRN passes): the GRN finalisation runs in the prologue of the element-wise pass (mpmae_grn_apply_fin / _bwd_apply_fin) - two launches fewer per block on the main lane
-    loss_rowsplit=0,        # (measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times; tested, off) continuous pixel losses: one workgroup per PATCH ROW of a sample (mpmae_loss_pix_cont_rows_split) instead of one per sample walking its 7 rows; the {sum, count} partials get N * grid slots per modality
+    loss_rowsplit=0,        # k > 1: continuous pixel losses with k workgroups per sample, each walking ceil(grid / k) patch rows (k = grid, one row per workgroup, measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times)
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
@@ -382,7 +382,8 @@ class Engine:
             off += -(-(blk["C"] * blk["H"] + blk["C"]) // 64) * 64
         # per-sample {sum, count} partials; with the row-split continuous losses N * grid slots per modality (slot n * grid + row; the kernels that
         # write one partial per sample use the first N slots, the rest stay zero: the finalisation folds all of them in a fixed order)
-        self.loss_slots = N * (self.grid if (bool(self.opt["loss_rowsplit"]) and bool(self.opt["loss_rows"]) and bool(self.opt["loss_multi"])) else 1)
+        self.loss_parts = min(self.grid, int(self.opt["loss_rowsplit"])) if (int(self.opt["loss_rowsplit"]) > 1 and bool(self.opt["loss_rows"]) and bool(self.opt["loss_multi"])) else 1
+        self.loss_slots = N * self.loss_parts
         self.loss_acc = torch.zeros(T, self.loss_slots, 2, dtype=f32, device=dev)
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
@@ -1504,7 +1505,7 @@ class Engine:
                     self._cont_rows = maxc
                     if self.loss_slots > N:
                         self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_split, dt, 2 if onepass else 0, _p(tab), len(mods), N, maxc,
-                                 self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                                 self.p, cfg.img_size, self.loss_parts, kind=f"loss_{kind}_fwd")
                     else:
                         self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
                                  dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
