@@ -72,16 +72,17 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         return launch_status();
       }
     }
-    if constexpr (KC == 160 || KC == 320) {
+    if constexpr (KC == 160 || KC == 320 || KC == 192 || KC == 384) {
       // one-shot form (rsc1.cuh): a workgroup keeps its weight slice (DMA, once) and walks row tiles; every operand requested in one burst
       const int rt1 = g_opt[MPMAE_OPT_RSC1];
       if (rt1 > 0) {
-        const int rtv = (rt1 >= 2 && !(KC == 320 && which == 0 && !a.ln_done)) ? 2 : 1;      // (LayerNorm mode at C = 320 with two row tiles per wave spills)
+        const int rtv = (rt1 >= 2 && !(KC >= 320 && which == 0 && !a.ln_done)) ? 2 : 1;      // (LayerNorm mode at C = 320 with two row tiles per wave spills)
         const int ntiles = cdiv(a.M, 64 * rtv);
         // measured (tools/probes/rs1_probe.py, incl. the fold): C = 160: which 0 24.0 (slice 128) / 27.4 (64) vs 29.9 us chunked, which 1 25.7 (128) / 19.1 (64) vs
         // 23.8; C = 320: which 0 25.3 vs 30.8, which 1 18.7 vs 22.5; without the fold launch (atomics) 22.5 / 16.4 at C = 320
-        const int cpsv = g_opt[MPMAE_OPT_RSC1_CPS] > 0 ? g_opt[MPMAE_OPT_RSC1_CPS] : ((KC == 160 && which == 0) ? 128 : 64);
-        if (cpsv != 64 && !(KC == 160 && cpsv == 128)) return (int)hipErrorInvalidValue;
+        // (tiny widths, BASELINE config 4: C = 192 in 96-column slices, C = 384 in 64-column slices)
+        const int cpsv = (KC == 192) ? 96 : (KC == 384) ? 64 : (g_opt[MPMAE_OPT_RSC1_CPS] > 0 ? g_opt[MPMAE_OPT_RSC1_CPS] : ((KC == 160 && which == 0) ? 128 : 64));
+        if (cpsv != 64 && !(KC == 160 && cpsv == 128) && !(KC == 192 && cpsv == 96)) return (int)hipErrorInvalidValue;
         const int ny = HN / cpsv;
         const int wgs = g_opt[MPMAE_OPT_RSC1_WGS] > 0 ? g_opt[MPMAE_OPT_RSC1_WGS] : 3 * ps_num_cus();
         const int gxmax = wgs / ny > 0 ? wgs / ny : 1;
@@ -101,7 +102,8 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
           if (lds1s > cur) { if (hipFuncSetAttribute((const void*)rsc_wide1_kernel<KC, MODE_, RT_, CPS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1s) != hipSuccess) return (int)hipGetLastError(); cur = lds1s; } \
           LAUNCH((rsc_wide1_kernel<KC, MODE_, RT_, CPS_>), g1, dim3(256), lds1s, st, p, ntiles); } while (0)
 #define RSC_WIDE1_M(MODE_) do { \
-          if constexpr (KC == 160) { if (cpsv == 128) { if (rtv == 2) RSC_WIDE1(MODE_, 2, 128); else RSC_WIDE1(MODE_, 1, 128); } \
+          if constexpr (KC == 192) { if (rtv == 2) RSC_WIDE1(MODE_, 2, 96); else RSC_WIDE1(MODE_, 1, 96); } \
+          else if constexpr (KC == 160) { if (cpsv == 128) { if (rtv == 2) RSC_WIDE1(MODE_, 2, 128); else RSC_WIDE1(MODE_, 1, 128); } \
                                      else { if (rtv == 2) RSC_WIDE1(MODE_, 2, 64); else RSC_WIDE1(MODE_, 1, 64); } } \
           else { if (rtv == 2) RSC_WIDE1(MODE_, 2, 64); else RSC_WIDE1(MODE_, 1, 64); } } while (0)
         if (which == 0) { if (a.ln_done) RSC_WIDE1_M(2); else RSC_WIDE1_M(0); }

@@ -28,9 +28,14 @@ __device__ unsigned long long rsc1_stamp_buf[4096 * 4 * 8];
 #define RSC1_ST(k) do { } while (0)
 #endif
 
+//       KC = 384 (48 chunks per row = 0 mod 16): slot = q'               ->  q' = q ^ ((R & 3) | (a << 2))              (f < 16, 48 = 3 x 16)
+//       (KC = 192: 24 chunks = 8 mod 16, the KC = 320 rule, 24 = 3 x 8)
 template <int KC> __device__ __forceinline__ int rsc1_swz(int row) {
-  if (KC == 320 || KC == 192) return ((row >> 1) & 1) | (((row >> 3) & 3) << 1);
+  constexpr int CM = (KC / 8) % 16;
+  static_assert(CM == 8 || CM == 4 || CM == 0, "swizzle table");
   const int a = (row >> 3) & 3;
+  if (CM == 8) return ((row >> 1) & 1) | (a << 1);
+  if (CM == 0) return (row & 3) | (a << 2);
   return (4 - a) & 3;                              // {0, 3, 2, 1}
 }
 
@@ -44,11 +49,11 @@ template <int KC> __device__ __forceinline__ int rsc1_swz(int row) {
 // MODE 1 paid one round trip per tile pair for its h operand; with one burst the wait is 3 us and the LayerNorm arithmetic itself
 // (redone by every column slice: 20 x at C = 320) 3.4 us with three workgroups sharing a CU's VALUs.
 // MODE 2: MODE 0 without the LayerNorm - A is xn as stored by the producer (dwln.cuh), h = xn W1^T + b1, sum gelu(h)^2.
-template <int KC, int MODE, int RT, int CPS, bool PFA = (KC <= 160)>
-__global__ __launch_bounds__(256, (RT == 1 && !(MODE == 0 && KC == 320)) ? 3 : 2) void rsc_wide1_kernel(const RsP p, int ntiles) {
+template <int KC, int MODE, int RT, int CPS, bool PFA = (KC <= 192)>
+__global__ __launch_bounds__(256, (RT == 1 && !(MODE == 0 && KC >= 320)) ? 3 : 2) void rsc_wide1_kernel(const RsP p, int ntiles) {
   using T = bf16_t;
   constexpr int HN = 4 * KC, KS = KC / 32, CPR = KC / 8, NP = CPS / 32, NINST = CPS * CPR / 64, cps = CPS;
-  static_assert(KC == 160 || KC == 320, "swizzle table");
+  static_assert(KC == 160 || KC == 320 || KC == 192 || KC == 384, "swizzle table");
   static_assert(CPS % 32 == 0 && HN % CPS == 0 && NINST % 4 == 0, "slice shape");
   static_assert(2 * KC / 4 <= 256, "one float4 of gamma / beta per thread");
   constexpr bool LN = MODE == 0, DZ = MODE == 1;
