@@ -48,6 +48,7 @@ ENGINE_OPTIONS = dict(
     loss_rows=1,            # continuous pixel losses: row-band forward kernel
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
+    cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
     front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
@@ -1538,6 +1539,22 @@ class Engine:
                     m["lane"] = 1
                     if j == 0:
                         m["wait"] = tuple(m["wait"]) + (prod["signal"],)
+                cat = [i for i, n in enumerate(names) if n.startswith("loss:pix_cat")]
+                if cat and bool(self.opt["cat_side"]) and self.loss_onepass and any(n.startswith("loss:pix_cont") for n in names):
+                    hp = f[names.index("head:pix")][3]          # the predictions the loss reads
+                    if hp["signal"] is None:
+                        hp["signal"] = "pred_pix"
+                    for i in cat:
+                        f[i][3]["lane"] = 1
+                        f[i][3]["wait"] = tuple(f[i][3]["wait"]) + (hp["signal"],)
+                    # the side lane is an in-order stream: the loss goes behind the image-head chain in the op list as well
+                    moved = [f[i] for i in cat]
+                    for i in reversed(cat):
+                        del f[i]
+                    names = [op[0] for op in f]
+                    at = max(i for i, n in enumerate(names) if n in side_names) + 1
+                    f[at:at] = moved
+                    idx = [i for i, op in enumerate(f) if op[3]["lane"] == 1 and (op[0] in side_names or op[0].startswith("loss:pix_cat"))]
                 f[idx[-1]][3]["signal"] = "img_side_done"
                 self._fwd_join_keys = ["img_side_done"]
         if self._front_rest is not None:          # the first main-lane op behind the fused stem kernel waits for the rest of the side-lane front
