@@ -48,6 +48,7 @@ ENGINE_OPTIONS = dict(
     loss_rows=1,            # continuous pixel losses: row-band forward kernel
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
+    ps_ng=4,                # accumulator copies of each GRN statistics vector of the persistent stage kernels (workgroup n adds into copy n % ps_ng)
     cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
@@ -362,7 +363,7 @@ class Engine:
         T = len(cfg.out_mods)
         self.n_stats = sum(self._stat_sizes)
         # persistent stage kernels: PS_NG accumulator copies of each statistics vector (same arena: zeroed once per step)
-        self.PS_NG = 4
+        self.PS_NG = max(1, min(16, int(self.opt["ps_ng"])))
         ps_blocks = [blk for blk in self.blocks if self._ps_ok(blk["stage"])]
         sw_blocks = [blk for blk in self.blocks if blk["sparse"] and blk["C"] <= int(self.opt["dzr_maxc"]) and bool(self.opt["stats_wgrad"]) and self.dt == BF16]
         sw_floats = sum(-(-(b["C"] * b["H"] + b["C"]) // 64) * 64 for b in sw_blocks)
