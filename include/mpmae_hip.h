@@ -564,6 +564,13 @@ int mpmae_loss_finalize_guarded(const float* acc, int N, const float* log_vars, 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
                 float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
                 mpmae_stream_t stream);
+/* One gradient bucket of the same update (round 5): elements [0, n) of the pointers given, with `nslots` workgroups whose g^2 partials land in
+ * gnorm2[1 + slot0 ...]; the part with slot0 == 0 writes gnorm2[0] = total_slots (<= 4096, the sum of the parts' nslots). Every part of a step
+ * runs behind that step's mpmae_hp_fetch; a bucket's part may run as soon as its gradients are final (and exchanged) and the last reader of its
+ * fp32 parameters in the backward has finished - the reference's optimizer.step() (main_pretrain.py:312-320) cut along dist.plan_buckets. */
+int mpmae_adamw_part(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
+                     float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
+                     int slot0, int nslots, int total_slots, mpmae_stream_t stream);
 int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
 /* hyper-parameter hand-over for replayed steps: copies record (*counter % slots) of a pinned,
  * device-visible ring of {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} records into hp and

@@ -231,6 +231,8 @@ SYMBOLS = {
                                     c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p, c_void_p],
+    "mpmae_adamw_part": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
+                         c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
     "mpmae_ln_fwd_down": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
                           c_void_p, c_void_p],

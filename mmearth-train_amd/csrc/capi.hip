@@ -857,8 +857,17 @@ int mpmae_loss_finalize(const float* acc, int N, const float* log_vars, int T, f
 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
                 float wd, size_t n, const uint8_t* decay, float* gnorm2, mpmae_stream_t s) {
-  LAUNCH(adamw_kernel, dim3(grid1d((long long)n, 256, 4096)), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2,
-                     eps, wd, n, decay, gnorm2);
+  const int nb = grid1d((long long)n, 256, 4096);
+  LAUNCH(adamw_kernel, dim3(nb), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2, eps, wd, n, decay, gnorm2, 0, nb);
+  RET();
+}
+
+int mpmae_adamw_part(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
+                     float wd, size_t n, const uint8_t* decay, float* gnorm2, int slot0, int nslots, int total_slots, mpmae_stream_t s) {
+  if (!p || !g || !m || !v || !hp || !decay || n == 0 || nslots < 1 || slot0 < 0 || slot0 + nslots > total_slots || total_slots > 4096)
+    return (int)hipErrorInvalidValue;
+  // exactly nslots workgroups: every partial slot of the part is written by every launch (a workgroup without elements writes 0)
+  LAUNCH(adamw_kernel, dim3(nslots), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2, eps, wd, n, decay, gnorm2, slot0, total_slots);
   RET();
 }
 

@@ -132,7 +132,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     const float* __restrict__ hp, float beta1, float beta2,
                                                     float eps, float wd, size_t n,
-                                                    const uint8_t* __restrict__ decay, float* __restrict__ gnorm2) {
+                                                    const uint8_t* __restrict__ decay, float* __restrict__ gnorm2,
+                                                    int slot0, int nslots) {
+  // (slot0, nslots): this launch's place among the per-workgroup partials of the step's gradient norm - one launch over the whole
+  // buffer (0, gridDim.x) or one launch per gradient bucket (mpmae_adamw_part: the buckets' updates run as their gradients become final)
   if (hp[4] != 0.f) return;      // non-finite loss this step (hp_fetch): the update is skipped, p / m / v stay intact
   const float lr = hp[0], ibc1 = hp[1], isbc2 = hp[2], gs = hp[3];
   float gsq = 0.f;               // sum g^2 (unscaled): the global gradient norm rides in the pass that reads every gradient anyway
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     gsq = wave_sum(gsq);
     if ((threadIdx.x & 63) == 0) gred[threadIdx.x >> 6] = gsq;
     __syncthreads();
-    if (threadIdx.x == 0) gnorm2[1 + blockIdx.x] = gred[0] + gred[1] + gred[2] + gred[3];
-    if (blockIdx.x == 0 && threadIdx.x == 0) gnorm2[0] = (float)gridDim.x;
+    if (threadIdx.x == 0) gnorm2[1 + slot0 + blockIdx.x] = gred[0] + gred[1] + gred[2] + gred[3];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && slot0 == 0) gnorm2[0] = (float)nslots;
   }
 }
 

@@ -49,6 +49,7 @@ ENGINE_OPTIONS = dict(
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
     ps_ng=4,                # accumulator copies of each GRN statistics vector of the persistent stage kernels (workgroup n adds into copy n % ps_ng)
+    adamw_split=0,          # round 5: the optimizer of the plain single-GPU step cut along the gradient buckets (dist.plan_buckets, mpmae_adamw_part): hp_fetch in front of the backward, a bucket's AdamW on the weight-gradient lane as soon as its gradients are final, only the last bucket's (stem, stages 0-1: 6 % of the parameters) behind the backward. The step boundary shrinks from 71 to 11 us in the kernel trace and the step does not move (3.653 / 3.656 vs 3.650 / 3.647 ms, profiles/r05/ab_adamw_split.txt): the 224 MB the update streams now compete inside the two-lane backward, which is throughput-bound
     cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
@@ -2116,7 +2117,8 @@ class Engine:
             out[c] = dict(value=float(win[0]), median=float(win.median()), avg=float(win.mean()), global_avg=float(sums[i]) / n)
         return out
 
-    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
+    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None,
+                    adamw_split=False):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
         runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
         [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
@@ -2134,6 +2136,13 @@ class Engine:
                     (a[0], self.loss_slots, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None) + tuple(self._err_words()), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
+        split = bool(adamw_split) and bwd_segments is None and self.lanes and bool(self.opt["adamw_split"])
+        if split:
+            from .dist import plan_buckets, split_bwd_segments
+            try:
+                cut, rng = split_bwd_segments(self.bwd_ops), plan_buckets(self.offsets, self.n_params)
+            except (StopIteration, AssertionError):
+                split = False
         # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane
         # event - the stem GEMM waiting for the weight staging - covers the statistics; the gradient finalisation waits for "grads_zero")
         fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), dict(zl, signal="stats_zero") if zs else zl)]
@@ -2165,9 +2174,47 @@ class Engine:
                 self._evseq += 1
                 op[3]["signal"] = f"j{self._evseq}"
             joins.append(op[3]["signal"])
-        opt = [("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
-                                                 _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), self._meters()),
-                dict(lane=0, wait=tuple(joins), signal=None)),
+        fetch = ("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
+                                                  _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), self._meters()))
+        if split:
+            # The optimizer cut along the gradient buckets. hp.fetch moves in front of the backward (the loss it guards, the error words of
+            # the forward's persistent kernels and the previous update's gradient-norm partials all exist there); bucket b's update is a
+            # weight-gradient-lane op behind the bucket's last weight gradient / fold (in-order lane) that waits for the segment's last
+            # main-lane op - the last reader of the bucket's fp32 parameters (LayerNorm / GRN vectors, depthwise taps, biases; the
+            # GEMMs read the bf16 copies staged at the step front). Only the last bucket's update stays behind the backward.
+            nsl, tot = [], 0
+            for lo, hi in rng:
+                nsl.append(max(1, min(1024, -(-(hi - lo) // 2048))))
+            tot = sum(nsl)
+            slot0 = [sum(nsl[:i]) for i in range(len(nsl))]
+
+            def part(i, meta):
+                lo, hi = rng[i]
+                return (f"adamw.part{i}", lib.mpmae_adamw_part,
+                        (_p(self.pflat[lo:hi]), _p(self.gflat[lo:hi]), _p(self.mflat[lo:hi]), _p(self.vflat[lo:hi]), _p(self.hp), beta1, beta2,
+                         eps, weight_decay, hi - lo, _p(self.decay_mask[lo:hi]), _p(self.gnorm2), slot0[i], nsl[i], tot), meta)
+            bw = [fin(True), fetch + (dict(lane=0, wait=(), signal=None),)]
+            for i, sg in enumerate(cut):
+                bw += list(sg)
+                if i + 1 < len(cut):
+                    mains = [op for op in sg if op[3]["lane"] == 0]
+                    if mains[-1][3]["signal"] is None:
+                        self._evseq += 1
+                        mains[-1][3]["signal"] = f"o{self._evseq}"
+                    bw.append(part(i, dict(lane=1, wait=(mains[-1][3]["signal"],), signal=None)))
+            last_side = {}
+            for op in bw:
+                if op[3]["lane"] != 0:
+                    last_side[op[3]["lane"]] = op
+            joins = []
+            for ln, op in sorted(last_side.items()):
+                if op[3]["signal"] is None:
+                    self._evseq += 1
+                    op[3]["signal"] = f"j{self._evseq}"
+                joins.append(op[3]["signal"])
+            self._bucket_keys = []
+            return [fwd, zero, bw, [part(len(cut) - 1, dict(lane=0, wait=tuple(joins), signal=None))]]
+        opt = [fetch + (dict(lane=0, wait=tuple(joins), signal=None),),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), _p(self.gnorm2)), m0)]
         # "bucket ready" points for a data-parallel runner that replays the whole backward as ONE call: per segment the keys of its last
