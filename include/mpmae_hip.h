@@ -397,6 +397,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSP_NWGS,   /* default 0 = as many as fit a CU's LDS, at most 2 per CU: workgroup count of the persistent NARROW kernels */
   MPMAE_OPT_RSP_NARROW,   /* default 2: which NARROW launches take the persistent burst-load kernels: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80 (measured: only which 5 at C = 40 gains, 88.6 -> 70 us) */
   MPMAE_OPT_RSN3,   /* default 5: the fused pointwise BACKWARD kernel at C = 160 (mpmae_rs which = 5, single GRN group, dz materialised) in its ring-pipelined form (csrc/rsn3.cuh: weight slabs by DMA into a three-slot LDS ring, rows two chunks ahead, one bare barrier per chunk); value = waves per workgroup (4 or 5); 0 = rsc_narrow */
+  MPMAE_OPT_EVX,   /* default 1: in a launch program an op's cross-lane signal is the completion event of its last kernel launch (hipExtLaunchKernelGGL stopEvent) instead of a hipEventRecord - a barrier packet of its own - behind it: 1.65 us less per signal on the signalling lane (tools/probes/ext_event_probe.hip); 0 = hipEventRecord */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

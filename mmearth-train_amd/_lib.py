@@ -152,7 +152,7 @@ class StemFrontArgs(C.Structure):
 
 
 SK_FLAGS = 2048              # MPMAE_SK_FLAGS (include/mpmae_hip.h)
-OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP RSC_W5 BLASLT NT5 RSC_ATOMIC SK DET RSC1 RSC1_CPS RSC1_WGS RSC1_ATOMIC RSP RSP_WGS RSP_NWV RSP_NWGS RSP_NARROW RSN3".split())}      # enum MpmaeOption (include/mpmae_hip.h)
+OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP RSC_W5 BLASLT NT5 RSC_ATOMIC SK DET RSC1 RSC1_CPS RSC1_WGS RSC1_ATOMIC RSP RSP_WGS RSP_NWV RSP_NWGS RSP_NARROW RSN3 EVX".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 

@@ -41,6 +41,7 @@ void launch_reduce_rowscale(const float* part, int P, int W, float* out, float* 
 // variables read inside the library; defaults are the measured-best choices.
 // ------------------------------------------------------------------------------------------
 thread_local MpmaeProgram* g_rec = nullptr;
+thread_local hipEvent_t g_stop_ev = nullptr;
 thread_local int g_launch_err = 0;
 
 int g_opt[MPMAE_OPT_COUNT_] = {
@@ -89,6 +90,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSP_NWGS */ 0,
     /* MPMAE_OPT_RSP_NARROW */ 2,
     /* MPMAE_OPT_RSN3 */ 5,
+    /* MPMAE_OPT_EVX */ 1,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -1202,9 +1204,17 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
       if (hipStreamWaitEvent(st, p->events[w], 0) != hipSuccess) return (int)hipGetLastError();
       seen[op.lane][sl] = so;
     }
-    for (auto& l : op.launches) l(st);
-    if (op.signal > 0 && p->waited[op.signal]) {
-      if (hipEventRecord(p->events[op.signal], st) != hipSuccess) return (int)hipGetLastError();
+    const bool sig = op.signal > 0 && p->waited[op.signal];
+    const size_t nl = op.launches.size();
+    for (size_t j = 0; j < nl; ++j) {
+      if (sig && j + 1 == nl && g_opt[MPMAE_OPT_EVX] > 0) g_stop_ev = p->events[op.signal];      // the last launch carries the signal itself
+      op.launches[j](st);
+    }
+    if (sig) {
+      if (g_stop_ev || nl == 0 || g_opt[MPMAE_OPT_EVX] <= 0) {      // not consumed (the last launch is no kernel) / no launch / option off
+        g_stop_ev = nullptr;
+        if (hipEventRecord(p->events[op.signal], st) != hipSuccess) return (int)hipGetLastError();
+      }
       p->epoch[op.signal] = p->run;
     }
   }

@@ -3,6 +3,7 @@
 // library options and a few host helpers. Kernel headers with non-template kernels are included by exactly ONE unit each.
 #pragma once
 #include "common.cuh"
+#include <hip/hip_ext.h>
 
 #define S_(s) reinterpret_cast<hipStream_t>(s)
 
@@ -46,8 +47,17 @@ static inline void submit(hipStream_t st, F&& f) {
 // the entry point returns and resets (launch_status()).
 extern thread_local int g_launch_err;
 static inline int launch_status() { const int e = g_launch_err; g_launch_err = 0; return e; }
+// g_stop_ev: set by mpmae_program_run in front of the LAST launch of an op whose cross-lane signal some other lane waits for
+// (MPMAE_OPT_EVX): that launch takes the event as its own completion event (hipExtLaunchKernelGGL stopEvent - the dispatch packet's
+// completion signal) instead of a hipEventRecord behind it, which is a barrier packet of its own in the lane's queue: 6.99 -> 5.34 us per
+// dependent small kernel on the signalling lane, plain 4.03 (tools/probes/ext_event_probe.hip). A submit that is not a kernel launch leaves
+// the event untouched and the replay loop records it the old way.
+extern thread_local hipEvent_t g_stop_ev;      // (defined in capi.hip)
 #define LAUNCH(kern, g, b, lds, st, ...) \
-  submit(st, [=](hipStream_t st__) { (void)hipGetLastError(); hipLaunchKernelGGL(kern, g, b, lds, st__, __VA_ARGS__); \
+  submit(st, [=](hipStream_t st__) { (void)hipGetLastError(); \
+                                     if (g_stop_ev) { hipEvent_t ev__ = g_stop_ev; g_stop_ev = nullptr; \
+                                                      hipExtLaunchKernelGGL(kern, g, b, lds, st__, nullptr, ev__, 0, __VA_ARGS__); } \
+                                     else hipLaunchKernelGGL(kern, g, b, lds, st__, __VA_ARGS__); \
                                      const hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess && !g_launch_err) g_launch_err = (int)e__; })
 #define RET() return launch_status()
 
