@@ -969,6 +969,28 @@ int mpmae_stem_front(const MpmaeStemFrontArgs* a, mpmae_stream_t s) {
   RET();
 }
 
+// ONE launch per FOLDG_MAX mode-1 fold records (blockIdx.z = record) instead of one launch per record
+static void launch_fold_records(const MpmaeFoldDesc* descs, int count, hipStream_t st) {
+  for (int i0 = 0; i0 < count; i0 += FOLDG_MAX) {
+    const int n = count - i0 < FOLDG_MAX ? count - i0 : FOLDG_MAX;
+    FoldGroupP g;
+    g.count = n; g.pad = 0;
+    int wmax = 1, pmax = 1;
+    for (int i = 0; i < n; ++i) {
+      const MpmaeFoldDesc& d = descs[i0 + i];
+      g.part[i] = d.part; g.out[i] = d.out; g.P[i] = d.P; g.W[i] = d.W; g.a[i] = d.a; g.b[i] = d.b; g.c[i] = d.c;
+      if (d.W > wmax) wmax = d.W;
+      if (d.P > pmax) pmax = d.P;
+    }
+    for (int i = n; i < FOLDG_MAX; ++i) { g.part[i] = nullptr; g.out[i] = nullptr; g.P[i] = g.W[i] = 0; g.a[i] = 1; g.b[i] = g.c[i] = 0; }
+    int R = pmax / 16;                 // as launch_reduce: >= 4 rows per thread
+    if (R < 1) R = 1;
+    if (R > 32) R = 32;
+    if (g_opt[MPMAE_OPT_DET] > 0) R = 1;      // (as launch_reduce: plain `+=` in a fixed order)
+    LAUNCH(reduce_partials_group1_kernel, dim3(cdiv(wmax, 64), R, n), dim3(256), 0, st, g);
+  }
+}
+
 int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t s) {
   if (!a || (a->C & 7) || a->C > 512 || a->M < 1) return (int)hipErrorInvalidValue;
   const int nvec = a->C / 8;
@@ -995,11 +1017,17 @@ int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t 
   if (bwd) {
     const int nw = blocks * 4;
     float* outs[3][2] = {{a->dg2, a->db2}, {a->dw, a->dwb}, {a->dg1, a->db1}};
+    MpmaeFoldDesc fd[3];
     for (int k = 0; k < 3; ++k) {      // slabs [k][wave][2][C]: e = n*C + c -> n == 0 ? first[c] : second[c]
       const long long delta = outs[k][1] - outs[k][0];
       if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
-      launch_reduce(1, a->ws + (size_t)k * nw * 2 * a->C, nw, 2 * a->C, outs[k][0], nullptr, a->C, (int)delta, 1, 0, S_(s));
+      fd[k].part = a->ws + (size_t)k * nw * 2 * a->C; fd[k].out = outs[k][0];
+      fd[k].P = nw; fd[k].W = 2 * a->C; fd[k].a = a->C; fd[k].b = (int)delta; fd[k].c = 1;
     }
+    // the three folds of ONE producer kernel in one launch (round 5: they are the exposed tail of the step on the main lane; grouping the
+    // folds of DIFFERENT producers was slower, MPMAE_OPT_FOLD_GROUP); FOLD_GROUP < 0 keeps the three launches
+    if (g_opt[MPMAE_OPT_FOLD_GROUP] >= 0) launch_fold_records(fd, 3, S_(s));
+    else for (int k = 0; k < 3; ++k) launch_reduce(1, fd[k].part, fd[k].P, fd[k].W, fd[k].out, nullptr, fd[k].a, fd[k].b, fd[k].c, 0, S_(s));
   }
   RET();
 }
@@ -1253,24 +1281,7 @@ int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t s) {
     }
     RET();
   }
-  // ONE launch per FOLDG_MAX records (blockIdx.z = record) instead of one per record
-  for (int i0 = 0; i0 < count; i0 += FOLDG_MAX) {
-    const int n = count - i0 < FOLDG_MAX ? count - i0 : FOLDG_MAX;
-    FoldGroupP g;
-    g.count = n; g.pad = 0;
-    int wmax = 1, pmax = 1;
-    for (int i = 0; i < n; ++i) {
-      const MpmaeFoldDesc& d = descs[i0 + i];
-      g.part[i] = d.part; g.out[i] = d.out; g.P[i] = d.P; g.W[i] = d.W; g.a[i] = d.a; g.b[i] = d.b; g.c[i] = d.c;
-      if (d.W > wmax) wmax = d.W;
-      if (d.P > pmax) pmax = d.P;
-    }
-    for (int i = n; i < FOLDG_MAX; ++i) { g.part[i] = nullptr; g.out[i] = nullptr; g.P[i] = g.W[i] = 0; g.a[i] = 1; g.b[i] = g.c[i] = 0; }
-    int R = pmax / 16;                 // as launch_reduce: >= 4 rows per thread
-    if (R < 1) R = 1;
-    if (R > 32) R = 32;
-    LAUNCH(reduce_partials_group1_kernel, dim3(cdiv(wmax, 64), R, n), dim3(256), 0, S_(s), g);
-  }
+  launch_fold_records(descs, count, S_(s));
   RET();
 }
 

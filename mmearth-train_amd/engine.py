@@ -50,6 +50,7 @@ ENGINE_OPTIONS = dict(
     img_side=1,             # image-level head chain on the side lane
     ps_ng=4,                # accumulator copies of each GRN statistics vector of the persistent stage kernels (workgroup n adds into copy n % ps_ng)
     adamw_split=0,          # round 5: the optimizer of the plain single-GPU step cut along the gradient buckets (dist.plan_buckets, mpmae_adamw_part): hp_fetch in front of the backward, a bucket's AdamW on the weight-gradient lane as soon as its gradients are final, only the last bucket's (stem, stages 0-1: 6 % of the parameters) behind the backward. The step boundary shrinks from 71 to 11 us in the kernel trace and the step does not move (3.653 / 3.656 vs 3.650 / 3.647 ms, profiles/r05/ab_adamw_split.txt): the 224 MB the update streams now compete inside the two-lane backward, which is throughput-bound
+    tail_fold_group=1,      # the LayerNorm-gradient fold group that runs in order on the main lane (tail_main) as ONE launch, like the stem kernel's three folds (library: FOLD_GROUP >= 0)
     cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
@@ -652,7 +653,16 @@ class Engine:
         def fold(stream, _arr=arr, _srcs=srcs):      # the records are filled by the mpmae_rs calls of the stage (recorded / issued before this op)
             for i_, fd in enumerate(_srcs):
                 _arr[i_] = fd
+            if lane == 0 and grouped:      # the fold group in order on the main lane (the step's exposed tail): ONE launch for its records
+                fg = _lib.OPT["FOLD_GROUP"]
+                old = self.lib.mpmae_get_option(fg)
+                self.lib.mpmae_set_option(fg, 1)
+                try:
+                    return self.lib.mpmae_fold_group(_arr, len(_srcs), stream)
+                finally:
+                    self.lib.mpmae_set_option(fg, old)
             return self.lib.mpmae_fold_group(_arr, len(_srcs), stream)
+        grouped = bool(self.opt["tail_fold_group"])
         k = self._after(lst) if lane else None
         self._op(lst, f"{stage}:ln.fold[{len(pend)}]", fold, kind="ln_fold_group", lane=lane, wait=(k,) if k else ())
 
