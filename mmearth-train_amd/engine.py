@@ -51,6 +51,7 @@ ENGINE_OPTIONS = dict(
     ps_ng=4,                # accumulator copies of each GRN statistics vector of the persistent stage kernels (workgroup n adds into copy n % ps_ng)
     adamw_split=0,          # round 5: the optimizer of the plain single-GPU step cut along the gradient buckets (dist.plan_buckets, mpmae_adamw_part): hp_fetch in front of the backward, a bucket's AdamW on the weight-gradient lane as soon as its gradients are final, only the last bucket's (stem, stages 0-1: 6 % of the parameters) behind the backward. The step boundary shrinks from 71 to 11 us in the kernel trace and the step does not move (3.653 / 3.656 vs 3.650 / 3.647 ms, profiles/r05/ab_adamw_split.txt): the 224 MB the update streams now compete inside the two-lane backward, which is throughput-bound
     tail_fold_group=1,      # the LayerNorm-gradient fold group that runs in order on the main lane (tail_main) as ONE launch, like the stem kernel's three folds (library: FOLD_GROUP >= 0)
+    img_dgrad_side=1,       # round 5: the image-level heads' data-gradient GEMM (eight workgroups, pure latency) on the weight-gradient lane in front of the heads' weight gradients
     cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
@@ -1687,6 +1688,19 @@ class Engine:
             ts = [Gd[f"pred_dict.{m.name}.{suffix}"] for m in mods]
             return all(a.data_ptr() + a.numel() * 4 == b_.data_ptr() for a, b_ in zip(ts, ts[1:]))
 
+        # The image-level heads' data-gradient GEMM (256 rows: eight workgroups, ~20 us of pure latency) on the weight-gradient lane IN FRONT of the
+        # heads' weight gradients: it only needs the image losses' gradient, and its consumer - the LayerNorm backward that accumulates
+        # into dy behind the pixel heads' data gradient - waits for its signal
+        img_dgrad_key = None
+        if cfg.img_mods and self.lanes and bool(self.opt["img_dgrad_side"]):
+            wt_i = self.w["head.imgT"]
+            k_ = self._after(b)
+            self._evseq += 1
+            img_dgrad_key = f"s{self._evseq}"
+            self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt_i["t"], C=self.dpooled, M=N, N=D,
+                       K=self.ldimg, lda=self.ldimg, ldb=wt_i["ld"], ldc=D)
+            b[-1][2][-1]._obj.ws = self.ws2.data_ptr()      # (side-lane scratch)
+            b[-1][3].update(lane=1, wait=(k_,) if k_ else (), signal=img_dgrad_key)
         if cfg.pix_mods and contiguous(cfg.pix_mods, "weight") and contiguous(cfg.pix_mods, "bias"):
             m0 = cfg.pix_mods[0]        # all pixel heads at once: dW [Wpix, D] and db [Wpix] are contiguous (see _build_params)
             self._side_wgrad(b, "head:pix.wgrad", "NONE", "NONE", [], P=self.dpred_pix, Q=y, M=N * L, Nn=self.Wpix, Kk=D,
@@ -1717,11 +1731,13 @@ class Engine:
             wt = self.w["head.imgT"]
             # K = the padded width: dpred_img's and the staged weights' padding columns are zero, and a multiple of 8
             # keeps this tiny GEMM on the fast kernel
-            self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
-                       K=self.ldimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
+            if img_dgrad_key is None:
+                self._gemm(b, "head:img.dgrad", "NONE", "STORE", A=self.dpred_img, B=wt["t"], C=self.dpooled, M=N, N=D,
+                           K=self.ldimg, lda=self.ldimg, ldb=wt["ld"], ldc=D)
             self._op(b, "head:ln.bwd", self._ln_bwd_callable(D), dt, _p(self.dpooled), L, 1.0 / L, _p(self.yhat), _p(self.rstd_y),
                      _p(P["layer_norm_tmp.weight"]), _p(P["layer_norm_tmp.bias"]), 0, _p(self.dy), 1 if have_pix else 0,
-                     _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None)
+                     _p(Gd["layer_norm_tmp.weight"]), _p(Gd["layer_norm_tmp.bias"]), N * L, D, None,
+                     wait=(img_dgrad_key,) if img_dgrad_key else ())
         self._fold_flush(b, "head")              # (inside the heads' gradient bucket: the exchange of a bucket must see its folds)
         # decoder block
         dxdec = self.scr_dxA[:N * L * D]
