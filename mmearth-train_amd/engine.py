@@ -16,6 +16,7 @@ Reference call path reproduced (paths relative to /root/reference):
   backward / optimizer     engine_pretrain.py:87-94, main_pretrain.py:312-320
 """
 import os
+import sys
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -2182,6 +2183,18 @@ class Engine:
         # ... and the forward's own finalisation is dropped: the one in front of the backward computes the same losses / total plus
         # d total / d log_vars (a caller that replays ONLY the forward piece reads its losses through Engine.forward instead)
         fwd += list(self.fwd_ops) + ([] if zs else [fin(False)])
+        defer_exp = os.environ.get("MPMAE_DEFER_EXPERIMENT")      # developer TIMING experiment (results INVALID): the weight-gradient-lane ops whose
+        if defer_exp and bwd_segments is None:                     # names contain one of these substrings run at the FRONT of the step, under the forward
+            pats = [t for t in defer_exp.split(",") if t]
+            moved = [op for op in self.bwd_ops if op[3]["lane"] == 1 and any(t in op[0] for t in pats)]
+            keep = [op for op in self.bwd_ops if not any(op is m for m in moved)]
+            moved = [(n_, f_, a_, dict(m_, wait=(), signal=None)) for n_, f_, a_, m_ in moved]
+            dead = {m_[3]["signal"] for m_ in [op for op in self.bwd_ops if op[3]["lane"] == 1 and any(t in op[0] for t in pats)] if m_[3]["signal"]}
+            keep = [(n_, f_, a_, dict(m_, wait=tuple(w for w in m_["wait"] if w not in dead))) for n_, f_, a_, m_ in keep]
+            front = max(i for i, op in enumerate(fwd[:14]) if op[3]["lane"] == 1)      # behind the side lane's own front (zero fill, weight staging, poolings)
+            fwd = fwd[:front + 1] + moved + fwd[front + 1:]
+            segs = [keep]
+            print(f"[defer experiment] {len(moved)} ops moved under the forward: {[m[0] for m in moved]}", file=sys.stderr)
         zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4),
                  dict(zl, signal="grads_zero") if zs else m0)]
         first = [fin(True)] + list(segs[0])
