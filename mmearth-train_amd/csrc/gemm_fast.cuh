@@ -38,6 +38,23 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Workgroup -> tile mapping of the 2-D tiled kernels, XCD-aware: the hardware deals workgroup L (x fastest) to XCD L % 8, and the XCDs' L2s
+// are private. With the plain mapping the column tiles of one row tile (which read the SAME rows of A, the large operand of every NT
+// product here) have ids L, L + gx, L + 2 gx ... -> different XCDs and different moments: every one of them pulled its A rows over the fabric
+// (pmc: 254 MB fetched per launch for 45 MB of operands at the decoder / head shapes). Here the j-th workgroup of XCD c takes row tile
+// (j / gy) * 8 + c, column tile j % gy: the gy column tiles of a row tile run back to back on ONE XCD and share its L2. (The last gx % 8 row
+// tiles keep the plain order.)
+__device__ __forceinline__ void xcd_tile(int& mt, int& nt) {
+  const int gx = gridDim.x, gy = gridDim.y, L = blockIdx.x + blockIdx.y * gx, gxm = gx & ~7;
+  if (L < gxm * gy) {
+    const int c = L & 7, j = L >> 3;
+    mt = (j / gy) * 8 + c; nt = j - (j / gy) * gy;
+  } else {
+    const int t = L - gxm * gy;
+    mt = gxm + t / gy; nt = t - (t / gy) * gy;
+  }
+}
+
 template <int BN, int EPI, int BK = FBK, bool GLDS = false>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
   constexpr int LDK = GLDS ? BK : BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
@@ -52,7 +69,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * FBM, n0 = blockIdx.y * BN;
+  int mt, nt;
+  xcd_tile(mt, nt);
+  const int m0 = mt * FBM, n0 = nt * BN;
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
   const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
 
@@ -316,8 +335,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
     for (int c = tid; c < nq * BN; c += 256) {
       const int q = c / BN, cc = c - q * BN;
       if (n0 + cc < p.N) {
-        p.ws[((size_t)blockIdx.x * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 0) * BN + cc];
-        if (EPI == EPI_DZ_STATS) p.ws[(((size_t)gridDim.x + blockIdx.x) * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 1) * BN + cc];
+        p.ws[((size_t)mt * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 0) * BN + cc];
+        if (EPI == EPI_DZ_STATS) p.ws[(((size_t)gridDim.x + mt) * nq + q) * p.N + n0 + cc] = colacc[(q * 2 + 1) * BN + cc];
       }
     }
     __syncthreads();
