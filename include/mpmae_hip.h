@@ -379,7 +379,7 @@ enum MpmaeOption {
   MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
   MPMAE_OPT_TN3_BLOCKS,   /* default 128: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2). Re-swept after the matrix-core depthwise kernels rebalanced the lanes: 128 (half the CUs, half the slabs) 3.87-3.88 vs 256 3.91 ms in three interleaved pairs - the weight-gradient lane's kernels leave CUs to the main lane's */
   MPMAE_OPT_TNG_BLOCKS,   /* default 512: target workgroup count of the GROUPED weight-gradient kernel (gemm_tng.cuh; 0 = one mpmae_wgrad per problem) */
-  MPMAE_OPT_NT4,   /* default 1: 256 x 256-tile NT GEMM (gemm_nt4.cuh) for M >= 8192, N = 1024..2048 a multiple of 256, K % 64 == 0 (decoder pwconv1, pwconv2 data gradient); 2 = every shape with M >= 8192, N >= 256 (256 x 128 tiles under N = 1024); 0 = the 128 x 128 kernels */
+  MPMAE_OPT_NT4,   /* default 0 since the 128 x 128 kernel maps its tiles XCD-aware (late round 5: 3.561-3.571 vs 3.586-3.613 ms with 1); 1: 256 x 256-tile NT GEMM (gemm_nt4.cuh) for M >= 8192, N = 1024..2048 a multiple of 256, K % 64 == 0 (decoder pwconv1, pwconv2 data gradient); 2 = every shape with M >= 8192, N >= 256 (256 x 128 tiles under N = 1024); 0 = the 128 x 128 kernels */
   MPMAE_OPT_FOLD_GROUP,   /* default 0: 1 = mpmae_fold_group folds up to 16 records per launch (blockIdx.z = record) instead of one launch per record - measured SLOWER in the step (4.035-4.04 vs 4.005-4.026 ms, three interleaved pairs): the small launches slot in between the weight-gradient lane's kernels, the grouped one waits for all its producers. Round 5: the three folds behind the stem-tail backward kernel (ONE producer, the exposed tail of the step) are one grouped launch unless the value is < 0 */
   MPMAE_OPT_RSC_W5,   /* default 1: 80-row (5-wave) tiles in the narrow fused pointwise kernels at C = 160 when 64-row tiles need more than one round of workgroups and 80-row tiles do not */
   MPMAE_OPT_BLASLT,   /* default 0 (round 5: every GEMM of the default step is this library's own kernel; the vendor route stays as a measured yardstick, tools/probes/blas_yardstick.py). 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */

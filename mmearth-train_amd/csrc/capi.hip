@@ -72,7 +72,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_STB_BLOCKS */ 512,
     /* MPMAE_OPT_TN3_BLOCKS */ 128,
     /* MPMAE_OPT_TNG_BLOCKS */ 512,
-    /* MPMAE_OPT_NT4 */ 1,
+    /* MPMAE_OPT_NT4 */ 0,
     /* MPMAE_OPT_FOLD_GROUP */ 0,
     /* MPMAE_OPT_RSC_W5 */ 1,
     /* MPMAE_OPT_BLASLT */ 0,

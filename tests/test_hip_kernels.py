@@ -335,7 +335,7 @@ def test_direct_to_lds_gemm_matches_torch(M, N, K, resid):
     try:
         assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
     finally:
-        lib.mpmae_set_option(L.OPT["BLASLT"], 1)
+        lib.mpmae_set_option(L.OPT["BLASLT"], 0)      # (the default since round 5)
     ref = a.float() @ w.float().t() + bias + (r.float() if resid else 0)
     assert _rel(c, ref) < 6e-3
 
@@ -364,12 +364,13 @@ def test_256_row_tile_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
     if resid:
         g.R, g.ldr = r.data_ptr(), N
-    assert lib.mpmae_set_option(L.OPT["NT4"], 2) == 0          # every eligible shape (default 1: only the shapes where it measured faster)
+    nt4_0, blas_0 = lib.mpmae_get_option(L.OPT["NT4"]), lib.mpmae_get_option(L.OPT["BLASLT"])
+    assert lib.mpmae_set_option(L.OPT["NT4"], 2) == 0          # every eligible shape (1: only the shapes where it once measured faster; default 0 since round 5)
     assert lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0       # (no vendor route: this test pins gemm_nt4_kernel)
     try:
         assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
     finally:
-        lib.mpmae_set_option(L.OPT["NT4"], 1)
+        lib.mpmae_set_option(L.OPT["NT4"], nt4_0)
     ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
     if act_on:
         ref = ref * act.bool()[:, None]
@@ -382,8 +383,8 @@ def test_256_row_tile_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
     try:
         assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
     finally:
-        lib.mpmae_set_option(L.OPT["NT4"], 1)
-        lib.mpmae_set_option(L.OPT["BLASLT"], 1)
+        lib.mpmae_set_option(L.OPT["NT4"], nt4_0)
+        lib.mpmae_set_option(L.OPT["BLASLT"], blas_0)
     torch.cuda.synchronize()
     d = (c.float() - c2.float()).abs()
     assert (d <= 2.0 ** -7 * c2.float().abs() + 1e-6).all(), float(d.max())      # same operands, fp32 accumulation order differs: <= 1 bf16 ulp
@@ -393,13 +394,13 @@ def test_256_row_tile_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
                                                  (4100, 384, 1408, True, False)])
 def test_vendor_blas_route_for_plain_gemms_matches_torch_and_own_kernels(M, N, K, resid, bias_on):
     """mpmae_gemm bf16, no prologue, epilogue = (+ bias) (+ residual), no row mask, M >= 4096, N K >= 512 Ki: the hipBLASLt route
-    (MPMAE_OPT_BLASLT = 1, the default; capi_gemm.hip: try_blaslt - row-major C = A W^T as the column-major product with op(T) on the
+    (MPMAE_OPT_BLASLT = 1; OFF by default since round 5 - a yardstick; capi_gemm.hip: try_blaslt - row-major C = A W^T as the column-major product with op(T) on the
     weight, fp32 bias through HIPBLASLT_EPILOGUE_BIAS, the residual as C with beta = 1). Against an fp32 matmul of the same bf16 operands
     (6e-3 relative to the tensor), against this library's own kernel on the same operands (one bf16 rounding of an fp32 sum whose order
     differs: <= 1 bf16 ulp), and a row mask must NOT take the route (masked rows come back zero)."""
     L, lib = _lib()
     dev = "cuda"
-    assert lib.mpmae_get_option(L.OPT["BLASLT"]) == 1
+    assert lib.mpmae_get_option(L.OPT["BLASLT"]) == 0      # the default: every kernel of the step is this library's own
     torch.manual_seed(M + N + K)
     a = torch.randn(M, K, device=dev).to(bf)
     w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
@@ -419,7 +420,7 @@ def test_vendor_blas_route_for_plain_gemms_matches_torch_and_own_kernels(M, N, K
         try:
             assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
         finally:
-            lib.mpmae_set_option(L.OPT["BLASLT"], 1)
+            lib.mpmae_set_option(L.OPT["BLASLT"], 0)      # (the default since round 5)
         torch.cuda.synchronize()
         outs.append(c)
     ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
@@ -429,7 +430,11 @@ def test_vendor_blas_route_for_plain_gemms_matches_torch_and_own_kernels(M, N, K
     act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
     c = torch.full((M, N), 7.0, device=dev, dtype=bf)
     g.C, g.act = c.data_ptr(), act.data_ptr()
-    assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+    assert lib.mpmae_set_option(L.OPT["BLASLT"], 1) == 0
+    try:
+        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
+    finally:
+        lib.mpmae_set_option(L.OPT["BLASLT"], 0)
     torch.cuda.synchronize()
     assert (c[~act.bool()] == 0).all() and _rel(c, ref * act.bool()[:, None]) < 6e-3
 
