@@ -38,23 +38,6 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Workgroup -> tile mapping of the 2-D tiled kernels, XCD-aware: the hardware deals workgroup L (x fastest) to XCD L % 8, and the XCDs' L2s
-// are private. With the plain mapping the column tiles of one row tile (which read the SAME rows of A, the large operand of every NT
-// product here) have ids L, L + gx, L + 2 gx ... -> different XCDs and different moments: every one of them pulled its A rows over the fabric
-// (pmc: 254 MB fetched per launch for 45 MB of operands at the decoder / head shapes). Here the j-th workgroup of XCD c takes row tile
-// (j / gy) * 8 + c, column tile j % gy: the gy column tiles of a row tile run back to back on ONE XCD and share its L2. (The last gx % 8 row
-// tiles keep the plain order.)
-__device__ __forceinline__ void xcd_tile(int& mt, int& nt) {
-  const int gx = gridDim.x, gy = gridDim.y, L = blockIdx.x + blockIdx.y * gx, gxm = gx & ~7;
-  if (L < gxm * gy) {
-    const int c = L & 7, j = L >> 3;
-    mt = (j / gy) * 8 + c; nt = j - (j / gy) * gy;
-  } else {
-    const int t = L - gxm * gy;
-    mt = gxm + t / gy; nt = t - (t / gy) * gy;
-  }
-}
-
 template <int BN, int EPI, int BK = FBK, bool GLDS = false>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
   constexpr int LDK = GLDS ? BK : BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
