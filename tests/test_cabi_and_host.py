@@ -209,3 +209,28 @@ def test_bench_multi_rank_dry_run_over_gloo(launcher, n):
     assert sum(d["config"]["buckets"]) == 7580674 and d["config"]["fold_loss"] is True
     for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert k in d, k
+
+
+def test_xcd_tile_order_is_a_permutation_that_keeps_a_row_tile_on_one_xcd():
+    """csrc/common.cuh xcd_tile(): workgroup L (x fastest; the hardware deals it to XCD L % 8) -> (row tile, column tile). The mapping must
+    visit every tile exactly once for any grid, and the column tiles of a row tile below the last gx % 8 row tiles must share one XCD and
+    be consecutive there (they read the same rows of A; round 5: 254 -> 85 MB of fabric fetch per launch at the decoder / head shapes)."""
+    def xcd_tile(L, gx, gy):
+        gxm = gx & ~7
+        if L < gxm * gy:
+            c, j = L & 7, L >> 3
+            return (j // gy) * 8 + c, j % gy
+        t = L - gxm * gy
+        return gxm + t // gy, t % gy
+
+    for gx, gy in ((98, 4), (98, 16), (98, 22), (28, 5), (28, 20), (7, 3), (8, 1), (1, 1), (33, 2), (2432, 2)):
+        tiles = [xcd_tile(L, gx, gy) for L in range(gx * gy)]
+        assert sorted(tiles) == [(m, n) for m in range(gx) for n in range(gy)], (gx, gy)
+        by_row = {}
+        for L, (m, n) in enumerate(tiles):
+            by_row.setdefault(m, []).append((L % 8, L // 8, n))
+        for m, lst in by_row.items():
+            if m < (gx & ~7):
+                assert len({c for c, _, _ in lst}) == 1, (gx, gy, m)                      # one XCD
+                js = sorted(j for _, j, _ in lst)
+                assert js == list(range(js[0], js[0] + gy)), (gx, gy, m)                  # back to back on it
