@@ -180,6 +180,39 @@ def pmc_traffic(family, path):
     return int(tot / n) if n else None
 
 
+def step_traffic(fam_doc, pmc_path):
+    """HBM bytes of ONE step: the committed per-kernel PMC traffic (bytes per launch) x the committed trace's launches per step, summed over
+    every kernel symbol of the step; (bytes, symbols priced, symbols without counters) or None."""
+    if not fam_doc or not pmc_path or not os.path.exists(pmc_path):
+        return None
+    ks = json.load(open(pmc_path))["kernels"]
+    tot, hit, miss = 0.0, 0, 0
+    for fam in fam_doc["families"].values():
+        for name, (_, per_step) in fam["kernels"].items():
+            d = next((v for k, v in ks.items() if k.startswith(name)), None)
+            if d is None:
+                miss += 1
+                continue
+            hit += 1
+            tot += d["traffic_bytes"] * per_step
+    return (int(tot), hit, miss) if hit else None
+
+
+def family_fracs(fams, in_step, min_share=0.03):
+    """Roofline fraction of EVERY kernel family with >= min_share of the step's kernel time: max(flops / MFMA peak, algorithmic bytes / HBM
+    peak) of the family's ops in one step (live launch program's own counts) / its in-step kernel time (committed trace, folds included)."""
+    out = {}
+    for k, f in fams.items():
+        t = in_step.get(k)
+        if not t or t["us_per_step"] <= 0 or t.get("share_of_kernel_time", 0) < min_share or not (f["bytes"] or f["flops"]):
+            continue
+        b, fl = f["bytes"] / 3, f["flops"] / 3                        # (per_kernel_times runs 3 eager passes)
+        roof_us = max(fl / MFMA_PEAK_TFS / 1e12, b / HBM_PEAK_GBS / 1e9) * 1e6
+        out[k] = dict(us_per_step=t["us_per_step"], share_of_kernel_time=t["share_of_kernel_time"], algorithmic_bytes_per_step=int(b),
+                      algorithmic_flops_per_step=int(fl), roofline_us=round(roof_us, 1), frac=round(roof_us / t["us_per_step"], 4))
+    return out
+
+
 def cpu_baseline(cfg, batches, steps, warm=3, threads=None):
     """Oracle (CPU restatement, kind 'port') forward+backward+AdamW on the host cores: `warm` warm-up + `steps` timed fp32 steps
     per batch size (bs 4 and bs 32, 3 + 5). `value` is the best batch size's images/sec."""
@@ -339,7 +372,7 @@ def dry_run(a):
                    dtype=a.dtype, data="synthetic (dry run: no kernels, host stand-ins for the launches)",
                    config=dict(workload=f"{a.subset} {a.model.replace('convnextv2_', '')} {a.img}x{a.img} patch{a.patch} DRY RUN over gloo",
                                per_gpu_batch=batch, global_batch=batch * world, parallelism=f"dp{world}", graph="eager",
-                               buckets=[hi - lo for lo, hi in buckets], fold_loss=bool(trainer.fold_loss)),
+                               buckets=[hi - lo for lo, hi in buckets], fold_loss=bool(trainer.fold_loss), options=real.nondefault_options()),
                    roofline=None, vendor_kernels_per_step=0.0, per_rank_ms_per_step=[round(t / a.steps * 1e3, 4) for t in per_rank],
                    exposed_comm_tail_ms=0.0)
         print(json.dumps(out), flush=True)
@@ -365,6 +398,13 @@ def _spawn_ranks(a, need_gpus=True):
 
 def main():
     a = parse()
+    # bench integrity: the timing-experiment variables of earlier rounds silenced / re-ordered ops inside the product engine;
+    # they are gone from it (tools/timing_experiment.py patches its own process and stamps the line), and a box that still exports them is refused
+    stale = [k for k in ("MPMAE_SKIP_OPS", "MPMAE_DEFER_EXPERIMENT") if os.environ.get(k)]
+    if stale:
+        print(f"bench.py: refusing to run with {stale} set (timing experiments produce INVALID results: use tools/timing_experiment.py)",
+              file=sys.stderr, flush=True)
+        sys.exit(3)
     if a.dry_run:
         return dry_run(a)
     if a.cpu_baseline_only:
@@ -387,6 +427,12 @@ def main():
     cfg = make_cfg(a.model, a.img, a.patch, out_modalities=M.subset(a.subset))
     eng = Engine(cfg, a.batch, dtype=a.dtype, device=dev, block_mode=a.block_mode)
     eng.load_state_dict(make_state_dict(cfg, seed=0))
+    options = eng.nondefault_options()
+    import mmearth_train_amd.engine as _E
+    if getattr(_E, "TIMING_EXPERIMENT", None):
+        options["TIMING_EXPERIMENT_INVALID"] = _E.TIMING_EXPERIMENT
+    if os.environ.get("MPMAE_LIB"):
+        options["MPMAE_LIB"] = os.environ["MPMAE_LIB"]
     inputs, noise = make_inputs(cfg, a.batch, seed=1000 + rank)
     eng.set_inputs(inputs, noise)
     torch.cuda.synchronize()
@@ -524,6 +570,20 @@ def main():
         if traffic is not None:
             roof["traffic_source"] = (f"{os.path.relpath(pmc_path, os.path.dirname(os.path.abspath(__file__)))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                       f"passes; commit {pmc_doc.get('meta', {}).get('commit', 'n/a')})")
+        if fam_doc:
+            # the WORST family beside the largest one (the depthwise weight gradient sat at 0.07 while the line priced `rs`)
+            ff = family_fracs(fams, in_step)
+            if ff:
+                worst = min(ff, key=lambda k: ff[k]["frac"])
+                roof["families"] = {k: v["frac"] for k, v in sorted(ff.items(), key=lambda kv: kv[1]["frac"])}
+                roof["worst_family"] = dict(kernel=worst, kernel_symbols=list(FAMILY_SYMBOLS.get(worst, ())), **ff[worst])
+            roof["launches_per_step"] = fam_doc["meta"].get("launches_per_step")
+            st = step_traffic(fam_doc, pmc_path)
+            if st:
+                roof["step_traffic_bytes"] = st[0]
+                roof["step_traffic_note"] = (f"sum over {st[1]} kernel symbols of PMC bytes per launch x launches per step (committed trace + counters)"
+                                             + (f"; {st[2]} symbols without counters" if st[2] else ""))
+        roof["ops_per_step"] = len(eng.fwd_ops) + len(eng.bwd_ops) + 3      # live: C-ABI ops of the recorded step (+ finalisation, hp_fetch, AdamW)
         if step_roof and a.batch == 256:
             roof["step_roofline_us"] = step_roof
             roof["step_frac"] = round(step_roof / (ms_per_step * 1e3), 4)
@@ -554,6 +614,9 @@ def main():
                                         f"mask0.6 uncertainty loss, fwd+loss+bwd+allreduce+AdamW",
                                per_gpu_batch=a.batch, global_batch=a.batch * world,
                                parallelism=f"dp{world}", graph=trainer.graph_mode, final_loss=round(loss, 4),
+                               # every engine / library switch that is NOT at its default ({} and {} on a clean run), and the stamp of a
+                               # timing experiment (tools/timing_experiment.py): a faster, wrong headline cannot appear without a trace
+                               options=options,
                                input_stage="outside the timed region of `value` (inputs and mask noise resident in HBM); "
                                            "ms_per_step_with_input_stage includes the D2D batch copy and device randn of every step, issued on an input stream "
                                            "behind the previous step's last reader of the input buffers (Engine.set_inputs_async)"),

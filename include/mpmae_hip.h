@@ -443,7 +443,8 @@ int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, co
                            float* dbeta, mpmae_stream_t stream);
 /* mpmae_grn_fwd_finalize + mpmae_grn_apply, and mpmae_grn_bwd_finalize + mpmae_grn_bwd_apply, as ONE launch each (round 5; single GRN group):
  * every workgroup recomputes the H-vector from the column sums in its prologue, workgroup 0 publishes Gx / Ainv / scale (coef, and adds the
- * GRN gamma / beta gradients). Same outputs as the two-launch forms. */
+ * GRN gamma / beta gradients). Same outputs as the two-launch forms. H % 8 == 0 and H <= 8160 (two H-vectors in the default 64 KiB of LDS beside
+ * the reduction scratch), else hipErrorInvalidValue. */
 int mpmae_grn_apply_fin(int dt, const void* h, void* z, const float* G2, const float* gamma, const float* beta, float eps, int M, int H,
                         const uint8_t* act, float* Gx, float* Ainv, float* scale, mpmae_stream_t stream);
 int mpmae_grn_bwd_apply_fin(int dt, void* dz, const void* h, const float* scale, const float* S0, const float* S1, const float* Gx,
@@ -531,8 +532,9 @@ int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N,
  * categorical twin (softmax - onehot at masked, labelled pixels). */
 int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int N, int maxC, int p, int H,
                                    mpmae_stream_t stream);
-/* B [D][ldb] (staged transposed head weights, storage type dt): column k *= coef[col_mod[k]] in place; rowscale[k] = coef[col_mod[k]]. */
-int mpmae_head_scale(int dt, void* B, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale,
+/* B [D][ldb] (staged transposed head weights, storage type dt): Bout[:, k] = B[:, k] * coef[col_mod[k]]; rowscale[k] = coef[col_mod[k]].
+ * Bout == B is allowed (in place) - the engine passes a buffer of its own so that a backward can be repeated behind one forward. */
+int mpmae_head_scale(int dt, const void* B, void* Bout, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale,
                      mpmae_stream_t stream);
 /* Row-split form (round 5) of mpmae_loss_pix_cont_rows (mode 0) / _fused (mode 2): `parts` workgroups per sample, each walking
  * ceil(grid / parts) patch rows; every record's `acc` must hold N * parts {sum, count} slots (slot n * parts + part) and the finalisation

@@ -223,7 +223,7 @@ SYMBOLS = {
     "mpmae_loss_pix_cont_rows_bwd": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_fused": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_split": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "mpmae_head_scale": [c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_head_scale": [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                             c_void_p, c_void_p],
@@ -262,6 +262,7 @@ OTHER_SYMBOLS = {
 }
 
 _lib = None
+OPT_DEFAULTS = {}            # filled by load(): the library's built-in option values
 
 
 class HipLibraryError(RuntimeError):
@@ -292,8 +293,15 @@ def load():
         fn.restype = restype
     if lib.mpmae_arch() != 950:
         raise HipLibraryError("libmpmae_hip.so was not built for gfx950")
+    OPT_DEFAULTS.update({n: int(lib.mpmae_get_option(i)) for n, i in OPT.items()})      # a fresh library: every switch at its built-in default
     _lib = lib
     return lib
+
+
+def nondefault_options():
+    """Library switches (mpmae_set_option) that differ from the built-in defaults right now: {} on a clean process. bench.py prints them."""
+    lib = load()
+    return {n: int(lib.mpmae_get_option(i)) for n, i in OPT.items() if int(lib.mpmae_get_option(i)) != OPT_DEFAULTS[n]}
 
 
 def check(err: int, what: str):

@@ -925,11 +925,11 @@ int mpmae_gather_kxk(int dt, const float* img, const int* vis, const int* inv, v
   RET();
 }
 
-int mpmae_head_scale(int dt, void* B, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale, mpmae_stream_t s) {
-  if (!B || !col_mod || !coef || !rowscale || D < 1 || W < 1 || ldb < W) return (int)hipErrorInvalidValue;
+int mpmae_head_scale(int dt, const void* B, void* Bout, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale, mpmae_stream_t s) {
+  if (!B || !Bout || !col_mod || !coef || !rowscale || D < 1 || W < 1 || ldb < W) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)D * W, 256, 2048);
-  if (dt == 0) LAUNCH(head_scale_kernel<float>, dim3(g), dim3(256), 0, S_(s), (float*)B, ldb, D, W, col_mod, coef, rowscale);
-  else LAUNCH(head_scale_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (bf16_t*)B, ldb, D, W, col_mod, coef, rowscale);
+  if (dt == 0) LAUNCH(head_scale_kernel<float>, dim3(g), dim3(256), 0, S_(s), (const float*)B, (float*)Bout, ldb, D, W, col_mod, coef, rowscale);
+  else LAUNCH(head_scale_kernel<bf16_t>, dim3(g), dim3(256), 0, S_(s), (const bf16_t*)B, (bf16_t*)Bout, ldb, D, W, col_mod, coef, rowscale);
   RET();
 }
 

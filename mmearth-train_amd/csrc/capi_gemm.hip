@@ -721,9 +721,11 @@ int mpmae_grn_bwd_apply(int dt, void* dz, const void* h, const float* scale, con
   RET();
 }
 
+// 2 * H floats of dynamic LDS beside the kernels' static reduction scratch, inside the default 64 KiB (no hipFuncSetAttribute): H <= 8160
+#define MPMAE_GRN_FIN_MAXH 8160
 int mpmae_grn_apply_fin(int dt, const void* h, void* z, const float* G2, const float* gamma, const float* beta, float eps, int M, int H,
                         const uint8_t* act, float* Gx, float* Ainv, float* scale, mpmae_stream_t s) {
-  if ((H & 7) || H > 8192 || !G2 || !gamma || !beta || !Gx || !Ainv || !scale) return (int)hipErrorInvalidValue;
+  if ((H & 7) || H > MPMAE_GRN_FIN_MAXH || !G2 || !gamma || !beta || !Gx || !Ainv || !scale) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)M * H / 8, 256, 2048);
   const size_t lds = (size_t)2 * H * 4;
   if (dt == 0) LAUNCH(grn_apply_fin_kernel<float>, dim3(g), dim3(256), lds, S_(s), (const float*)h, (float*)z, G2, gamma, beta, eps, M, H, act, Gx, Ainv, scale);
@@ -733,7 +735,7 @@ int mpmae_grn_apply_fin(int dt, const void* h, void* z, const float* G2, const f
 
 int mpmae_grn_bwd_apply_fin(int dt, void* dz, const void* h, const float* scale, const float* S0, const float* S1, const float* Gx,
                             const float* Ainv, const float* gamma, int M, int H, float* coef, float* dgamma, float* dbeta, mpmae_stream_t s) {
-  if ((H & 7) || H > 8192 || !scale || !S0 || !S1 || !Gx || !Ainv || !gamma || !coef || !dgamma || !dbeta) return (int)hipErrorInvalidValue;
+  if ((H & 7) || H > MPMAE_GRN_FIN_MAXH || !scale || !S0 || !S1 || !Gx || !Ainv || !gamma || !coef || !dgamma || !dbeta) return (int)hipErrorInvalidValue;
   const int g = grid1d((long long)M * H / 8, 256, 2048);
   const size_t lds = (size_t)2 * H * 4;
   if (dt == 0) LAUNCH(grn_bwd_apply_fin_kernel<float>, dim3(g), dim3(256), lds, S_(s), (float*)dz, (const float*)h, scale, S0, S1, Gx, Ainv, gamma, M, H, coef, dgamma, dbeta);

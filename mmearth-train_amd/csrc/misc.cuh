@@ -416,14 +416,13 @@ __global__ __launch_bounds__(256) void reduce_partials_rowscale_kernel(const flo
 // coef[col_mod[k]] in place (the data-gradient GEMM then computes sum_t coef_t dpred_t W_t); rs[k] = the same scalar per prediction
 // column = per ROW of the heads' weight gradient (MpmaeWgradArgs.rowscale).
 template <typename T>
-__global__ __launch_bounds__(256) void head_scale_kernel(T* __restrict__ B, int ldb, int D, int W, const uint8_t* __restrict__ col_mod,
+__global__ __launch_bounds__(256) void head_scale_kernel(const T* B, T* Bout, int ldb, int D, int W, const uint8_t* __restrict__ col_mod,
                                                          const float* __restrict__ coef, float* __restrict__ rs) {
   const int total = D * W;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int r = i / W, k = i - r * W;
     const float c = coef[col_mod[k]];
-    T* q = B + (size_t)r * ldb + k;
-    stf<T>(q, ldf<T>(q) * c);
+    stf<T>(Bout + (size_t)r * ldb + k, ldf<T>(B + (size_t)r * ldb + k) * c);
     if (r == 0) rs[k] = c;
   }
 }

@@ -15,6 +15,7 @@ Reference call path reproduced (paths relative to /root/reference):
   forward_loss             models/fcmae.py:267-412, custom_loss.py:19-30
   backward / optimizer     engine_pretrain.py:87-94, main_pretrain.py:312-320
 """
+import contextlib
 import os
 import sys
 import ctypes as C
@@ -129,7 +130,8 @@ class Engine:
         # DET is a process-wide library switch read while THIS engine's launches are built / recorded: set it from this engine's option
         # every time (an earlier det = 1 engine of the process must not leave later engines on the slower ordered folds);
         # a developer override MPMAE_ENGINE_OPTS="DET=..." (A/B of the shared-row behaviour, -1) is kept
-        if "DET=" not in os.environ.get("MPMAE_ENGINE_OPTS", ""):
+        self._det_env = "DET=" in os.environ.get("MPMAE_ENGINE_OPTS", "")
+        if not self._det_env:
             _lib.check(self.lib.mpmae_set_option(_lib.OPT["DET"], 1 if self.opt["det"] else 0), "set_option DET")
         self.cfg = cfg
         self.N = N = int(batch_size)
@@ -562,9 +564,6 @@ class Engine:
         lane 0 = main dependency chain, lane 1 = side HIP stream (weight gradients); `wait` /
         `signal` are event keys ordering the two lanes (see _run)."""
         kname = kind or fn.__name__
-        skip = os.environ.get("MPMAE_SKIP_OPS")          # developer timing experiment (results INVALID): ops whose name contains one of these
-        if skip and any(t and t in name for t in skip.split(",")):      # comma-separated substrings launch nothing (events / waits stay)
-            fn, args = (lambda *a: 0), ()
         lst.append((name, fn, args, dict(kind=kname, bytes=int(nbytes), flops=int(flops), lane=lane,
                                          wait=tuple(wait), signal=signal)))
 
@@ -950,7 +949,7 @@ class Engine:
                      _p(P[nm["gb"]]), eps, M, H, rpg, _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]),
                      kind="grn_group_fwd", nbytes=2 * M * H * esz)
         afin = blk["afin"] = (not fold and not gg and rs_n != "fused" and G == 1 and blk["sparse"] and bool(self.opt["grn_apply_fin"])
-                              and not self._mx_block(blk) and H % 8 == 0 and H <= 8192)
+                              and not self._mx_block(blk) and H % 8 == 0 and H <= 8160)
         if gg or afin:
             pass
         elif not fold:
@@ -1649,8 +1648,11 @@ class Engine:
                     cm[c0:c0 + om.head_out] = t
             self.head_col_mod = cm.to(self.device)
             self.head_rs = torch.zeros(self.Wpix, dtype=torch.float32, device=self.device)
+            # OUT of place: the staged copy is only rewritten by the forward's weight staging, so a second backward behind one forward
+            # (retain_graph, the backward-only span replays of tools/) must not compound the scalars into it
             wt_ = self.w["head.pixT"]
-            self._op(b, "head:scale", lib.mpmae_head_scale, dt, _p(wt_["t"]), wt_["ld"], D, self.Wpix, _p(self.head_col_mod), _p(self.coef),
+            self.head_pixT_scaled = torch.zeros_like(wt_["t"])
+            self._op(b, "head:scale", lib.mpmae_head_scale, dt, _p(wt_["t"]), _p(self.head_pixT_scaled), wt_["ld"], D, self.Wpix, _p(self.head_col_mod), _p(self.coef),
                      _p(self.head_rs), kind="head_scale", nbytes=2 * D * self.Wpix * 2)
         if self.loss_multi:
             # (the categorical losses on the side lane next to the continuous ones, forward and gradient: 4.99 vs 4.97 ms, not kept)
@@ -1715,7 +1717,7 @@ class Engine:
         have_pix = bool(cfg.pix_mods)
         if have_pix:
             wt = self.w["head.pixT"]
-            self._gemm(b, "head:pix.dgrad", "NONE", "STORE", A=self.dpred_pix, B=wt["t"], C=self.dy, M=N * L, N=D,
+            self._gemm(b, "head:pix.dgrad", "NONE", "STORE", A=self.dpred_pix, B=self.head_pixT_scaled if self.loss_onepass else wt["t"], C=self.dy, M=N * L, N=D,
                        K=self.Wpix, lda=ldp, ldb=wt["ld"], ldc=D)
         if cfg.img_mods:
             if contiguous(cfg.img_mods, "weight") and contiguous(cfg.img_mods, "bias"):
@@ -1896,10 +1898,41 @@ class Engine:
             self._inputs_free_key = b[-1][3]["signal"]
 
     # ------------------------------------------------------------------ execution
+    def nondefault_options(self):
+        """Every switch of this engine's step that is not at its measured-best default: {"engine": {...}, "library": {...}}, both empty on a
+        clean run. bench.py prints it in the JSON line (config.options), so that a stray MPMAE_ENGINE_OPTS on a box leaves a trace."""
+        eng = {k: v for k, v in self.opt.items() if ENGINE_OPTIONS.get(k) != v}
+        if self.opt["det"] and eng.get("ps") == 0:      # (implied by det = 1, not a switch of its own)
+            eng.pop("ps")
+        lib = _lib.nondefault_options()
+        if self.opt["det"] and lib.get("DET") == 1:
+            lib.pop("DET")
+        return dict(engine=eng, library=lib)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    @contextlib.contextmanager
+    def _det_scope(self):
+        """DET is a process-wide library switch read when a launch is ISSUED or RECORDED: every eager run and every program recording of this
+        engine sets it from the engine's own `det` option and puts the previous value back (a det = 0 engine built after a det = 1
+        engine must not flip the first one's later eager launches to unordered folds). A developer override MPMAE_ENGINE_OPTS="DET=..." wins."""
+        i, want = _lib.OPT["DET"], (1 if self.opt["det"] else 0)
+        old = int(self.lib.mpmae_get_option(i))
+        if self._det_env or old == want:
+            yield
+            return
+        _lib.check(self.lib.mpmae_set_option(i, want), "set_option DET")
+        try:
+            yield
+        finally:
+            self.lib.mpmae_set_option(i, old)
+
     def _run(self, ops, stream=None):
+        with self._det_scope():
+            return self._run_ops(ops, stream)
+
+    def _run_ops(self, ops, stream=None):
         """Enqueue a launch program. Lane-1 ops (weight gradients) go to a side HIP stream forked
         from the current stream and ordered by events; the side stream is joined at the end, so a
         program is self-contained (and capturable into one HIP graph with parallel branches)."""
@@ -2066,6 +2099,8 @@ class Engine:
             self.loss_acc.zero_()
         elif which == "encoder":
             self.stats.zero_()
+            if hasattr(self, "ps_sync"):
+                self.ps_sync[:, 2].zero_()      # (as in Engine.forward: an eager encoder pass starts with clean grid-barrier error words)
         self._run(ops, self._stream())
         if which == "loss":
             self.finalize_loss(self._stream(), False, 1.0)
@@ -2183,18 +2218,6 @@ class Engine:
         # ... and the forward's own finalisation is dropped: the one in front of the backward computes the same losses / total plus
         # d total / d log_vars (a caller that replays ONLY the forward piece reads its losses through Engine.forward instead)
         fwd += list(self.fwd_ops) + ([] if zs else [fin(False)])
-        defer_exp = os.environ.get("MPMAE_DEFER_EXPERIMENT")      # developer TIMING experiment (results INVALID): the weight-gradient-lane ops whose
-        if defer_exp and bwd_segments is None:                     # names contain one of these substrings run at the FRONT of the step, under the forward
-            pats = [t for t in defer_exp.split(",") if t]
-            moved = [op for op in self.bwd_ops if op[3]["lane"] == 1 and any(t in op[0] for t in pats)]
-            keep = [op for op in self.bwd_ops if not any(op is m for m in moved)]
-            moved = [(n_, f_, a_, dict(m_, wait=(), signal=None)) for n_, f_, a_, m_ in moved]
-            dead = {m_[3]["signal"] for m_ in [op for op in self.bwd_ops if op[3]["lane"] == 1 and any(t in op[0] for t in pats)] if m_[3]["signal"]}
-            keep = [(n_, f_, a_, dict(m_, wait=tuple(w for w in m_["wait"] if w not in dead))) for n_, f_, a_, m_ in keep]
-            front = max(i for i, op in enumerate(fwd[:14]) if op[3]["lane"] == 1)      # behind the side lane's own front (zero fill, weight staging, poolings)
-            fwd = fwd[:front + 1] + moved + fwd[front + 1:]
-            segs = [keep]
-            print(f"[defer experiment] {len(moved)} ops moved under the forward: {[m[0] for m in moved]}", file=sys.stderr)
         zero = [("grads.zero", lib.mpmae_memset_async, (_p(self.gflat), 0, self.gflat.numel() * 4),
                  dict(zl, signal="grads_zero") if zs else m0)]
         first = [fin(True)] + list(segs[0])
@@ -2282,6 +2305,8 @@ class Engine:
         lib = self.lib
         prog = C.c_void_p(lib.mpmae_program_create())
         ids, spans, n = {}, [], 0
+        det = self._det_scope()
+        det.__enter__()
         try:
             for piece in pieces:
                 spans.append((n, len(piece)))
@@ -2294,6 +2319,7 @@ class Engine:
                     n += 1
         finally:
             err = lib.mpmae_program_end(prog)
+            det.__exit__(None, None, None)
         _lib.check(err, "program_end")
         assert lib.mpmae_program_num_ops(prog) == n
         self._programs = getattr(self, "_programs", []) + [prog]
@@ -2306,6 +2332,10 @@ class Engine:
     def forward(self, loss_scale: float = 1.0):
         st = self._stream()
         self.stats.zero_()
+        if hasattr(self, "ps_sync"):
+            # the grid-barrier error words are consumed (and cleared) by hp_fetch, i.e. by an optimizer step: a forward-only / eval caller would
+            # keep reading total = +inf after ONE timeout although its own forwards completed - an eager forward starts clean
+            self.ps_sync[:, 2].zero_()
         self._run(self.fwd_ops, st)
         self.finalize_loss(st, False, loss_scale)
         self._loss_scale = float(loss_scale)

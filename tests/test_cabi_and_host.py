@@ -209,6 +209,27 @@ def test_bench_multi_rank_dry_run_over_gloo(launcher, n):
     assert sum(d["config"]["buckets"]) == 7580674 and d["config"]["fold_loss"] is True
     for k in ("metric", "value", "unit", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline"):
         assert k in d, k
+    assert d["config"]["options"] == {"engine": {}, "library": {}}      # a clean run: every engine / library switch at its default
+
+
+def test_bench_refuses_timing_experiment_variables_and_stamps_options():
+    """the timing hooks are out of Engine (tools/timing_experiment.py patches its own process); bench.py exits non-zero
+    when a box still exports their old variables, and prints every non-default switch in config.options."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "MPMAE_ENGINE_OPTS")}
+    for var in ("MPMAE_SKIP_OPS", "MPMAE_DEFER_EXPERIMENT"):
+        r = subprocess.run([sys.executable, bench, "--dry-run", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600,
+                           cwd=ROOT, env=dict(base, **{var: ".wgrad"}))
+        assert r.returncode == 3 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT, env=dict(base, MPMAE_ENGINE_OPTS="tail_main=0,TN3_BLOCKS=64"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["config"]["options"] == {"engine": {"tail_main": 0}, "library": {"TN3_BLOCKS": 64}}
+    src = open(os.path.join(ROOT, "mmearth-train_amd", "engine.py")).read()
+    assert "MPMAE_SKIP_OPS" not in src and "MPMAE_DEFER_EXPERIMENT" not in src
 
 
 def test_xcd_tile_order_is_a_permutation_that_keeps_a_row_tile_on_one_xcd():

@@ -604,3 +604,29 @@ def test_rccl_two_gpus_ranks_agree_and_bench_runs(tmp_path):
     assert b.returncode == 0, b.stdout[-2000:] + b.stderr[-2000:]
     line = json.loads(b.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and len(line["per_rank_ms_per_step"]) == 2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_backward_is_repeatable_behind_one_forward(dtype):
+    """with the one-pass pixel losses the per-modality scalars go into the heads' data-gradient weights; scaled IN PLACE a second
+    backward behind the same forward compounded them (wrong dy and every encoder / decoder gradient, silently). The scaled copy is a
+    buffer of its own now: two backwards give the same gradients, and the staged weights are untouched."""
+    c = CASES["allmod_atto_56"]
+    cfg = case_cfg(c)
+    sd, inputs, noise = case_data(c, cfg)
+    eng = _engine(cfg, c["N"], dtype, sd, inputs, noise)
+    eng.forward()
+    staged = eng.w["head.pixT"]["t"].clone()
+    eng.backward()
+    torch.cuda.synchronize()
+    g1 = eng.gflat.clone()
+    eng.backward()
+    torch.cuda.synchronize()
+    g2 = eng.gflat.clone()
+    assert torch.equal(eng.w["head.pixT"]["t"], staged)
+    assert g1.abs().max().item() > 0
+    # (the default program is not bit-reproducible run to run - float atomics in the statistics folds - so compare at the noise floor)
+    tol = 1e-5 if dtype == "f32" else 2e-2
+    assert (g1 - g2).abs().max().item() <= tol * g1.abs().max().item(), (g1 - g2).abs().max().item() / g1.abs().max().item()
+    k = "encoder.stages.0.0.pwconv1.linear.weight"
+    assert _rel(eng.grads[k], g1[eng.offsets[k][0]:eng.offsets[k][0] + eng.offsets[k][1]].view_as(eng.grads[k])) <= tol
