@@ -573,13 +573,16 @@ def test_meter_records_the_rank_mean_loss_and_a_barrier_timeout_skips_the_update
     assert not torch.equal(eng.pflat, before) and eng.hp[5].item() == 1 and eng.hp[6].item() == 1
     # ... and the skip is COLLECTIVE: the loss finalisation of the timed-out rank writes +inf as its total, which is what the data-parallel
     # exchange all-reduces into every rank's guard loss
-    eng.ps_sync[0, 2] = 1
     eng.forward()
+    eng.ps_sync[0, 2] = 1                       # (a barrier of THIS forward timed out: the word is set by the kernel, i.e. behind the forward's start)
+    eng.finalize_loss(eng._stream(), False, 1.0)
     torch.cuda.synchronize()
     assert math.isinf(eng.total.item()) and eng.total.item() > 0
-    eng.ps_sync[0, 2] = 0
+    # the word is only consumed by an optimizer launch; a forward-only / eval caller must not keep reading +inf for forwards that
+    # completed - an eager forward starts with clean error words
     eng.forward()
     torch.cuda.synchronize()
+    assert int(eng.ps_sync[:, 2].sum()) == 0
     assert math.isfinite(eng.total.item()) and abs(eng.total.item() - L) <= 0.2 * abs(L)      # (two lr = 1e-5 updates lie between the two)
 
 
