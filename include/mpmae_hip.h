@@ -144,6 +144,12 @@ typedef struct MpmaeImgArgs {
  *   which = 1: dz = dout W2 and (sum dz, sum dz*gelu(h))                        (pwconv2 data grad)
  *   which = 4: z = gelu(h)*scale + beta (stored to xn), out = x + z W2^T + b2    (GRN apply + pwconv2)
  *   which = 5: dh = (dz*scale + coef*gelu(h))*gelu'(h) stored OVER dz (= A), then dd = LayerNorm-backward(dh W1), dgamma, dbeta
+ *   which = 6 (round 6; C = 40 / 80): T[C][H] += dout^T gelu(h), db2[C] += sum_rows dout - the pwconv2 weight gradient BEFORE the GRN affine, in
+ *              one read of A = dout [M,C] and R = h [M,H] (csrc/rst.cuh), ws >= workgroups * (C*H + C) floats. Every consumer is linear in T:
+ *              with W = staged pwconv2 weights [C][ldw], v0 = GRN scale [H], v1 = GRN beta [H] the slab fold adds S0[j] += sum_c W[c][j] db2[c],
+ *              S1[j] += sum_c W[c][j] T[c][j] into s0 / s1 and the parameter gradients dW2[c][j] += v0[j] T[c][j] + v1[j] db2[c], db2 into
+ *              fin_dgamma [C][H] / fin_dbeta [C] - the statistics pass (which = 1, out = NULL) AND the separate weight-gradient product over the same
+ *              two tensors both go away. With W == NULL: s0 = T, s1 = db2 raw (added to), mpmae_grn_stats_from_wgrad as a separate second step
  *   (which = 2 / 3 - pwconv2 / pwconv1 data gradient on MATERIALISED z / dh, the resident-weights kernels of rounds 1-3 - were
  *   removed in round 4: invalid value)
  * C in {40,80,96,160,192,320,384}: weights streamed through LDS in chunks (csrc/rsc.cuh), any M;
@@ -185,8 +191,18 @@ typedef struct MpmaeRsArgs {
   /* Optional (which = 0, C = 160 / 320): A already IS the LayerNorm output xn (stored by mpmae_dwln_fwd) - no LayerNorm here, x-hat / rstd / xn
    * are not written: h = A W1^T + b1 and the GELU^2 column sums only. */
   int ln_done;
+  /* Optional (which = 5 at C = 40 with dz_dout set; round 6): pwconv1's weight gradient INSIDE the fused backward kernel. By linearity
+   * dW1 = dh^T (x-hat * gamma + beta) = gamma[c] * (dh^T x-hat)[j][c] + beta[c] * db1[j]; dh and x-hat are both in the kernel's registers, so every
+   * persistent workgroup accumulates U = dh^T x-hat and db1 = sum_rows dh over its row tiles (transposing LDS reads, MFMA) and writes ONE fp32 slab
+   * row [H * C | H] to wg_ws; *wg_rows (HOST memory) receives the number of rows written. dh is then NOT stored (A is untouched), and neither
+   * pwconv1's transpose-read product over dh and xn nor the forward's xn store is needed. mpmae_rs_wgrad_fold folds the slab rows into the
+   * parameter gradients. wg_ws_floats >= workgroups * (H * C + H) (2 workgroups per CU). */
+  float* wg_ws; size_t wg_ws_floats; int* wg_rows;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
+/* Second stage of MpmaeRsArgs.wg_ws: dW1[j][c] += ln_gamma[c] * sum_p U_p[j][c] + ln_beta[c] * sum_p d_p[j]; db1[j] += sum_p d_p[j] over the `rows` slab rows
+ * [H * C | H] (H = 4C) of `slabs`; dW1 is pwconv1's weight gradient [H][C] (convnextv2_sparse.py:41 under autograd), C = 40. */
+int mpmae_rs_wgrad_fold(int C, const float* slabs, int rows, const float* ln_gamma, const float* ln_beta, float* dW1, float* db1, mpmae_stream_t stream);
 int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t stream);
 
 /* ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------------
@@ -398,6 +414,8 @@ enum MpmaeOption {
   MPMAE_OPT_RSP_NARROW,   /* default 2: which NARROW launches take the persistent burst-load kernels: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80 (measured: only which 5 at C = 40 gains, 88.6 -> 70 us) */
   MPMAE_OPT_RSN3,   /* default 5: the fused pointwise BACKWARD kernel at C = 160 (mpmae_rs which = 5, single GRN group, dz materialised) in its ring-pipelined form (csrc/rsn3.cuh: weight slabs by DMA into a three-slot LDS ring, rows two chunks ahead, one bare barrier per chunk); value = waves per workgroup (4 or 5); 0 = rsc_narrow */
   MPMAE_OPT_EVX,   /* default 1: in a launch program an op's cross-lane signal is the completion event of its last kernel launch (hipExtLaunchKernelGGL stopEvent) instead of a hipEventRecord - a barrier packet of its own - behind it: 1.65 us less per signal on the signalling lane (tools/probes/ext_event_probe.hip); 0 = hipEventRecord */
+  MPMAE_OPT_RST_WGS,   /* default 0 = 1 per CU with 16 waves (with 4 waves: 3 per CU at C = 40, 2 per CU at C = 80): persistent workgroups of the weight-gradient-as-statistics pass (mpmae_rs which = 6, csrc/rst.cuh); one fp32 slab row [C * H + C] each */
+  MPMAE_OPT_RST_NW,   /* default 16: waves per workgroup of that pass (16: 1024 threads, 256-row tiles, one workgroup per CU - a quarter of the slab rows; 4: 256 threads, 64-row tiles, 2-3 per CU) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

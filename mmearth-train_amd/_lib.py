@@ -103,7 +103,8 @@ class RsArgs(C.Structure):
                 ("fin_sum", c_void_p), ("fin_sum0", c_void_p), ("fin_gamma", c_void_p), ("fin_gx", c_void_p),
                 ("fin_ainv", c_void_p), ("fin_out", c_void_p), ("fin_dgamma", c_void_p), ("fin_dbeta", c_void_p),
                 ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p),
-                ("defer_fold", c_void_p), ("ln_done", c_int)]
+                ("defer_fold", c_void_p), ("ln_done", c_int),
+                ("wg_ws", c_void_p), ("wg_ws_floats", c_size_t), ("wg_rows", c_void_p)]
 
 
 class FoldDesc(C.Structure):
@@ -152,7 +153,7 @@ class StemFrontArgs(C.Structure):
 
 
 SK_FLAGS = 2048              # MPMAE_SK_FLAGS (include/mpmae_hip.h)
-OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP RSC_W5 BLASLT NT5 RSC_ATOMIC SK DET RSC1 RSC1_CPS RSC1_WGS RSC1_ATOMIC RSP RSP_WGS RSP_NWV RSP_NWGS RSP_NARROW RSN3 EVX".split())}      # enum MpmaeOption (include/mpmae_hip.h)
+OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP RSC_W5 BLASLT NT5 RSC_ATOMIC SK DET RSC1 RSC1_CPS RSC1_WGS RSC1_ATOMIC RSP RSP_WGS RSP_NWV RSP_NWGS RSP_NARROW RSN3 EVX RST_WGS RST_NW".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 
@@ -200,6 +201,7 @@ SYMBOLS = {
     "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                        c_void_p],
     "mpmae_rs": [c_int, P(RsArgs), c_void_p],
+    "mpmae_rs_wgrad_fold": [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_ps_fwd": [P(PsArgs), c_void_p],
     "mpmae_quant_mx": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mpmae_gemm_mx": [c_int, P(GemmArgs), c_void_p, c_int, c_void_p, c_int, c_void_p],

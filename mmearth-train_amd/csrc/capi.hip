@@ -91,6 +91,8 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSP_NARROW */ 2,
     /* MPMAE_OPT_RSN3 */ 5,
     /* MPMAE_OPT_EVX */ 1,
+    /* MPMAE_OPT_RST_WGS */ 0,
+    /* MPMAE_OPT_RST_NW */ 16,
 };
 
 int mpmae_set_option(int option, int value) {
@@ -282,8 +284,8 @@ int mpmae_grn_bwd_finalize(const float* S0, const float* S1, const float* Gx, co
 int mpmae_grn_stats_from_wgrad(int dt, const float* T, const float* dbt, const void* W2s, int ldw, const float* scale, const float* beta,
                                float* dW2, float* db2, float* S0, float* S1, int C, int H, mpmae_stream_t s) {
   if (!T || !dbt || !W2s || !scale || !beta || !dW2 || !db2 || !S0 || !S1 || C < 1 || H < 1 || ldw < H) return (int)hipErrorInvalidValue;
-  if (dt == 0) LAUNCH(grn_stats_from_wgrad_kernel<float>, dim3(cdiv(H, 256)), dim3(256), 0, S_(s), T, dbt, (const float*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
-  else LAUNCH(grn_stats_from_wgrad_kernel<bf16_t>, dim3(cdiv(H, 256)), dim3(256), 0, S_(s), T, dbt, (const bf16_t*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
+  if (dt == 0) LAUNCH(grn_stats_from_wgrad_kernel<float>, dim3(cdiv(H, 16)), dim3(256), 0, S_(s), T, dbt, (const float*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
+  else LAUNCH(grn_stats_from_wgrad_kernel<bf16_t>, dim3(cdiv(H, 16)), dim3(256), 0, S_(s), T, dbt, (const bf16_t*)W2s, ldw, scale, beta, dW2, db2, S0, S1, C, H);
   RET();
 }
 

@@ -6,6 +6,7 @@
 #include "rsc1.cuh"
 #include "rsp.cuh"
 #include "rsn3.cuh"
+#include "rst.cuh"
 #include "ps.cuh"
 
 // ------------------------------------------------------------------------------------------
@@ -22,12 +23,50 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.fin_sum = a.fin_sum; p.fin_sum0 = a.fin_sum0; p.fin_gamma = a.fin_gamma; p.fin_gx = a.fin_gx; p.fin_ainv = a.fin_ainv;
   p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
   p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
-  p.s0a = nullptr; p.s1a = nullptr; p.perwave = 0;
+  p.s0a = nullptr; p.s1a = nullptr; p.perwave = 0; p.wg_ws = a.wg_ws;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
   if ((a.ldw & 7) || HN % NC || HN % KCH) return (int)hipErrorInvalidValue;
   const int rowblocks = cdiv(a.M, 64 * RT);
+  if (which == 6) {
+    // T = dout^T gelu(h) and db2 = sum_rows dout (rst.cuh): A = dout [M][C], R = h [M][H]; ws = one slab row [C * H + C] per persistent workgroup.
+    // With W = staged W2 [C][ldw], v0 = GRN scale, v1 = GRN beta the fold produces what T is for: s0 = S0 [H], s1 = S1 [H], fin_dgamma = dW2 [C][H],
+    // fin_dbeta = db2 [C] (all ADDED to). Without W: s0 = T [C * H], s1 = db2 [C] raw (added to; mpmae_grn_stats_from_wgrad is the separate second step)
+    if constexpr (KC == 40 || KC == 80) {
+      if (!a.A || !a.R || !a.s0 || !a.s1 || !a.ws || HN % 160) return (int)hipErrorInvalidValue;
+      if (((uintptr_t)a.A | (uintptr_t)a.R) & 15) return (int)hipErrorInvalidValue;
+      const int nw = g_opt[MPMAE_OPT_RST_NW] == 4 ? 4 : 16, ny = HN / 160;
+      const int ntiles = cdiv(a.M, 16 * nw);
+      // (tools/probes/rst_probe.py. NW = 4: C = 40 flat between 2 and 3 per CU, 33.9-34.5 us; C = 80 best at 2 per CU over both column slices: 27.1 vs 33.4 us at 3)
+      const int wgs = g_opt[MPMAE_OPT_RST_WGS] > 0 ? g_opt[MPMAE_OPT_RST_WGS] : (nw == 16 ? 1 : (KC == 40 ? 3 : 2)) * ps_num_cus();
+      int gx = wgs / ny > 0 ? wgs / ny : 1;
+      if (gx > ntiles) gx = ntiles;
+      const size_t W = (size_t)KC * HN + KC;
+      if (a.ws_floats < (size_t)gx * W) return (int)hipErrorInvalidValue;
+      constexpr int BXv = ((KC + 15) / 16) * 16;
+      const size_t ldst = (size_t)16 * nw * (tn2_ld(BXv) + tn2_ld(160)) * 2;
+      const bool fused = a.W != nullptr;      // the fold goes straight on to S0 / S1 / dW2 / db2 (see the header); without W: raw T / db2 into s0 / s1
+      if (fused && (!a.v0 || !a.v1 || !a.fin_dgamma || !a.fin_dbeta || a.ldw < HN)) return (int)hipErrorInvalidValue;
+      if (nw == 16) {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute((const void*)rst_kernel<KC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst) != hipSuccess) return (int)hipGetLastError(); attr = true; }
+        LAUNCH((rst_kernel<KC, 16>), dim3(gx, ny), dim3(1024), ldst, st, p, ntiles);
+      } else {
+        LAUNCH((rst_kernel<KC, 4>), dim3(gx, ny), dim3(256), ldst, st, p, ntiles);
+      }
+      if (!fused) launch_reduce(3, a.ws, gx, (int)W, a.s0, a.s1, KC * HN, 0, 0, 0, st);
+      else {
+        int R = gx / 4 < 1 ? 1 : (gx / 4 > 64 ? 64 : gx / 4);      // <= 4 slab rows per thread: every load of a thread in flight at once
+        if (g_opt[MPMAE_OPT_DET] > 0) R = 1;      // one row group per column block: plain += in a fixed order
+        LAUNCH((rst_fold_kernel<KC>), dim3(HN / 32, R), dim3(256), 0, st, (const float*)a.ws, gx, (const bf16_t*)a.W, a.ldw, a.v0, a.v1, a.fin_dgamma, a.fin_dbeta,
+               a.s0, a.s1);
+      }
+      return launch_status();
+    } else {
+      return (int)hipErrorInvalidValue;
+    }
+  }
   if (which == 0 || which == 1) {
     if (a.fin_sum) return (int)hipErrorInvalidValue;
     // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
@@ -204,8 +243,10 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         if (nwv != 4 && nwv != 8) return (int)hipErrorInvalidValue;
         const int ntiles = cdiv(a.M, 16 * nwv);
         constexpr int NPv = ((KC + 15) / 16) * 16, KP2v = ((KC + 31) / 32) * 32;
+        const bool wg = a.wg_ws != nullptr;      // pwconv1's weight gradient inside the kernel (C = 40, 4 waves: 64-row staging tiles of dh and x-hat)
+        if (wg && (KC != 40 || which != 5 || nwv != 4 || !a.wg_rows)) return (int)hipErrorInvalidValue;
         const size_t ldsn = ((size_t)NPv * (HN + RSC_PAD) + (which == 5 ? (size_t)HN * (KP2v + RSC_PAD) : 0)) * 2 + (size_t)(2 * HN + NPv + 8) * 4 +
-                            (which == 5 ? (size_t)nwv * 2 * NPv * 4 : 0);
+                            (which == 5 ? (size_t)nwv * 2 * NPv * 4 : 0) + (wg ? (size_t)16 * nwv * (tn2_ld(HN) + tn2_ld(NPv)) * 2 : 0);
         const int wgs = g_opt[MPMAE_OPT_RSP_NWGS] > 0 ? g_opt[MPMAE_OPT_RSP_NWGS] : (int)((160 * 1024) / ldsn > 2 ? 2 : (160 * 1024) / ldsn) * ps_num_cus();
         const int gx = ntiles < wgs ? ntiles : wgs;
         if (ldsn > 160 * 1024 - 512 || (which == 5 && (!a.ws || a.ws_floats < (size_t)gx * 2 * KC))) return (int)hipErrorInvalidValue;
@@ -213,9 +254,18 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
           static size_t cur = 64 * 1024; \
           if (ldsn > cur) { if (hipFuncSetAttribute((const void*)rsp_narrow_kernel<KC, MODE_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn) != hipSuccess) return (int)hipGetLastError(); cur = ldsn; } \
           LAUNCH((rsp_narrow_kernel<KC, MODE_, NWV_>), dim3(gx), dim3(64 * NWV_), ldsn, st, p, ntiles); } while (0)
+        if (wg) { if (a.wg_ws_floats < (size_t)gx * ((size_t)HN * KC + HN)) return (int)hipErrorInvalidValue; *a.wg_rows = gx; }
         if (which == 4) { if (nwv == 8) RSP_NARROW(0, 8); else RSP_NARROW(0, 4); }
         else {
-          if (nwv == 8) RSP_NARROW(1, 8); else RSP_NARROW(1, 4);
+          if constexpr (KC == 40) {
+            if (wg) {
+              static size_t curw = 64 * 1024;
+              if (ldsn > curw) { if (hipFuncSetAttribute((const void*)rsp_narrow_kernel<40, 1, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn) != hipSuccess) return (int)hipGetLastError(); curw = ldsn; }
+              LAUNCH((rsp_narrow_kernel<40, 1, 4, true>), dim3(gx), dim3(256), ldsn, st, p, ntiles);
+            } else if (nwv == 8) RSP_NARROW(1, 8); else RSP_NARROW(1, 4);
+          } else {
+            if (nwv == 8) RSP_NARROW(1, 8); else RSP_NARROW(1, 4);
+          }
           const long long delta = a.s1 - a.s0;        // s0 = dgamma, s1 = dbeta (same flat gradient buffer)
           if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
           if (a.defer_fold) *a.defer_fold = MpmaeFoldDesc{a.ws, gx, 2 * KC, a.s0, KC, (int)delta, 1};
@@ -225,6 +275,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         return launch_status();
       }
     }
+    if (a.wg_ws) return (int)hipErrorInvalidValue;      // (the fused weight gradient only exists in the persistent C = 40 backward kernel above)
 #define RSC_NARROW_W(MODE_, PF_, NWV_) do { \
       static size_t cur = 64 * 1024; \
       if (lds > cur) { if (hipFuncSetAttribute((const void*)rsc_narrow_kernel<KC, MODE_, RTN, KCH, PF_, NWV_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } \
@@ -251,8 +302,16 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   return launch_status();
 }
 
+int mpmae_rs_wgrad_fold(int C, const float* slabs, int rows, const float* ln_gamma, const float* ln_beta, float* dW1, float* db1, mpmae_stream_t s) {
+  if (C != 40 || !slabs || rows < 1 || !ln_gamma || !ln_beta || !dW1 || !db1) return (int)hipErrorInvalidValue;
+  int R = rows / 16 < 1 ? 1 : (rows / 16 > 32 ? 32 : rows / 16);
+  if (g_opt[MPMAE_OPT_DET] > 0) R = 1;
+  LAUNCH((rsu_fold_kernel<40>), dim3(cdiv(4 * C * C, 64), R), dim3(256), 0, S_(s), slabs, rows, ln_gamma, ln_beta, dW1, db1);
+  RET();
+}
+
 int mpmae_rs(int which, const MpmaeRsArgs* a, mpmae_stream_t s) {
-  if (!a || which < 0 || which > 5) return (int)hipErrorInvalidValue;
+  if (!a || which < 0 || which > 6) return (int)hipErrorInvalidValue;
   if (a->C == 160 && a->H == 640) return launch_rsc<160, 1, 32, 64, 1, 3>(which, *a, S_(s));      // 32-column chunks: the N range splits 4 ways (27.7 -> 24.1 us vs 64)
   if (a->C == 320 && a->H == 1280) return launch_rsc<320, 1, 32, 32>(which, *a, S_(s));
   // ConvNeXtV2-tiny widths (BASELINE config 4: 96 / 192 / 384; 768 stays on the tiled GEMMs)

@@ -171,24 +171,45 @@ static __global__ __launch_bounds__(256) void grn_fwd_finalize_kernel(const floa
 // read of the block's widest tensor whose only products are these two H-vectors - is the weight-gradient product itself: mpmae_wgrad runs
 // with a GELU-only operand prologue into T / db2 (zero-initialised scratch), this kernel turns them into the statistics AND the parameter
 // gradients. One thread per column j; W2s = the bf16 weights the forward and the data gradient multiply with ([C][ldw], k = j).
+// Launch shape (round 6): 16 columns x 16 c-lanes per workgroup, every load of a thread independent of the others (C / 16 <= 5 rows each), one LDS
+// fold over the c-lanes: the first version - one thread per column walking all C rows with the dW2 read-modify-write inside the loop, ONE
+// workgroup at H = 160 - was a 40-trip dependent chain on the main lane in front of the fused backward kernel.
 template <typename T>
 static __global__ __launch_bounds__(256) void grn_stats_from_wgrad_kernel(const float* __restrict__ Tm, const float* __restrict__ dbt,
                                                                         const T* __restrict__ W2s, int ldw, const float* __restrict__ scale,
                                                                         const float* __restrict__ beta, float* __restrict__ dW2,
                                                                         float* __restrict__ db2, float* __restrict__ S0,
                                                                         float* __restrict__ S1, int C, int H) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j < H) {
-    const float sc = scale[j], bt = beta[j];
-    float s0 = 0.f, s1 = 0.f;
-    for (int c = 0; c < C; ++c) {
-      const float t = Tm[(size_t)c * H + j], d = dbt[c], w = ldf<T>(W2s + (size_t)c * ldw + j);
-      s0 += w * d;
-      s1 += w * t;
-      dW2[(size_t)c * H + j] += sc * t + bt * d;
+  __shared__ float red[2][16][17];
+  const int jl = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jl, jc = min(j, H - 1);
+  const float sc = scale[jc], bt = beta[jc];
+  float s0 = 0.f, s1 = 0.f;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    float t[4], d[4], w[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = min(c0 + cl + 16 * u, C - 1);
+      t[u] = Tm[(size_t)c * H + jc]; d[u] = dbt[c]; w[u] = ldf<T>(W2s + (size_t)c * ldw + jc); g[u] = dW2[(size_t)c * H + jc];
     }
-    S0[j] += s0;
-    S1[j] += s1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + cl + 16 * u;
+      if (c < C && j < H) {
+        s0 += w[u] * d[u];
+        s1 += w[u] * t[u];
+        dW2[(size_t)c * H + j] = g[u] + sc * t[u] + bt * d[u];
+      }
+    }
+  }
+  red[0][cl][jl] = s0; red[1][cl][jl] = s1;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int q = threadIdx.x >> 4;
+    float a = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a += red[q][r][jl];
+    if (j < H) { if (q == 0) S0[j] += a; else S1[j] += a; }
   }
   if (blockIdx.x == 0) for (int c = threadIdx.x; c < C; c += 256) db2[c] += dbt[c];
 }

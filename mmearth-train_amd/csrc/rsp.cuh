@@ -16,6 +16,7 @@
 // generations agree to the last bit on everything but the order of the fp32 statistics sums.
 #pragma once
 #include "rsc.cuh"
+#include "gemm_tn2.cuh"
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // rsp_wide: N = H outputs in slices of 160 columns (grid.y = H / 160), whole K = C per row.
@@ -240,12 +241,21 @@ __global__ __launch_bounds__(256) void rsp_wide_kernel(const RsP p, int ntiles) 
 // Optional folded GRN finalisation (p.fin_sum), once per workgroup: see rsc_narrow.
 // grid = GX; block = 64 NWV
 // ---------------------------------------------------------------------------------------------------------------------------------
-template <int KC, int MODE, int NWV>
+template <int KC, int MODE, int NWV, bool WG = false>
 __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int ntiles) {
   using T = bf16_t;
   constexpr int NTH = 64 * NWV, HN = 4 * KC, KSH = HN / 32, LDW = HN + RSC_PAD, VPR = HN / 8;
   constexpr int NT = (KC + 15) / 16, NP = NT * 16;
   constexpr bool PAD = NP != KC, BW = MODE == 1;
+  static_assert(!WG || (BW && NWV == 4), "the fused weight gradient rides in the 4-wave backward kernel");
+  // WG (round 6): pwconv1's weight gradient inside this kernel. dW1 = dh^T xn with xn = x-hat * gamma + beta is, by linearity,
+  // gamma[c] * U[j][c] + beta[c] * db1[j] with U = dh^T x-hat and db1 = sum_rows dh - and dh and x-hat are both in this kernel's registers. The 64 rows
+  // of a workgroup iteration go to LDS row-major (dh [64][LDG], x-hat [64][LDX]; odd multiples of 16 elements like gemm_tn2's slabs), the transposing
+  // LDS read hands a lane 4 consecutive rows of one column, and wave w accumulates the U tiles of hidden-column tiles w, w + 4, ... for all C over ALL
+  // tiles of the persistent workgroup (9 + 3 accumulator tiles at C = 40); one slab row [H * C | H] per workgroup in p.wg_ws, folded by rsu_fold_kernel.
+  // dh is then never written to HBM (100 MB per stage-0 block), the transpose-read GEMM over dh and xn and its fold leave the weight-gradient lane,
+  // and the forward need not store xn.
+  constexpr int NJT = HN / 16, JU = (NJT + 3) / 4, LDG = tn2_ld(HN), LDXH = tn2_ld(NP);
   constexpr int KS2 = (KC + 31) / 32, KP2 = KS2 * 32, LDW2 = KP2 + RSC_PAD, VPR2 = KP2 / 8;
   static_assert(KC % 8 == 0 && HN % 32 == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char rsc_smem[];
@@ -255,6 +265,8 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
   float* cv = vec + 2 * HN;                                                                  // [NP]: b2 (MODE 0) / LayerNorm gamma (MODE 1), zero beyond KC
   float* fsh = cv + NP;                                                                      // [8] block-reduction scratch
   float* red = fsh + 8;                                                                      // [NWV][2][NP] (MODE 1)
+  bf16_t* Gs = reinterpret_cast<bf16_t*>(red + NWV * 2 * NP);                                // WG: dh rows [16 NWV][LDG]
+  bf16_t* Xh = Gs + 16 * NWV * LDG;                                                          // WG: x-hat rows [16 NWV][LDXH] (columns KC.. stay zero)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -372,6 +384,21 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
   }
   __syncthreads();
 
+  f32x4_t accu[WG ? JU : 1][WG ? NT : 1], accd[WG ? JU : 1];      // WG: U tiles (hidden tile wave + 4 u, channel tile i) and the db1 tile of each
+  if (WG) {
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      accd[u] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < NT; ++i) accu[u][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    if (PAD) {
+      for (int i = tid; i < 16 * NWV * (NP - KC) / 4; i += NTH) {
+        const int r = i / ((NP - KC) / 4), c = KC + (i - r * ((NP - KC) / 4)) * 4;
+        *reinterpret_cast<uint2*>(Xh + r * LDXH + c) = make_uint2(0u, 0u);
+      }
+    }
+  }
   float cg[BW ? NT : 1][4][2];                     // MODE 1: this lane's dgamma / dbeta partials over every tile of the workgroup
 #pragma unroll
   for (int j = 0; j < (BW ? NT : 1); ++j)
@@ -398,6 +425,12 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
 #pragma unroll
     for (int j = 0; j < NT; ++j) xc[j] = and2(xraw[j], inb && (!PAD || j * 16 + lg * 4 < KC) && (BW || p.R != nullptr));
     if (tile + (int)gridDim.x < ntiles) request(tile + gridDim.x);       // the next tile's operands travel under this tile's arithmetic
+    if (WG) {
+      __syncthreads();                               // every wave has finished the previous iteration's transposed reads
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (!PAD || j * 16 + lg * 4 < KC) *reinterpret_cast<uint2*>(Xh + (wave * 16 + lr) * LDXH + j * 16 + lg * 4) = xc[j];
+    }
 
     f32x4_t acc[NT];
 #pragma unroll
@@ -439,7 +472,9 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
         for (int e = 0; e < 8; ++e) z[e] = (a[e] * sc[e] + tc[e] * gl[e]) * dg[e];                 // dh
       }
       const bf16x8_t af = pack_bf16x8(z);
-      if (inb) {
+      if (WG) {
+        *reinterpret_cast<uint4*>(Gs + (wave * 16 + lr) * LDG + k) = __builtin_bit_cast(uint4, af);      // dh stays on the CU (rows beyond M are zero: h = 0)
+      } else if (inb) {
         bf16_t* dst = BW ? const_cast<bf16_t*>(p.A) : p.xn;
         if (dst) *reinterpret_cast<uint4*>(dst + (size_t)row * HN + k) = __builtin_bit_cast(uint4, af);
       }
@@ -497,6 +532,50 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
         if (inb && (!PAD || n4 < KC)) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
       }
     }
+    if (WG) {
+      __syncthreads();                               // the workgroup's 64 rows of dh and x-hat are in LDS
+      typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+      const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+      const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
+      const int goff = (lg * 4 + (lr >> 2)) * LDG + 4 * (lr & 3), xoff = (lg * 4 + (lr >> 2)) * LDXH + 4 * (lr & 3);
+#pragma unroll
+      for (int ks = 0; ks < (16 * NWV) / 32; ++ks) {
+        bf16x8_t xf[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) xf[i] = tn2_frag(Xh + ks * 32 * LDXH + xoff + i * 16, 16 * LDXH);
+#pragma unroll
+        for (int u = 0; u < JU; ++u) {
+          const int jt = wave + 4 * u;
+          if (jt < NJT) {                            // (wave-uniform)
+            const bf16x8_t gf = tn2_frag(Gs + ks * 32 * LDG + goff + jt * 16, 16 * LDG);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) accu[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, xf[i], accu[u][i], 0, 0, 0);
+            accd[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf, ones, accd[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  if (WG) {
+    // one slab row per workgroup: [HN * KC | HN]; D layout: row (hidden j) = lg * 4 + r, column (channel c) = lr
+    float* slab = p.wg_ws + (size_t)blockIdx.x * ((size_t)HN * KC + HN);
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int jt = wave + 4 * u;
+      if (jt < NJT) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = jt * 16 + lg * 4 + r, c = i * 16 + lr;
+            if (c < KC) slab[(size_t)j * KC + c] = accu[u][i][r];
+          }
+        if (lr == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) slab[(size_t)HN * KC + jt * 16 + lg * 4 + r] = accd[u][r];
+        }
+      }
+    }
   }
   if (BW) {
     float* redw = red + (size_t)wave * 2 * NP;
@@ -516,4 +595,39 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
       p.ws[((size_t)blockIdx.x * 2 + 1) * KC + i] = b;
     }
   }
+}
+
+// Second stage of the fused pwconv1 weight gradient (rsp_narrow_kernel<.., WG = true>): slab rows [P][H * C | H] of U = dh^T x-hat and db1 = sum_rows dh ->
+//     dW1[j][c] += gamma[c] * U[j][c] + beta[c] * db1[j]          db1[j] += db1[j]
+// (xn = x-hat * gamma + beta is never needed as a tensor). grid = (ceil(H C / 64), R row chunks); block = 64 elements x 4 row lanes, like reduce_partials.
+template <int KC>
+__global__ __launch_bounds__(256) void rsu_fold_kernel(const float* __restrict__ part, int P, const float* __restrict__ lng, const float* __restrict__ lnb,
+                                                       float* __restrict__ dW1, float* __restrict__ db1) {
+  constexpr int HN = 4 * KC, NE = HN * KC, NJB = 64 / KC + 2;
+  constexpr size_t W = (size_t)NE + HN;
+  __shared__ float red[4][64];
+  __shared__ float dred[4][NJB];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col, j0 = (blockIdx.x * 64) / KC;
+  const int chunk = (P + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
+  float s = 0.f;
+  if (e < NE) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
+  }
+  if (col < NJB) {
+    float d = 0.f;
+    if (j0 + col < HN) for (int p = p0 + rl; p < p1; p += 4) d += part[(size_t)p * W + NE + j0 + col];
+    dred[rl][col] = d;
+  }
+  red[rl][col] = s;
+  __syncthreads();
+  if (rl != 0 || e >= NE) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  const int j = e / KC, c = e - j * KC;
+  const float d = dred[0][j - j0] + dred[1][j - j0] + dred[2][j - j0] + dred[3][j - j0];
+  const float g = lng[c] * s + lnb[c] * d;
+  if (gridDim.y == 1) { dW1[e] += g; if (c == 0) db1[j] += d; }
+  else { atomicAdd(dW1 + e, g); if (c == 0) atomicAdd(db1 + j, d); }
 }

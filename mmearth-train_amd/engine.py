@@ -80,7 +80,8 @@ ENGINE_OPTIONS = dict(
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
-    stats_wgrad=0,          # (measured SLOWER, 3.76 vs 3.66 ms: the transpose-read weight gradient + its fold on the main lane cost more than the statistics pass they replace; parity-tested, off) blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient (T = dout^T gelu(h) into scratch on the MAIN lane, then mpmae_grn_stats_from_wgrad) instead of a statistics-only pass over dout and h (mpmae_rs which = 1, out = NULL): one read of the block's widest tensor less per block; implies z_free for those blocks
+    wg_fused=1,             # round 6: pwconv1's weight gradient of the stage-0 blocks (C = 40, dz recomputed) INSIDE the fused backward kernel (MpmaeRsArgs.wg_ws: U = dh^T x-hat and db1 per persistent workgroup, folded by mpmae_rs_wgrad_fold with the LayerNorm affine applied by linearity): dh is never stored (100 MB per block), the transpose-read product over dh and xn and its fold leave the weight-gradient lane, the forward does not store xn
+    stats_wgrad=1,          # blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient - T = dout^T gelu(h) on the MAIN lane (mpmae_rs which = 6, csrc/rst.cuh: one read of dout and h at the price of the statistics-only pass it replaces, 33.9 vs 34.7 us at stage 0), then mpmae_grn_stats_from_wgrad -> S0, S1, dW2, db2: the weight-gradient lane loses pwconv2's transpose-read product and fold over the same two tensors (72 + 12 us per stage-0 block), the forward never stores z at those widths. Round 6: 3.471 vs 3.569 ms (profiles/r06/ab_stats_wgrad.txt). 2 = round 5's route (T through the generic gemm_tn2 kernel: 3.65 ms, slower than off); 0 = statistics pass + separate weight gradient
     grn_apply_fin=1,        # unfused sparse blocks (C = 320: tiled GEMMs + element-wise GRN passes): the GRN finalisation runs in the prologue of the element-wise pass (mpmae_grn_apply_fin / _bwd_apply_fin) - two launches fewer per block on the main lane
     loss_rowsplit=0,        # k > 1: continuous pixel losses with k workgroups per sample, each walking ceil(grid / k) patch rows (k = grid, one row per workgroup, measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times)
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
@@ -380,6 +381,7 @@ class Engine:
             for nm in ("G2", "S0", "S1"):
                 blk[nm] = self.stats[off:off + G * H]
                 off += G * H
+            blk["S01"] = self.stats[off - 2 * G * H:off]      # the two backward statistics vectors, adjacent (Engine.backward zeroes them)
         for blk in ps_blocks:
             for nm in ("G2", "S0", "S1"):
                 blk["ps_" + nm] = self.stats[off:off + self.PS_NG * blk["H"]]
@@ -912,10 +914,17 @@ class Engine:
         self._dwconv(lst, tag + ":dw", blk, x, blk["d"], None, 0, True)
         rs, rs_n = self._rs_plan(blk)
         blk["rs"], blk["rs_n"] = rs, rs_n
+        # pwconv1's weight gradient inside the fused backward kernel (wg_fused): the same conditions as the dz recomputation it rides on, C = 40
+        blk["wgf"] = (bool(self.opt["wg_fused"]) and rs and rs_n == "fused" and Cc == 40 and blk["sparse"] and G == 1 and self.grn_fold
+                      and Cc >= int(self.opt["grn_fold_minc"]) and Cc <= int(self.opt["dzr_maxc"]) and self.dz_recompute
+                      and Cc > int(self.opt["hr_maxc"]) and bool(self.opt["rsc_pf"])
+                      # (it lives in the persistent 4-wave backward kernel of rsp.cuh: the library switches that select another kernel switch it off)
+                      and lib.mpmae_get_option(_lib.OPT["RSP"]) > 0 and (lib.mpmae_get_option(_lib.OPT["RSP_NARROW"]) & 2)
+                      and lib.mpmae_get_option(_lib.OPT["RSP_NWV"]) in (0, 4) and lib.mpmae_get_option(_lib.OPT["RSC_PF"]) > 0)
         if rs:   # LN + pwconv1 + GELU^2 column sums in one row-streaming kernel
-            self._rs(lst, tag + ":ln+pw1", 0, blk, (3 * M * Cc + M * H) * esz, 2 * M * Cc * H, A=blk["d"],
+            self._rs(lst, tag + ":ln+pw1", 0, blk, ((2 if blk["wgf"] else 3) * M * Cc + M * H) * esz, 2 * M * Cc * H, A=blk["d"],
                      W=self.w[tag + ".W1"]["t"], ldw=self.w[tag + ".W1"]["ld"], bias=P[nm["b1"]], v0=P[nm["ln_w"]],
-                     v1=P[nm["ln_b"]], out=blk["h"], xhat=blk["dhat"], xn=blk["xn"], rstd=blk["rstd"], act=act,
+                     v1=P[nm["ln_b"]], out=blk["h"], xhat=blk["dhat"], xn=None if blk["wgf"] else blk["xn"], rstd=blk["rstd"], act=act,
                      s0=blk["G2"])
         else:
             self._op(lst, tag + ":ln", lib.mpmae_ln_fwd, dt, _p(blk["d"]), _p(blk["dhat"]), _p(blk["rstd"]),
@@ -1016,10 +1025,17 @@ class Engine:
             if H not in self._sw_ones:
                 self._sw_ones[H] = torch.ones(H, dtype=torch.float32, device=self.device)
                 self._sw_zeros[H] = torch.zeros(H, dtype=torch.float32, device=self.device)
-            self._wgrad(lst, tag + ":pw2.wgrad(T)", "NONE", "GRN", P=dout, Q=blk["h"], qp0=self._sw_ones[H], qp1=self._sw_zeros[H], M=M, Nn=Cc, Kk=H,
-                        ldp=Cc, ldq=H, dW=blk["Tw2"], sn=H, sk=1, db=blk["dbt"])
+            if int(self.opt["stats_wgrad"]) == 2:      # (round 5's route: the generic transpose-read weight-gradient kernel with a GELU-only prologue)
+                self._wgrad(lst, tag + ":pw2.wgrad(T)", "NONE", "GRN", P=dout, Q=blk["h"], qp0=self._sw_ones[H], qp1=self._sw_zeros[H], M=M, Nn=Cc, Kk=H,
+                            ldp=Cc, ldq=H, dW=blk["Tw2"], sn=H, sk=1, db=blk["dbt"])
+            else:                                       # round 6: the persistent T kernel (csrc/rst.cuh) at the statistics pass's price
+                w2s_ = self.w[tag + ".W2"]
+                self._rs(lst, tag + ":pw2.wgrad(T)+stats", 6, blk, (M * Cc + M * H) * esz + Cc * H * 4, 2 * M * Cc * H, A=dout, R=blk["h"],
+                         W=w2s_["t"], ldw=w2s_["ld"], v0=blk["scale"], v1=P[nm["gb"]], s0=blk["S0"], s1=blk["S1"],
+                         fin_dgamma=Gd[nm["w2"]], fin_dbeta=Gd[nm["b2"]])
             w2s = self.w[tag + ".W2"]
-            self._op(lst, tag + ":grn.stats(T)", lib.mpmae_grn_stats_from_wgrad, dt, _p(blk["Tw2"]), _p(blk["dbt"]), _p(w2s["t"]), w2s["ld"],
+            if int(self.opt["stats_wgrad"]) == 2:
+              self._op(lst, tag + ":grn.stats(T)", lib.mpmae_grn_stats_from_wgrad, dt, _p(blk["Tw2"]), _p(blk["dbt"]), _p(w2s["t"]), w2s["ld"],
                      _p(blk["scale"]), _p(P[nm["gb"]]), _p(Gd[nm["w2"]]), _p(Gd[nm["b2"]]), _p(blk["S0"]), _p(blk["S1"]), Cc, H,
                      kind="grn_stats_wgrad", nbytes=3 * Cc * H * 4)
         elif rs:
@@ -1095,7 +1111,15 @@ class Engine:
                 self._keepalive.append(fd)
                 self._fold_pending.append(fd)
                 dzkw = dict(dzkw, ws=blk["ln_slab"], ws_floats=blk["ln_slab"].numel(), defer_fold=C.addressof(fd))
-            self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd", 5, blk, ((2 if dzr else 3) * M * H + (3 if dzr else 2) * M * Cc) * esz,
+            wgf = bool(blk.get("wgf")) and dzr
+            if wgf:      # U = dh^T x-hat, db1 per persistent workgroup into the block's own slab (<= 2 workgroups per CU); dh is not stored
+                if "wg_slab" not in blk:
+                    cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+                    blk["wg_slab"] = torch.empty(2 * cus * (H * Cc + H), dtype=torch.float32, device=self.device)
+                    blk["wg_rows"] = C.c_int(0)
+                dzkw = dict(dzkw, wg_ws=blk["wg_slab"], wg_ws_floats=blk["wg_slab"].numel(), wg_rows=C.addressof(blk["wg_rows"]))
+            self._rs(lst, tag + ":grn.bapply+pw1.dgrad+ln.bwd" + ("+pw1.wgrad" if wgf else ""), 5, blk,
+                     ((1 if wgf else 2 if dzr else 3) * M * H + (3 if dzr else 2) * M * Cc) * esz,
                      (4 if dzr else 2) * M * Cc * H,
                      A=dz, A2=blk["h"], W=w1t["t"], ldw=w1t["ld"], v0=blk["scale"], v1=blk["coef"], out=dd,
                      xhat=blk["dhat"], rstd=blk["rstd"], lng=P[nm["ln_w"]], act=act, s0=Gd[nm["ln_w"]],
@@ -1114,7 +1138,18 @@ class Engine:
         if late_w2 and not grouped and not sw:
             self._side_wgrad(lst, tag + ":pw2.wgrad", "NONE", w2_qpro, [dout], **w2_args)
         w1_args = dict(P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
-        if grouped or (sw and self._group_ok(blk, "NONE")):
+        if rsc and bool(blk.get("wgf")) and dzr:
+            # second stage of the weight gradient the fused kernel accumulated (LayerNorm affine applied by linearity): nothing on the chain reads it
+            def wfold(stream, _b=blk, _c=Cc, _g=P[nm["ln_w"]], _bt=P[nm["ln_b"]], _dw=Gd[nm["w1"]], _db=Gd[nm["b1"]]):
+                return lib.mpmae_rs_wgrad_fold(_c, _p(_b["wg_slab"]), _b["wg_rows"].value, _p(_g), _p(_bt), _p(_dw), _p(_db), stream)
+            if self.lanes and not (int(self.opt["tail_main"]) >= 1 and tag == "encoder.stages.0.0"):
+                k = self._after(lst)
+                self._evseq += 1
+                self._op(lst, tag + ":pw1.wgrad.fold", wfold, kind="rs_wgrad_fold", nbytes=blk["wg_slab"].numel() * 4, lane=1, wait=(k,) if k else (),
+                         signal=f"s{self._evseq}")
+            else:      # (single lane, or the last block of the backward: in order on the main lane like its depthwise weight gradient - tail_main)
+                self._op(lst, tag + ":pw1.wgrad.fold", wfold, kind="rs_wgrad_fold", nbytes=blk["wg_slab"].numel() * 4)
+        elif grouped or (sw and self._group_ok(blk, "NONE")):
             self._group_add(lst, tag + ":pw1.wgrad", [dz], **w1_args)
         elif not late_all:
             if self.lanes and int(self.opt["tail_main"]) >= 2 and tag == "encoder.stages.0.0":
@@ -2344,6 +2379,13 @@ class Engine:
         st = self._stream()
         if zero_grad:
             self.gflat.zero_()
+        # the GRN backward statistics are ACCUMULATED into the arena the forward zeroed: a second backward behind the same forward (retain_graph,
+        # backward-only replays) must start from zero again, like the gradient buffer (the step programs zero the whole arena once per step)
+        for blk in self.blocks + self.decs:
+            blk["S01"].zero_()
+            for k in ("Tw2", "dbt"):
+                if k in blk:
+                    blk[k].zero_()
         # d(total)/d(log_vars) and the per-modality coefficients (second finalize pass adds dlog_vars)
         self.finalize_loss(st, True, self._loss_scale)
         self._run(self.bwd_ops, st)

@@ -611,3 +611,104 @@ def test_stream_k_gemm_matches_torch_and_leaves_its_flags_zero(M, N, K, resid, b
             assert int(flags.abs().sum()) == 0
     finally:
         lib.mpmae_set_option(L.OPT["SK"], 0)
+
+
+@pytest.mark.parametrize("M,Cc", [(1000, 40), (64, 40), (333, 80), (77824, 80), (100000, 40)])
+def test_weight_gradient_as_statistics_pass_matches_torch_and_the_statistics_kernel(M, Cc):
+    """mpmae_rs which = 6 (csrc/rst.cuh, round 6): T = dout^T gelu(h), db2 = sum_rows dout in ONE read of dout and h, against fp32 matmuls on the
+    same bf16 operands (the kernel rounds gelu(h) to bf16 like every MFMA operand of the bf16 mode), accumulating into non-zero outputs; then
+    mpmae_grn_stats_from_wgrad on its result against the statistics pass it replaces (mpmae_rs which = 1, out = NULL) and the parameter
+    gradients dW2 = dout^T (gelu(h) * scale + beta), db2. Ragged row counts, one tile, more tiles than workgroups, both widths."""
+    L, lib = _lib()
+    dev, H = "cuda", 4 * Cc
+    torch.manual_seed(3 * M + Cc)
+    ws = torch.empty(24 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    live = (torch.rand(M, device=dev) > 0.1)[:, None]
+    h = torch.randn(M, H, device=dev).to(bf)
+    dout = (torch.randn(M, Cc, device=dev) * 0.1).to(bf) * live
+    T = torch.full((Cc * H + Cc,), 0.5, device=dev)                   # T | db2 adjacent, as in the engine's arena; the call ADDS
+    assert lib.mpmae_rs(6, C.byref(args(A=dout, R=h, s0=T, s1=T[Cc * H:])), _st()) == 0
+    torch.cuda.synchronize()
+    g = _gelu(h.float()).to(bf).float()
+    Tref = dout.float().t() @ g
+    dbref = dout.float().sum(0)
+    scl = Tref.abs().max().item()
+    assert (T[:Cc * H].view(Cc, H) - 0.5 - Tref).abs().max().item() <= 2e-3 * scl      # (the kernel's GELU is a 3e-5-accurate fit: a bf16 ulp of g now and then)
+    assert (T[Cc * H:] - 0.5 - dbref).abs().max().item() <= 1e-4 * dbref.abs().max().item() + 1e-5
+    # the statistics and parameter gradients it stands for
+    T -= 0.5
+    W2 = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)          # [C][H]: the staged forward weight
+    W2T = W2.t().contiguous()
+    scale, beta = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+    dW2, db2, S0, S1 = torch.zeros(Cc, H, device=dev), torch.zeros(Cc, device=dev), torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    assert lib.mpmae_grn_stats_from_wgrad(1, T.data_ptr(), T[Cc * H:].data_ptr(), W2.data_ptr(), H, scale.data_ptr(), beta.data_ptr(), dW2.data_ptr(),
+                                          db2.data_ptr(), S0.data_ptr(), S1.data_ptr(), Cc, H, _st()) == 0
+    u0, u1 = torch.zeros(H, device=dev), torch.zeros(H, device=dev)
+    assert lib.mpmae_rs(1, C.byref(args(A=dout, W=W2T, ldw=Cc, out=None, R=h, s0=u0, s1=u1)), _st()) == 0
+    torch.cuda.synchronize()
+    # (S1 through T carries one bf16 rounding of gelu(h) per term - the rounding pwconv2's weight gradient has always had - where the statistics
+    # kernel multiplies the fp32 value: a relative 2^-9 per term, ~ 1e-3 of a random-sign sum; bound 6e-3 of the largest column)
+    assert (S0 - u0).abs().max().item() <= 2e-3 * u0.abs().max().item() + 1e-4
+    assert (S1 - u1).abs().max().item() <= 6e-3 * u1.abs().max().item() + 1e-4
+    z = (g * scale + beta)
+    assert _rel(dW2, dout.float().t() @ z) < 3e-3 and _rel(db2, dbref) < 1e-4
+    # the fused form (what the engine issues): the slab fold adds straight into S0 / S1 / dW2 / db2, T is never stored
+    f0, f1, fW, fb = torch.ones(H, device=dev), torch.ones(H, device=dev), torch.ones(Cc, H, device=dev), torch.ones(Cc, device=dev)
+    assert lib.mpmae_rs(6, C.byref(args(A=dout, R=h, W=W2, ldw=H, v0=scale, v1=beta, s0=f0, s1=f1, fin_dgamma=fW, fin_dbeta=fb)), _st()) == 0
+    torch.cuda.synchronize()
+    for got, ref in ((f0 - 1, S0), (f1 - 1, S1), (fW - 1, dW2), (fb - 1, db2)):
+        assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5      # (same products, another summation order)
+
+
+@pytest.mark.parametrize("M", [1000, 64, 40000])
+def test_pointwise1_weight_gradient_inside_the_fused_backward_kernel(M):
+    """MpmaeRsArgs.wg_ws (round 6, C = 40): mpmae_rs which = 5 accumulates U = dh^T x-hat and db1 = sum_rows dh per persistent workgroup and does
+    NOT store dh; mpmae_rs_wgrad_fold applies the LayerNorm affine by linearity. Against the same call without wg_ws (dd, the LayerNorm gamma / beta
+    partials: identical arithmetic) and against fp32 matmuls on the dh that call stored: dW1 = dh^T (x-hat * gamma + beta), db1 = sum dh."""
+    L, lib = _lib()
+    dev, Cc = "cuda", 40
+    H = 4 * Cc
+    torch.manual_seed(11 * M)
+    ws, ws2 = torch.empty(8 << 20, dtype=torch.float32, device=dev), torch.empty(8 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    live = act.bool()[:, None]
+    h = torch.randn(M, H, device=dev).to(bf) * live
+    dout = (torch.randn(M, Cc, device=dev) * 0.1).to(bf) * live
+    W2T = (torch.randn(H, Cc, device=dev) / math.sqrt(H)).to(bf)
+    W1T = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    scale, coef = torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.05
+    xhat = torch.randn(M, Cc, device=dev).to(bf) * live
+    rstd, lng, lnb = (torch.rand(M, device=dev) + 0.5) * act, torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.3
+    dd0, dd1 = torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf)
+    g0, g1 = torch.zeros(2 * Cc, device=dev), torch.zeros(2 * Cc, device=dev)
+    dh0, dh1 = torch.zeros(M, H, device=dev, dtype=bf), torch.full((M, H), 7.0, device=dev, dtype=bf)
+    rows = C.c_int(0)
+    common = dict(A2=h, W=W1T, ldw=H, v0=scale, v1=coef, xhat=xhat, rstd=rstd, lng=lng, act=act, dz_dout=dout, dz_w2t=W2T, dz_ldw2=Cc)
+    assert lib.mpmae_rs(5, C.byref(args(A=dh0, out=dd0, s0=g0, s1=g0[Cc:], **common)), _st()) == 0
+    assert lib.mpmae_rs(5, C.byref(args(A=dh1, out=dd1, s0=g1, s1=g1[Cc:], wg_ws=ws2, wg_ws_floats=ws2.numel(), wg_rows=C.addressof(rows), **common)),
+                        _st()) == 0
+    dW1, db1 = torch.full((H, Cc), 0.25, device=dev), torch.full((H,), 0.25, device=dev)
+    assert rows.value >= 1
+    assert lib.mpmae_rs_wgrad_fold(Cc, ws2.data_ptr(), rows.value, lng.data_ptr(), lnb.data_ptr(), dW1.data_ptr(), db1.data_ptr(), _st()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dd1, dd0) and _rel(g1, g0) < 1e-5
+    assert (dh1 == 7.0).all(), "dh must not be written in the fused form"
+    xn = xhat.float() * lng + lnb
+    ref_w, ref_b = dh0.float().t() @ xn, dh0.float().sum(0)
+    assert _rel(dW1 - 0.25, ref_w) < 2e-4 and _rel(db1 - 0.25, ref_b) < 2e-4
