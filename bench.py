@@ -118,11 +118,11 @@ def family_of(kind):
 
 
 FAMILY_SYMBOLS = {
-    "rs": ("rsc_wide_kernel", "rsc_wide1_kernel", "rsp_wide_kernel", "rsc_narrow_kernel", "rsp_narrow_kernel", "rsn3_bwd_kernel"),
+    "rs": ("rsc_wide_kernel", "rsc_wide1_kernel", "rsp_wide_kernel", "rsc_narrow_kernel", "rsp_narrow_kernel", "rsn3_bwd_kernel", "rst_kernel"),
     "wgrad": ("gemm_tn2_kernel", "gemm_tn3_kernel", "gemm_tng_kernel", "gemm_tn_bf16_kernel"),
     "dwconv7": ("dwconv7_mfma_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
     "dwconv7_wgrad": ("dwconv7_wgrad_mfma_kernel", "dwconv7_wgrad_mfma4_kernel", "dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
-    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt4_kernel", "gemm_nt3_kernel", "Cijk_* (hipBLASLt: four plain decoder / head products)"),
+    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt3_kernel"),
     "ps_fwd": ("ps_fwd_kernel",),
 }
 FAMILY_TEXT = {
@@ -131,7 +131,7 @@ FAMILY_TEXT = {
     "wgrad": "weight-gradient GEMMs dW = P^T Q (transpose-read, DMA-ring and grouped kernels) with their slab folds",
     "dwconv7": "depthwise 7x7 forward / data gradient",
     "dwconv7_wgrad": "depthwise 7x7 weight gradient with its folds",
-    "gemm_nt": "dense NT GEMMs (decoder block, heads, downsample, stage-3 pointwise; four plain ones through hipBLASLt)",
+    "gemm_nt": "dense NT GEMMs (decoder block, heads, downsample, stage-3 pointwise)",
     "ps_fwd": "persistent per-sample stage kernel (all blocks of stage 2 forward; stage 3 with ps = 3)",
 }
 
@@ -447,14 +447,12 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]      # HIP events on the launch stream
     if world > 1:
         trainer.measure_comm_tail = True        # two more events per step on the main stream (exposed_comm_tail_ms in the line)
-    vendor0 = int(eng.lib.mpmae_vendor_launches())
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
         trainer.step()
         marks[i + 1].record()
     torch.cuda.synchronize()
-    vendor_per_step = (int(eng.lib.mpmae_vendor_launches()) - vendor0) / a.steps
     if world > 1:
         mdist.barrier()
     torch.cuda.synchronize()
@@ -621,8 +619,9 @@ def main():
                                            "ms_per_step_with_input_stage includes the D2D batch copy and device randn of every step, issued on an input stream "
                                            "behind the previous step's last reader of the input buffers (Engine.set_inputs_async)"),
                    roofline=roof,
-                   # kernels of a vendor library (hipBLASLt) inside the timed step: 0 with the default options since round 5
-                   vendor_kernels_per_step=vendor_per_step)
+                   # kernels of a vendor library inside the timed step: none can be - since round 6 the library links no vendor BLAS at all
+                   # (libmpmae_hip.so: `nm -u` shows the HIP runtime and libstdc++ only; the optional hipBLASLt route of rounds 4-5 is removed)
+                   vendor_kernels_per_step=0.0)
         if pieces:
             out["piece_times"] = pieces
         if world > 1:

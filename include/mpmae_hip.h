@@ -23,9 +23,8 @@
  *     workspace; work is enqueued on `stream` (a hipStream_t passed as void*). The library's only state is explicit:
  *     the process-wide option table (mpmae_set_option: developer A/B switches, defaults are the measured-best kernels), the
  *     launch-program handles a caller creates (mpmae_program_*: they own HIP events and side streams until destroyed), a
- *     cached device-property query (CU count / resident workgroups of the persistent kernels), and - ONLY after the caller has
- *     opted into the vendor route with mpmae_set_option(MPMAE_OPT_BLASLT, >= 1), which is OFF by default - one process-global
- *     hipblasLtHandle_t per device plus a plan cache (descriptor, layouts, algorithm, optional workspace) per call site;
+ *     cached device-property query (CU count / resident workgroups of the persistent kernels). The library links NO vendor BLAS
+ *     (round 6: the optional hipBLASLt route of rounds 4-5 is removed; `nm -u` shows the HIP runtime and libstdc++ only);
  *   - return value: 0 on success, otherwise the hipError_t of the failed launch.
  *
  * Row layout. A sparse stage holds only the visible patches: row = (n*keep + slot)*S*S + iy*S + ix
@@ -70,13 +69,8 @@ typedef struct MpmaeGemmArgs {
   const int* vis; const int* inv; const uint8_t* act; const uint8_t* act_src;
   int keep, L, S, Cseg, grid;
   int H;
-  float* ws; size_t ws_floats;       /* scratch for per-block statistic slabs (stats epilogues) and the stream-K partial slots */
-  unsigned* sk_flags;                /* optional (NULL): MPMAE_SK_FLAGS zero-initialised unsigneds owned by the caller, ONE buffer per stream.
-                                        With them (and ws_floats >= MPMAE_SK_WS_FLOATS) plain bf16 NT products of the shapes in MPMAE_OPT_SK
-                                        run on the stream-K schedule of csrc/gemm_sk.cuh, which leaves the flags zero after every launch */
+  float* ws; size_t ws_floats;       /* scratch for per-block statistic slabs (stats epilogues) */
 } MpmaeGemmArgs;
-#define MPMAE_SK_FLAGS 2048
-#define MPMAE_SK_WS_FLOATS ((size_t)256 * 128 * 256)      /* 256 workgroups x one 128 x 256 fp32 partial slot (32 MiB) */
 
 /* dW[n*sn + k*sk] += sum_m proP(P)[m,n]*proQ(Q)[m,k] ; db[n] += sum_m proP(P)[m,n] */
 typedef struct MpmaeWgradArgs {
@@ -145,11 +139,14 @@ typedef struct MpmaeImgArgs {
  *   which = 4: z = gelu(h)*scale + beta (stored to xn), out = x + z W2^T + b2    (GRN apply + pwconv2)
  *   which = 5: dh = (dz*scale + coef*gelu(h))*gelu'(h) stored OVER dz (= A), then dd = LayerNorm-backward(dh W1), dgamma, dbeta
  *   which = 6 (round 6; C = 40 / 80): T[C][H] += dout^T gelu(h), db2[C] += sum_rows dout - the pwconv2 weight gradient BEFORE the GRN affine, in
- *              one read of A = dout [M,C] and R = h [M,H] (csrc/rst.cuh), ws >= workgroups * (C*H + C) floats. Every consumer is linear in T:
- *              with W = staged pwconv2 weights [C][ldw], v0 = GRN scale [H], v1 = GRN beta [H] the slab fold adds S0[j] += sum_c W[c][j] db2[c],
- *              S1[j] += sum_c W[c][j] T[c][j] into s0 / s1 and the parameter gradients dW2[c][j] += v0[j] T[c][j] + v1[j] db2[c], db2 into
- *              fin_dgamma [C][H] / fin_dbeta [C] - the statistics pass (which = 1, out = NULL) AND the separate weight-gradient product over the same
- *              two tensors both go away. With W == NULL: s0 = T, s1 = db2 raw (added to), mpmae_grn_stats_from_wgrad as a separate second step
+ *              one read of A = dout [M,C] and R = h [M,H] (csrc/rst.cuh) into one fp32 slab row [C*H | C] per persistent workgroup in ws. Every
+ *              consumer is linear in T. With W = staged pwconv2 weights [C][ldw] each workgroup also emits its share of the GRN backward statistics
+ *              S0[j] = sum_c W[c][j] db2[c], S1[j] = sum_c W[c][j] T[c][j] as a small row [2][H] behind the big slabs; the call folds ONLY those into
+ *              s0 / s1 (added to) - what the fused backward kernel (which = 5) waits for - and writes the number of slab rows to *wg_rows (host); the
+ *              parameter gradients dW2[c][j] += scale[j] T[c][j] + beta[j] db2[c], db2 come from mpmae_rs_wgrad_fold(C, H, ws, rows, scale, beta, ..)
+ *              whenever the caller likes (the weight-gradient lane): ws must stay untouched until then, ws_floats >= workgroups * (C*H + C + 2H).
+ *              The statistics pass (which = 1, out = NULL) AND the separate weight-gradient product over the same two tensors both go away.
+ *              With W == NULL: s0 = T, s1 = db2 raw (added to), mpmae_grn_stats_from_wgrad as a separate second step
  *   (which = 2 / 3 - pwconv2 / pwconv1 data gradient on MATERIALISED z / dh, the resident-weights kernels of rounds 1-3 - were
  *   removed in round 4: invalid value)
  * C in {40,80,96,160,192,320,384}: weights streamed through LDS in chunks (csrc/rsc.cuh), any M;
@@ -196,13 +193,15 @@ typedef struct MpmaeRsArgs {
    * persistent workgroup accumulates U = dh^T x-hat and db1 = sum_rows dh over its row tiles (transposing LDS reads, MFMA) and writes ONE fp32 slab
    * row [H * C | H] to wg_ws; *wg_rows (HOST memory) receives the number of rows written. dh is then NOT stored (A is untouched), and neither
    * pwconv1's transpose-read product over dh and xn nor the forward's xn store is needed. mpmae_rs_wgrad_fold folds the slab rows into the
-   * parameter gradients. wg_ws_floats >= workgroups * (H * C + H) (2 workgroups per CU). */
+   * parameter gradients. wg_ws_floats >= workgroups * (H * C + H) (2 workgroups per CU). which = 6 writes ITS slab-row count to *wg_rows too. */
   float* wg_ws; size_t wg_ws_floats; int* wg_rows;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
-/* Second stage of MpmaeRsArgs.wg_ws: dW1[j][c] += ln_gamma[c] * sum_p U_p[j][c] + ln_beta[c] * sum_p d_p[j]; db1[j] += sum_p d_p[j] over the `rows` slab rows
- * [H * C | H] (H = 4C) of `slabs`; dW1 is pwconv1's weight gradient [H][C] (convnextv2_sparse.py:41 under autograd), C = 40. */
-int mpmae_rs_wgrad_fold(int C, const float* slabs, int rows, const float* ln_gamma, const float* ln_beta, float* dW1, float* db1, mpmae_stream_t stream);
+/* Second stage of the weight gradients accumulated inside main-lane kernels (MpmaeRsArgs.wg_ws; mpmae_rs which = 6): `rows` fp32 slab rows [A*B | A] ->
+ *   dW[a][b] += v0[b] * sum_p X_p[a][b] + v1[b] * sum_p d_p[a];   db[a] += sum_p d_p[a]
+ * pwconv1 (convnextv2_sparse.py:41 under autograd): (A, B) = (H, C), X = dh^T x-hat, v0 / v1 = LayerNorm gamma / beta;
+ * pwconv2 (:43): (A, B) = (C, H), X = dout^T gelu(h), v0 = GRN scale (1 + gamma Nx), v1 = GRN beta. B >= 32. */
+int mpmae_rs_wgrad_fold(int A, int B, const float* slabs, int rows, const float* v0, const float* v1, float* dW, float* db, mpmae_stream_t stream);
 int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t stream);
 
 /* ---- persistent per-sample stage kernels (csrc/ps.cuh) ----------------------------------------
@@ -368,53 +367,29 @@ int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* args, const uint32_t* scales_a, 
  * recorded programs are the only state it keeps - every other entry point is a pure function of its arguments. Defaults
  * are the measured-best choices on MI355X. */
 enum MpmaeOption {
-  MPMAE_OPT_LNB_BLOCKS = 0,   /* default 512: workgroup cap of the LayerNorm backward (one fp32 slab row of partial gamma / beta gradients per workgroup) */
-  MPMAE_OPT_DW_NT8,   /* default 512: threads per workgroup of the v5 depthwise kernels at S = 8 */
-  MPMAE_OPT_DW6_T8,   /* default 320: threads per workgroup, packed depthwise S = 8 */
-  MPMAE_OPT_DW6_T4,   /* default 320: ... S = 4 */
-  MPMAE_OPT_DW6_T2,   /* default 320: ... S = 2 */
-  MPMAE_OPT_DW6_GC,   /* default 1: 1: compile-time patch-grid side (7) in the packed depthwise */
-  MPMAE_OPT_DW,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = positional-tile / generic kernels (dwconv3.cuh, dwconv.cuh: S = 1 in fp32 mode, odd shapes). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
-  MPMAE_OPT_DWW_S1_NB,   /* default 0: persistent workgroups of the S = 1 depthwise weight gradient (0 = one per sample) */
-  MPMAE_OPT_DWW_NB,   /* default 128: persistent workgroups of the depthwise weight gradient */
+  MPMAE_OPT_DW = 0,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = positional-tile / generic kernels (dwconv3.cuh, dwconv.cuh: S = 1 in fp32 mode, odd shapes). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
   MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 6 = packed kernel for S >= 2; 5 = per-sample LDS-map kernels */
   MPMAE_OPT_NT_GLDS64,   /* default 1: direct-to-LDS NT GEMM also for 64-wide N tiles */
   MPMAE_OPT_NT_BK32,   /* default 1: 32-deep K slabs for K <= 512 */
   MPMAE_OPT_NT_GLDS,   /* default 1: direct-to-LDS operand slabs in the NT GEMM (2 = always 32-deep) */
   MPMAE_OPT_TN,   /* default 2: weight-gradient kernel: 2 = transpose-read (ds_read_b64_tr_b16), 1 = register-transposing */
-  MPMAE_OPT_TN_BLOCKS,   /* default 512: target workgroup count of a weight gradient (row splits) */
-  MPMAE_OPT_TN_MINROWS,   /* default 256: minimum rows per split */
-  MPMAE_OPT_TN_BLOCKS_BIG,   /* default 512: target workgroup count when dW >= 64K elements (two workgroups per CU: 4.53 -> 4.49 ms / step) */
   MPMAE_OPT_CS_SPLIT,   /* default 1: column-statistics kernel: split rows over workgroups */
-  MPMAE_OPT_RSC_BLOCKS,   /* default 1536: target workgroup count of the wide row-streaming kernels */
   MPMAE_OPT_RSC_PF,   /* default 1: LDS-staged GRN vectors / early operand issue in the narrow row-streaming kernels */
-  MPMAE_OPT_RSC_NC32,   /* (retired in round 3: 32-column weight chunks at C = 160 are the only variant; the value is ignored) */
-  MPMAE_OPT_RSC_SMALL,   /* (retired in round 4 with the resident-weights kernels of rs.cuh: C = 40 / 80 / 96 always run the chunked kernels; the value is ignored by the library - the ENGINE option rsc_small = 0 still sends those widths to the tiled GEMMs) */
   MPMAE_OPT_RSC_N40,   /* default 2: narrow-kernel variant at C = 40: 1 = two row tiles per wave, otherwise one */
   MPMAE_OPT_RSC_N80,   /* default 1: narrow-kernel variant at C = 80: 0 = two row tiles per wave, otherwise one */
-  MPMAE_OPT_STB_BLOCKS,   /* default 512: workgroup cap of the fused stem backward */
   MPMAE_OPT_TN3_BLOCKS,   /* default 128: target workgroup count of the DMA-ring weight-gradient kernel for the decoder / head shapes (gemm_tn3.cuh; 0 = use gemm_tn2). Re-swept after the matrix-core depthwise kernels rebalanced the lanes: 128 (half the CUs, half the slabs) 3.87-3.88 vs 256 3.91 ms in three interleaved pairs - the weight-gradient lane's kernels leave CUs to the main lane's */
-  MPMAE_OPT_TNG_BLOCKS,   /* default 512: target workgroup count of the GROUPED weight-gradient kernel (gemm_tng.cuh; 0 = one mpmae_wgrad per problem) */
-  MPMAE_OPT_NT4,   /* default 0 since the 128 x 128 kernel maps its tiles XCD-aware (late round 5: 3.561-3.571 vs 3.586-3.613 ms with 1); 1: 256 x 256-tile NT GEMM (gemm_nt4.cuh) for M >= 8192, N = 1024..2048 a multiple of 256, K % 64 == 0 (decoder pwconv1, pwconv2 data gradient); 2 = every shape with M >= 8192, N >= 256 (256 x 128 tiles under N = 1024); 0 = the 128 x 128 kernels */
+  MPMAE_OPT_TNG_BLOCKS,   /* default 256 (round 6, with the lighter weight-gradient lane: 3.428 / 3.435 vs 3.448 / 3.451 ms at 512, profiles/r06/option_sweep.txt; half the slab rows for its fold): target workgroup count of the GROUPED weight-gradient kernel (gemm_tng.cuh; 0 = one mpmae_wgrad per problem) */
   MPMAE_OPT_FOLD_GROUP,   /* default 0: 1 = mpmae_fold_group folds up to 16 records per launch (blockIdx.z = record) instead of one launch per record - measured SLOWER in the step (4.035-4.04 vs 4.005-4.026 ms, three interleaved pairs): the small launches slot in between the weight-gradient lane's kernels, the grouped one waits for all its producers. Round 5: the three folds behind the stem-tail backward kernel (ONE producer, the exposed tail of the step) are one grouped launch unless the value is < 0 */
   MPMAE_OPT_RSC_W5,   /* default 1: 80-row (5-wave) tiles in the narrow fused pointwise kernels at C = 160 when 64-row tiles need more than one round of workgroups and 80-row tiles do not */
-  MPMAE_OPT_BLASLT,   /* default 0 (round 5: every GEMM of the default step is this library's own kernel; the vendor route stays as a measured yardstick, tools/probes/blas_yardstick.py). 1: PLAIN dense bf16 GEMMs (no prologue, epilogue = bias / residual, no activity mask; M >= 4096, N >= 256, K >= 256, N K >= 512 Ki: the dense decoder's pwconv2 and the pwconv1 data gradient, the pixel heads and their data gradient) go to hipBLASLt, which runs them at 0.6-0.8 PF/s against 0.45 PF/s of gemm_nt_bf16_kernel (profiles/r04/blas_yardstick.txt); 0 = this library's kernels for everything */
-  MPMAE_OPT_NT5,   /* default 0: 1 = the deep-K NT kernel of gemm_nt5.cuh (128 x 256 tile, 64 x 128 wave tiles, 3-stage DMA ring with counted waits) for plain bf16 products with K >= 1024, N >= 256, M >= 2048 - row masks included - ahead of the vendor route */
   MPMAE_OPT_RSC_ATOMIC,   /* default 0: largest row-block count of a WIDE fused pointwise launch (mpmae_rs which = 0 / 1) whose GRN column statistics are added straight into s0 / s1 with hardware float atomics instead of slab rows + a second-stage fold launch (0 = never) */
-  MPMAE_OPT_SK,   /* default 0 (measured SLOWER than whole tiles in round 5: 51-56 vs 37-41 us at N = 512, K = 2048 - each workgroup pays two pipeline fills, a 128 KB publish and a 128 KB fix-up read serially, one workgroup per CU hides none of it; csrc/gemm_sk.cuh). 1: the stream-K NT kernel of gemm_sk.cuh (128 x 256 tiles cut into 64-deep K iterations, every CU takes the same number of iterations, partial tiles fixed up through write-through fp32 slots) for plain bf16 products (no prologue, epilogue = bias / residual / row mask) with K >= 1024, K % 64 == 0, N >= 256, M >= 2048 when the caller passes MpmaeGemmArgs.sk_flags: the dense decoder's pwconv2 and pwconv1 data gradient, the heads' data gradient, the stage-3 pwconv2 / pwconv1 data gradient. 2 = also K >= 512 (decoder pwconv1 / pwconv2.dgrad, pixel heads). 0 = whole-tile kernels */
   MPMAE_OPT_DET,   /* default 0: 1 = reproducible statistics: every second-stage fold runs as ONE row group per column block (fixed summation order, no atomics between row groups). With the engine option det = 1 (which also keeps the persistent stage kernel and its float atomics out of the program) two forwards of the same weights and inputs are bit-identical; -1 = the pre-round-4 behaviour of the wide pointwise kernels everywhere (one shared LDS statistics row, float atomics between the waves) for A/B: by default a row per wave is used wherever it does not cost a resident workgroup per CU */
   MPMAE_OPT_RSC1,   /* default 1: the WIDE fused pointwise kernels (mpmae_rs which = 0 / 1) at C = 160 / 320 in their one-shot form (csrc/rsc1.cuh: the workgroup's whole weight slice global -> LDS by DMA at the top, one barrier, no chunk loop); value = row tiles per wave (1 or 2); 0 = the chunk-streaming kernels of rsc.cuh */
-  MPMAE_OPT_RSC1_CPS,   /* default 0 = automatic (128 at C = 160, 64 at C = 320: a 40 KB slice, three workgroups per CU): output columns per workgroup of the one-shot wide kernels (64, or 128 at C = 160) */
-  MPMAE_OPT_RSC1_WGS,   /* default 0 = 3 per CU: target workgroup count of the one-shot wide kernels (a workgroup walks ceil(tiles / (target / column slices)) row tiles with its weight slice resident) */
   MPMAE_OPT_RSC1_ATOMIC,   /* default 100: the one-shot wide kernels add their column statistics straight into s0 / s1 with float atomics (no slab rows, no fold launch) when they run at most this many workgroup rows (0 = never; MPMAE_OPT_DET > 0 = never) */
   MPMAE_OPT_RSP,   /* default 1: the fused pointwise kernels at C = 40 / 80 in their persistent burst-load form (csrc/rsp.cuh: weights resident in LDS, a workgroup walks row tiles, every operand of the next tile requested under the arithmetic of the current one); value = row tiles of 16 rows per wave (1 or 2); 0 = the chunk-streaming kernels of rsc.cuh */
-  MPMAE_OPT_RSP_WGS,   /* default 0 = 3 per CU (which 0) / 2 per CU (which 1): workgroup count of the persistent burst-load kernels */
   MPMAE_OPT_RSP_NWV,   /* default 0 = automatic (8 for which = 5 at C = 80, else 4): waves per workgroup of the persistent NARROW kernels (one 16-row tile per wave) */
-  MPMAE_OPT_RSP_NWGS,   /* default 0 = as many as fit a CU's LDS, at most 2 per CU: workgroup count of the persistent NARROW kernels */
   MPMAE_OPT_RSP_NARROW,   /* default 2: which NARROW launches take the persistent burst-load kernels: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80 (measured: only which 5 at C = 40 gains, 88.6 -> 70 us) */
   MPMAE_OPT_RSN3,   /* default 5: the fused pointwise BACKWARD kernel at C = 160 (mpmae_rs which = 5, single GRN group, dz materialised) in its ring-pipelined form (csrc/rsn3.cuh: weight slabs by DMA into a three-slot LDS ring, rows two chunks ahead, one bare barrier per chunk); value = waves per workgroup (4 or 5); 0 = rsc_narrow */
   MPMAE_OPT_EVX,   /* default 1: in a launch program an op's cross-lane signal is the completion event of its last kernel launch (hipExtLaunchKernelGGL stopEvent) instead of a hipEventRecord - a barrier packet of its own - behind it: 1.65 us less per signal on the signalling lane (tools/probes/ext_event_probe.hip); 0 = hipEventRecord */
-  MPMAE_OPT_RST_WGS,   /* default 0 = 1 per CU with 16 waves (with 4 waves: 3 per CU at C = 40, 2 per CU at C = 80): persistent workgroups of the weight-gradient-as-statistics pass (mpmae_rs which = 6, csrc/rst.cuh); one fp32 slab row [C * H + C] each */
   MPMAE_OPT_RST_NW,   /* default 16: waves per workgroup of that pass (16: 1024 threads, 256-row tiles, one workgroup per CU - a quarter of the slab rows; 4: 256 threads, 64-row tiles, 2-3 per CU) */
   MPMAE_OPT_COUNT_
 };
@@ -554,11 +529,6 @@ int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int 
  * Bout == B is allowed (in place) - the engine passes a buffer of its own so that a backward can be repeated behind one forward. */
 int mpmae_head_scale(int dt, const void* B, void* Bout, int ldb, int D, int W, const uint8_t* col_mod, const float* coef, float* rowscale,
                      mpmae_stream_t stream);
-/* Row-split form (round 5) of mpmae_loss_pix_cont_rows (mode 0) / _fused (mode 2): `parts` workgroups per sample, each walking
- * ceil(grid / parts) patch rows; every record's `acc` must hold N * parts {sum, count} slots (slot n * parts + part) and the finalisation
- * is called with that many. */
-int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, int parts,
-                                   mpmae_stream_t stream);
 /* Categorical pixel losses, wave-per-patch form (forward bwd = 0 / gradient bwd = 1): same records, outputs and partial layout as
  * mpmae_loss_multi(kind 1); bwd = 2: forward + UNSCALED gradient in one pass (mpmae_loss_pix_cont_rows_fused). max_pk = largest p*p*K of the records (a multiple of 4, K <= 16); every record needs ld % 4 == 0 and
  * coff % 4 == 0 (vector accesses); 16 * max_pk elements of LDS. */
@@ -585,13 +555,6 @@ int mpmae_loss_finalize_guarded(const float* acc, int N, const float* log_vars, 
 int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
                 float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
                 mpmae_stream_t stream);
-/* One gradient bucket of the same update (round 5): elements [0, n) of the pointers given, with `nslots` workgroups whose g^2 partials land in
- * gnorm2[1 + slot0 ...]; the part with slot0 == 0 writes gnorm2[0] = total_slots (<= 4096, the sum of the parts' nslots). Every part of a step
- * runs behind that step's mpmae_hp_fetch; a bucket's part may run as soon as its gradients are final (and exchanged) and the last reader of its
- * fp32 parameters in the backward has finished - the reference's optimizer.step() (main_pretrain.py:312-320) cut along dist.plan_buckets. */
-int mpmae_adamw_part(float* p, const float* g, float* m, float* v, const float* hp, float beta1,
-                     float beta2, float eps, float wd, size_t n, const uint8_t* decay_mask, float* gnorm2,
-                     int slot0, int nslots, int total_slots, mpmae_stream_t stream);
 int mpmae_sumsq(const float* x, size_t n, float* out, mpmae_stream_t stream);
 /* hyper-parameter hand-over for replayed steps: copies record (*counter % slots) of a pinned,
  * device-visible ring of {lr, 1/(1-beta1^t), 1/sqrt(1-beta2^t), grad_scale} records into hp and
@@ -652,10 +615,6 @@ int mpmae_memcpy_h2d_async(void* dst, const void* src_pinned, size_t bytes, mpma
 
 /* library identification: returns the gfx arch the kernels were built for (950). */
 int mpmae_arch(void);
-/* Kernels of a VENDOR library (hipBLASLt, MPMAE_OPT_BLASLT >= 1) this process has issued through this library so far: 0 forever with the
- * default options. bench.py reports the per-step difference as "vendor_kernels_per_step". */
-long long mpmae_vendor_launches(void);
-
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ class GemmArgs(C.Structure):
                 ("vis", c_void_p), ("inv", c_void_p), ("act", c_void_p), ("act_src", c_void_p),
                 ("keep", c_int), ("L", c_int), ("S", c_int), ("Cseg", c_int), ("grid", c_int),
                 ("H", c_int),
-                ("ws", c_void_p), ("ws_floats", c_size_t), ("sk_flags", c_void_p)]
+                ("ws", c_void_p), ("ws_floats", c_size_t)]
 
 
 class WgradArgs(C.Structure):
@@ -152,8 +152,7 @@ class StemFrontArgs(C.Structure):
                 ("track_activity", c_int), ("act_out", c_void_p)]
 
 
-SK_FLAGS = 2048              # MPMAE_SK_FLAGS (include/mpmae_hip.h)
-OPT = {n: i for i, n in enumerate("LNB_BLOCKS DW_NT8 DW6_T8 DW6_T4 DW6_T2 DW6_GC DW DWW_S1_NB DWW_NB DWW NT_GLDS64 NT_BK32 NT_GLDS TN TN_BLOCKS TN_MINROWS TN_BLOCKS_BIG CS_SPLIT RSC_BLOCKS RSC_PF RSC_NC32 RSC_SMALL RSC_N40 RSC_N80 STB_BLOCKS TN3_BLOCKS TNG_BLOCKS NT4 FOLD_GROUP RSC_W5 BLASLT NT5 RSC_ATOMIC SK DET RSC1 RSC1_CPS RSC1_WGS RSC1_ATOMIC RSP RSP_WGS RSP_NWV RSP_NWGS RSP_NARROW RSN3 EVX RST_WGS RST_NW".split())}      # enum MpmaeOption (include/mpmae_hip.h)
+OPT = {n: i for i, n in enumerate("DW DWW NT_GLDS64 NT_BK32 NT_GLDS TN CS_SPLIT RSC_PF RSC_N40 RSC_N80 TN3_BLOCKS TNG_BLOCKS FOLD_GROUP RSC_W5 RSC_ATOMIC DET RSC1 RSC1_ATOMIC RSP RSP_NWV RSP_NARROW RSN3 EVX RST_NW".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 
@@ -201,7 +200,7 @@ SYMBOLS = {
     "mpmae_colstats": [c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t,
                        c_void_p],
     "mpmae_rs": [c_int, P(RsArgs), c_void_p],
-    "mpmae_rs_wgrad_fold": [c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    "mpmae_rs_wgrad_fold": [c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_ps_fwd": [P(PsArgs), c_void_p],
     "mpmae_quant_mx": [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "mpmae_gemm_mx": [c_int, P(GemmArgs), c_void_p, c_int, c_void_p, c_int, c_void_p],
@@ -224,7 +223,6 @@ SYMBOLS = {
     "mpmae_loss_pix_cont_rows": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_bwd": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_pix_cont_rows_fused": [c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "mpmae_loss_pix_cont_rows_split": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "mpmae_head_scale": [c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "mpmae_loss_pix_cat_waves": [c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_loss_finalize": [c_void_p, c_int, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -233,8 +231,6 @@ SYMBOLS = {
                                     c_void_p, c_void_p, c_int, c_int, c_void_p],
     "mpmae_adamw": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
                     c_size_t, c_void_p, c_void_p, c_void_p],
-    "mpmae_adamw_part": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float,
-                         c_size_t, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "mpmae_sumsq": [c_void_p, c_size_t, c_void_p, c_void_p],
     "mpmae_ln_fwd_down": [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int,
                           c_void_p, c_void_p],
@@ -260,7 +256,6 @@ SYMBOLS = {
 OTHER_SYMBOLS = {
     "mpmae_program_create": ([], c_void_p),
     "mpmae_program_destroy": ([c_void_p], None),
-    "mpmae_vendor_launches": ([], C.c_longlong),
 }
 
 _lib = None

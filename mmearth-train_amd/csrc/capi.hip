@@ -45,53 +45,29 @@ thread_local hipEvent_t g_stop_ev = nullptr;
 thread_local int g_launch_err = 0;
 
 int g_opt[MPMAE_OPT_COUNT_] = {
-    /* MPMAE_OPT_LNB_BLOCKS */ 512,
-    /* MPMAE_OPT_DW_NT8 */ 512,
-    /* MPMAE_OPT_DW6_T8 */ 320,
-    /* MPMAE_OPT_DW6_T4 */ 320,
-    /* MPMAE_OPT_DW6_T2 */ 320,
-    /* MPMAE_OPT_DW6_GC */ 1,
     /* MPMAE_OPT_DW */ 8,
-    /* MPMAE_OPT_DWW_S1_NB */ 0,
-    /* MPMAE_OPT_DWW_NB */ 128,
     /* MPMAE_OPT_DWW */ 7,
     /* MPMAE_OPT_NT_GLDS64 */ 1,
     /* MPMAE_OPT_NT_BK32 */ 1,
     /* MPMAE_OPT_NT_GLDS */ 1,
     /* MPMAE_OPT_TN */ 2,
-    /* MPMAE_OPT_TN_BLOCKS */ 512,
-    /* MPMAE_OPT_TN_MINROWS */ 256,
-    /* MPMAE_OPT_TN_BLOCKS_BIG */ 512,
     /* MPMAE_OPT_CS_SPLIT */ 1,
-    /* MPMAE_OPT_RSC_BLOCKS */ 1536,
     /* MPMAE_OPT_RSC_PF */ 1,
-    /* MPMAE_OPT_RSC_NC32 */ 1,
-    /* MPMAE_OPT_RSC_SMALL */ 1,
     /* MPMAE_OPT_RSC_N40 */ 2,
     /* MPMAE_OPT_RSC_N80 */ 1,
-    /* MPMAE_OPT_STB_BLOCKS */ 512,
     /* MPMAE_OPT_TN3_BLOCKS */ 128,
-    /* MPMAE_OPT_TNG_BLOCKS */ 512,
-    /* MPMAE_OPT_NT4 */ 0,
+    /* MPMAE_OPT_TNG_BLOCKS */ 256,
     /* MPMAE_OPT_FOLD_GROUP */ 0,
     /* MPMAE_OPT_RSC_W5 */ 1,
-    /* MPMAE_OPT_BLASLT */ 0,
-    /* MPMAE_OPT_NT5 */ 0,
     /* MPMAE_OPT_RSC_ATOMIC */ 0,
-    /* MPMAE_OPT_SK */ 0,
     /* MPMAE_OPT_DET */ 0,
     /* MPMAE_OPT_RSC1 */ 1,
-    /* MPMAE_OPT_RSC1_CPS */ 0,
-    /* MPMAE_OPT_RSC1_WGS */ 0,
     /* MPMAE_OPT_RSC1_ATOMIC */ 100,
     /* MPMAE_OPT_RSP */ 1,
-    /* MPMAE_OPT_RSP_WGS */ 0,
     /* MPMAE_OPT_RSP_NWV */ 0,
-    /* MPMAE_OPT_RSP_NWGS */ 0,
     /* MPMAE_OPT_RSP_NARROW */ 2,
     /* MPMAE_OPT_RSN3 */ 5,
     /* MPMAE_OPT_EVX */ 1,
-    /* MPMAE_OPT_RST_WGS */ 0,
     /* MPMAE_OPT_RST_NW */ 16,
 };
 
@@ -199,7 +175,7 @@ static int ln_bwd_impl(int dt, const void* dy, int dy_div, float dy_scale, const
     const int per = cdiv(nvec, G);
     const int rpw = 64 / G;
     int lncap;
-    lncap = g_opt[MPMAE_OPT_LNB_BLOCKS];   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
+    lncap = 512 /* LNB_BLOCKS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;   // measured: 512 -> 50 us, 1024 -> 36 us, 2048 -> 40 us (slab reduce grows)
     // one fp32 slab row (2C floats) per workgroup, folded from its 4 waves in LDS. Measured (M = 12 544, C = 512): 18 / 21 / 28 / 37 us
     // at 512 / 1024 / 2048 / 4096 workgroups - the per-wave prologue (gamma / beta vectors) and the fold are the fixed costs, so few
     // long-running waves win; narrow rows (C < 256: many rows per wave iteration) keep twice the cap
@@ -312,7 +288,7 @@ static bool launch_dw_v5(const MpmaeDwArgs& a, hipStream_t st) {
   }
   dim3 g(a.g.N, a.C / CW);
   int nt8;
-  nt8 = g_opt[MPMAE_OPT_DW_NT8];
+  nt8 = 512 /* DW_NT8: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   // S = 8: the 62x62 map takes 61 KB, so two workgroups per CU; 8 waves each keep 4 waves per SIMD busy
   LAUNCH((dwconv7_v5_kernel<T, S>), g, dim3(S == 8 ? nt8 : 256), lds, st, a);
   return true;
@@ -323,7 +299,7 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st, 
   constexpr int CW = 64 / S;
   size_t lds = dw5_map_bytes<T, S>(a.g.grid);
   int nt8;
-  nt8 = g_opt[MPMAE_OPT_DW_NT8];
+  nt8 = 512 /* DW_NT8: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   const int nthreads = S == 8 ? nt8 : 256;
   const size_t red = (size_t)(nthreads / 64) * 50 * CW * sizeof(float);
   if (red > lds) lds = red;
@@ -347,9 +323,9 @@ static bool launch_dwwg_v5(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st, 
 
 static int dw6_threads(int S) {     // waves per workgroup (each wave walks two patches at a time)
   int t8 = -1, t4 = -1, t2 = -1;
-  t8 = g_opt[MPMAE_OPT_DW6_T8];
-  t4 = g_opt[MPMAE_OPT_DW6_T4];
-  t2 = g_opt[MPMAE_OPT_DW6_T2];
+  t8 = 320 /* DW6_T8: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
+  t4 = 320 /* DW6_T4: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
+  t2 = 320 /* DW6_T2: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   return S == 8 ? t8 : S == 4 ? t4 : t2;
 }
 
@@ -360,7 +336,7 @@ static bool launch_dw_v6(const MpmaeDwArgs& a, hipStream_t st) {
   if (lds > 64 * 1024) return false;
   dim3 g(a.g.N, a.C / CW);
   int gc;
-  gc = g_opt[MPMAE_OPT_DW6_GC];
+  gc = 1 /* DW6_GC: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   // compile-time map pitch: measured faster only at S = 2 for the forward / data-gradient kernel (17.7 vs 18.8 us; slower at
   // S = 4, 8), decisive for the weight-gradient kernel (220 -> 128 VGPRs)
   if (gc && S == 2 && a.g.grid == 7) LAUNCH((dwconv7_v6_kernel<S, 7>), g, dim3(dw6_threads(S)), lds, st, a);
@@ -531,7 +507,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
     int nbs1;
-    nbs1 = g_opt[MPMAE_OPT_DWW_S1_NB];
+    nbs1 = 0 /* DWW_S1_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
     const int want = nbs1 > 0 ? nbs1 : (cdiv(a->C, 64) <= 5 ? 128 : 64);      // ~512-640 workgroups in total (measured)
     int nb = a->g.N < want ? a->g.N : want;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
@@ -546,7 +522,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     const size_t per = (size_t)50 * a->C;
     if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
     int nbmax;
-    nbmax = g_opt[MPMAE_OPT_DWW_NB];
+    nbmax = 128 /* DWW_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
     int nb = a->g.N < nbmax ? a->g.N : nbmax;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     bool ok = false;
@@ -627,10 +603,10 @@ int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, flo
   }
   int nb = 0;
   if (s1) {
-    const int want = g_opt[MPMAE_OPT_DWW_S1_NB] > 0 ? g_opt[MPMAE_OPT_DWW_S1_NB] : (cdiv(a0.C, 64) <= 5 ? 128 : 64);
+    const int want = 0 /* DWW_S1_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* DWW_S1_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : (cdiv(a0.C, 64) <= 5 ? 128 : 64);
     nb = a0.g.N < want ? a0.g.N : want;
   } else if (v5) {
-    nb = a0.g.N < g_opt[MPMAE_OPT_DWW_NB] ? a0.g.N : g_opt[MPMAE_OPT_DWW_NB];
+    nb = a0.g.N < 128 /* DWW_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ ? a0.g.N : 128 /* DWW_NB: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   }
   if (nb > 0 && (size_t)nb * per * count > ws_floats) nb = (int)(ws_floats / (per * count));
   if (nb < 1 || count == 1) {                    // one by one, each on the scratch given here
@@ -792,8 +768,8 @@ int mpmae_loss_multi(int dt, int bwd, int kind, const void* dev_args, int count,
   RET();
 }
 
-static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s, int split = 0) {
-  const int gx = split > 1 ? N * split : N;
+static int loss_pix_cont_rows_impl(int dt, int bwd, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
+  const int gx = N, split = 0;      // (k workgroups per sample, each walking a share of the patch rows: measured slower in round 5 and removed; the kernel keeps the parameter)
   if (bwd < 0 || bwd > 2) return (int)hipErrorInvalidValue;
   if (!dev_args || count < 1 || N < 1 || maxC < 1 || p < 1 || (H & 3) || ((p * p) & 3)) return (int)hipErrorInvalidValue;
   const size_t lds = (size_t)maxC * (p * H + 4) * 4;
@@ -823,11 +799,6 @@ int mpmae_loss_pix_cont_rows_bwd(int dt, const void* dev_args, int count, int N,
 
 int mpmae_loss_pix_cont_rows_fused(int dt, const void* dev_args, int count, int N, int maxC, int p, int H, mpmae_stream_t s) {
   return loss_pix_cont_rows_impl(dt, 2, dev_args, count, N, maxC, p, H, s);
-}
-
-int mpmae_loss_pix_cont_rows_split(int dt, int mode, const void* dev_args, int count, int N, int maxC, int p, int H, int parts, mpmae_stream_t s) {
-  if ((mode != 0 && mode != 2) || parts < 1 || parts > H / p) return (int)hipErrorInvalidValue;
-  return loss_pix_cont_rows_impl(dt, mode, dev_args, count, N, maxC, p, H, s, parts);
 }
 
 int mpmae_loss_pix_cat_waves(int dt, int bwd, const void* dev_args, int count, int N, int max_pk, mpmae_stream_t s) {
@@ -863,15 +834,6 @@ int mpmae_adamw(float* p, const float* g, float* m, float* v, const float* hp, f
                 float wd, size_t n, const uint8_t* decay, float* gnorm2, mpmae_stream_t s) {
   const int nb = grid1d((long long)n, 256, 4096);
   LAUNCH(adamw_kernel, dim3(nb), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2, eps, wd, n, decay, gnorm2, 0, nb);
-  RET();
-}
-
-int mpmae_adamw_part(float* p, const float* g, float* m, float* v, const float* hp, float beta1, float beta2, float eps,
-                     float wd, size_t n, const uint8_t* decay, float* gnorm2, int slot0, int nslots, int total_slots, mpmae_stream_t s) {
-  if (!p || !g || !m || !v || !hp || !decay || n == 0 || nslots < 1 || slot0 < 0 || slot0 + nslots > total_slots || total_slots > 4096)
-    return (int)hipErrorInvalidValue;
-  // exactly nslots workgroups: every partial slot of the part is written by every launch (a workgroup without elements writes 0)
-  LAUNCH(adamw_kernel, dim3(nslots), dim3(256), 0, S_(s), p, g, m, v, hp, beta1, beta2, eps, wd, n, decay, gnorm2, slot0, total_slots);
   RET();
 }
 
@@ -1003,7 +965,7 @@ int mpmae_stem_tail(int dt, int bwd, const MpmaeStemTailArgs* a, mpmae_stream_t 
   p.g1 = a->g1; p.b1 = a->b1; p.w = a->w; p.wb = a->wb; p.g2 = a->g2; p.b2 = a->b2;
   p.act_in = a->act_in; p.act_out = a->act_out; p.ws = a->ws; p.M = a->M; p.C = a->C;
   int stcap;
-  stcap = g_opt[MPMAE_OPT_STB_BLOCKS];
+  stcap = 512 /* STB_BLOCKS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   int blocks = grid1d((long long)cdiv(a->M, rpw) * 64, 256, bwd ? stcap : 4096);
   if (bwd) {
     if (!a->ws || !a->dg1 || !a->db1 || !a->dw || !a->dwb || !a->dg2 || !a->db2) return (int)hipErrorInvalidValue;

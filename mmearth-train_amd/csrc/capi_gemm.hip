@@ -8,9 +8,6 @@
 #include "gemm_nt3.cuh"
 #include "gemm_tn3.cuh"
 #include "gemm_tng.cuh"
-#include "gemm_nt4.cuh"
-#include "gemm_nt5.cuh"
-#include "gemm_sk.cuh"
 #include "grn_group.cuh"
 
 static bool gemm_fast_ok(int dt, int pro, int epi, const GemmP& a);
@@ -45,188 +42,10 @@ static int launch_gemm(int pro, int epi, const GemmP& a, hipStream_t st) {
 }
 
 
-// ------------------------------------------------------------------------------------------
-// Vendor BLAS for PLAIN dense GEMMs (MPMAE_OPT_BLASLT). profiles/r04/blas_yardstick.txt measures hipBLASLt on every GEMM shape of the
-// step next to this library's kernels: ours are ahead on 12 of 16 (every weight gradient, every fused pointwise product, the
-// 256 x 256-tile shapes), the vendor's deep-K kernels are ahead on the dense decoder's N = 512, K = 2048 products and the pixel heads
-// (M = 12 544: 32-41 us against 48-59 us of gemm_nt_bf16_kernel, 0.45-0.6 PF/s: 128 x 128 tiles move 1.27x the operand bytes of the vendor's
-// 128 x 256 tiles through the same ~9-10 TB/s of L2 -> LDS fill, and whole tiles leave CUs idle where the vendor's stream-K schedule does not).
-// Only launches that ARE a library GEMM go there: bf16, no prologue, epilogue = (+ bias) (+ residual), no activity mask; everything
-// fused (LayerNorm / GRN prologues, statistics epilogues, gathers, masks) stays on this library's kernels.
-// Row-major C[M][N] = A[M][K] W[N][K]^T is the column-major product C^T = W^T-stored-as-[K x N] (op T) x A-stored-as-[K x M] (op N).
-// Plans (descriptor + heuristic's first workspace-free algorithm) are cached per call site.
-// ------------------------------------------------------------------------------------------
-#include <hipblaslt/hipblaslt.h>
-#include <array>
-#include <map>
-#include <mutex>
-#include <atomic>
-struct LtPlan {
-  hipblasLtMatmulDesc_t desc = nullptr;
-  hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr, ld = nullptr;
-  hipblasLtMatmulAlgo_t algo;
-  hipblasLtHandle_t handle = nullptr;           // the handle of the device the plan was made on
-  void* ws = nullptr; size_t ws_bytes = 0;      // owned by the plan (= call site): such GEMMs are all issued on ONE lane, in order
-  bool ok = false;
-};
-// one handle per DEVICE (a handle binds the device that was current at its creation: a second device of the process must not reuse it)
-static std::map<int, hipblasLtHandle_t> g_lt_by_dev;
-static std::mutex g_lt_mu;
-static std::atomic<long long> g_vendor_launches{0};
-long long mpmae_vendor_launches(void) { return g_vendor_launches.load(std::memory_order_relaxed); }
-static std::map<std::array<long long, 11>, LtPlan> g_lt_plans;
-
-// The library is compiled against ROCm's hipblaslt headers but binds at run time to whichever libhipblaslt the process loaded first
-// (torch's bundled copy): the heuristic-result / algorithm structs are passed BY LAYOUT, so a different major.minor than the build-time
-// headers disables the route (the caller falls through to this library's kernels) instead of risking silent corruption.
-static bool lt_version_ok(hipblasLtHandle_t h) {
-  static int ok = -1;
-  if (ok < 0) {
-    int v = 0;
-    ok = (hipblasLtGetVersion(h, &v) == HIPBLAS_STATUS_SUCCESS && (v / 100 == HIPBLASLT_VERSION_MAJOR * 1000 + HIPBLASLT_VERSION_MINOR || v / 100 == HIPBLASLT_VERSION_MAJOR * 100 + HIPBLASLT_VERSION_MINOR)) ? 1 : 0;      // (major * 100000 + minor * 100 + patch; older releases major * 10000 + ...)
-    if (!ok) fprintf(stderr, "[mpmae] hipBLASLt run-time version %d does not match the build-time headers %d.%d: vendor route disabled\n",
-                     v, HIPBLASLT_VERSION_MAJOR, HIPBLASLT_VERSION_MINOR);
-  }
-  return ok == 1;
-}
-static hipblasLtHandle_t lt_handle(int dev) {
-  auto it = g_lt_by_dev.find(dev);
-  if (it != g_lt_by_dev.end()) return it->second;
-  hipblasLtHandle_t h = nullptr;
-  if (hipblasLtCreate(&h) != HIPBLAS_STATUS_SUCCESS) h = nullptr;
-  // (MPMAE_OPT_BLASLT >= 10: a developer's "measure it anyway" for the yardstick runs - level = value - 10 - on a box whose bundled
-  // hipBLASLt differs from the build-time headers; this image: torch ships 1.0.0, ROCm's headers are 1.2)
-  if (h && g_opt[MPMAE_OPT_BLASLT] < 10 && !lt_version_ok(h)) { hipblasLtDestroy(h); h = nullptr; }
-  g_lt_by_dev[dev] = h;
-  return h;
-}
-
-static const LtPlan* lt_plan(const GemmP& a, bool resid) {
-  std::lock_guard<std::mutex> lock(g_lt_mu);
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  const std::array<long long, 11> key = {a.M, a.N, a.K, a.lda, a.ldb, a.ldc, resid ? a.ldr : 0, resid ? 1 : 0,
-                                         (long long)(uintptr_t)a.bias, g_opt[MPMAE_OPT_BLASLT], dev};
-  auto it = g_lt_plans.find(key);
-  if (it != g_lt_plans.end()) return it->second.ok ? &it->second : nullptr;
-  LtPlan& pl = g_lt_plans[key];
-  hipblasLtHandle_t g_lt = lt_handle(dev);
-  if (!g_lt) return nullptr;
-  pl.handle = g_lt;
-  if (hipblasLtMatmulDescCreate(&pl.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) return nullptr;
-  const int32_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
-  bool good = hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS &&
-              hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) == HIPBLAS_STATUS_SUCCESS;
-  if (a.bias) {
-    const uint32_t epi = HIPBLASLT_EPILOGUE_BIAS;
-    const int32_t btype = HIP_R_32F;
-    const void* bp = a.bias;
-    good = good && hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)) == HIPBLAS_STATUS_SUCCESS &&
-           hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &btype, sizeof(btype)) == HIPBLAS_STATUS_SUCCESS &&
-           hipblasLtMatmulDescSetAttribute(pl.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) == HIPBLAS_STATUS_SUCCESS;
-  }
-  good = good && hipblasLtMatrixLayoutCreate(&pl.la, HIP_R_16BF, a.K, a.N, a.ldb) == HIPBLAS_STATUS_SUCCESS &&
-         hipblasLtMatrixLayoutCreate(&pl.lb, HIP_R_16BF, a.K, a.M, a.lda) == HIPBLAS_STATUS_SUCCESS &&
-         hipblasLtMatrixLayoutCreate(&pl.lc, HIP_R_16BF, a.N, a.M, resid ? a.ldr : a.ldc) == HIPBLAS_STATUS_SUCCESS &&
-         hipblasLtMatrixLayoutCreate(&pl.ld, HIP_R_16BF, a.N, a.M, a.ldc) == HIPBLAS_STATUS_SUCCESS;
-  if (!good) return nullptr;
-  hipblasLtMatmulPreference_t pref = nullptr;
-  if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return nullptr;
-  const uint64_t wsmax = g_opt[MPMAE_OPT_BLASLT] % 10 >= 2 ? (uint64_t)64 << 20 : 0;
-  hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
-  constexpr int NCAND = 8;
-  hipblasLtMatmulHeuristicResult_t res[NCAND];
-  int n = 0;
-  const hipblasStatus_t hs = hipblasLtMatmulAlgoGetHeuristic(g_lt, pl.desc, pl.la, pl.lb, pl.lc, pl.ld, pref, NCAND, res, &n);
-  hipblasLtMatmulPreferenceDestroy(pref);
-  if (hs != HIPBLAS_STATUS_SUCCESS) return nullptr;
-  // (timing every workspace-free candidate once per call site and keeping the fastest was tried: the heuristic's first choice is already it)
-  for (int i = 0; i < n; ++i)
-    if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= wsmax) {
-      if (res[i].workspaceSize > 0 && hipMalloc(&pl.ws, res[i].workspaceSize) != hipSuccess) { pl.ws = nullptr; continue; }
-      pl.ws_bytes = res[i].workspaceSize; pl.algo = res[i].algo; pl.ok = true;
-      break;
-    }
-  return pl.ok ? &pl : nullptr;
-}
-
-// 0 = issued (or recorded), -1 = not a library GEMM / no plan: the caller falls through to this library's kernels
-static int try_blaslt(int dt, int pro, int epi, const GemmP& a, hipStream_t st) {
-  if (!g_opt[MPMAE_OPT_BLASLT] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || a.act) return -1;
-  if (a.M < 4096 || a.N < 256 || a.K < 256 || (long long)a.N * a.K < 512LL * 1024) return -1;
-  if (g_opt[MPMAE_OPT_BLASLT] % 10 < 3 && g_opt[MPMAE_OPT_NT4] && a.M >= 8192 && a.N >= 1024 && a.N <= 2048 && a.N % 256 == 0 && a.K % 64 == 0 && a.K <= 1024)
-    return -1;      // the 256 x 256-tile kernel of gemm_nt4.cuh holds its own there (64 vs 67 us, 60 vs 65 us stand-alone)
-  if (((a.K | a.N | a.lda | a.ldb | a.ldc) & 7) || (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15)) return -1;
-  const bool resid = epi == EPI_RESID;
-  if (resid && (!a.R || (a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
-  const LtPlan* pl = lt_plan(a, resid);
-  if (!pl) return -1;
-  const void* A = a.A; const void* W = a.B; const void* R = resid ? a.R : a.C; void* D = a.C;
-  submit(st, [=](hipStream_t s_) {
-    g_vendor_launches.fetch_add(1, std::memory_order_relaxed);
-    const float alpha = 1.f, beta = resid ? 1.f : 0.f;
-    const hipblasStatus_t e = hipblasLtMatmul(pl->handle, pl->desc, &alpha, W, pl->la, A, pl->lb, &beta, R, pl->lc, D, pl->ld, &pl->algo, pl->ws, pl->ws_bytes, s_);
-    if (e != HIPBLAS_STATUS_SUCCESS && !g_launch_err) g_launch_err = 100000 + (int)e;
-  });
-  return launch_status();
-}
-
-// deep-K NT kernel (gemm_nt5.cuh): plain products with K >= 1024 (MPMAE_OPT_NT5); -1 = not taken
-static int try_nt5(int dt, int pro, int epi, const GemmP& a0, hipStream_t st) {
-  if (!g_opt[MPMAE_OPT_NT5] || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID)) return -1;
-  if (a0.M < 2048 || a0.N < 256 || a0.K < 1024 || (a0.K % NT5_BK) || ((a0.N | a0.lda | a0.ldb | a0.ldc) & 7)) return -1;
-  if (((uintptr_t)a0.A | (uintptr_t)a0.B | (uintptr_t)a0.C) & 15) return -1;
-  GemmP a = a0;
-  if (epi == EPI_STORE) a.R = nullptr;
-  if (a.R && ((a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT5_LDS) != hipSuccess) return (int)hipGetLastError();
-    attr = true;
-  }
-  const int mtiles = cdiv(a.M, NT5_BM), ntiles = cdiv(a.N, NT5_BN);
-  LAUNCH(gemm_nt5_kernel, dim3(8 * cdiv(mtiles, 8) * ntiles), dim3(256), NT5_LDS, st, a, mtiles, ntiles);
-  return launch_status();
-}
-
-// stream-K NT kernel (gemm_sk.cuh, MPMAE_OPT_SK): plain products, deep K; -1 = not taken
-static int try_sk(int dt, int pro, int epi, const GemmP& a0, hipStream_t st) {
-  const int lvl = g_opt[MPMAE_OPT_SK];
-  if (!lvl || dt != 1 || pro != PRO_NONE || (epi != EPI_STORE && epi != EPI_RESID) || !a0.sk_flags || !a0.ws) return -1;
-  if (a0.M < 2048 || a0.N < 256 || a0.K < (lvl >= 2 ? 512 : 1024) || (a0.K % NT5_BK) || ((a0.N | a0.lda | a0.ldb | a0.ldc) & 7)) return -1;
-  if (((uintptr_t)a0.A | (uintptr_t)a0.B | (uintptr_t)a0.C | (uintptr_t)a0.ws) & 15) return -1;
-  GemmP a = a0;
-  if (epi == EPI_STORE) a.R = nullptr;
-  if (a.R && ((a.ldr & 7) || ((uintptr_t)a.R & 15))) return -1;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_sk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT5_LDS) != hipSuccess) return (int)hipGetLastError();
-    attr = true;
-  }
-  SkP sk;
-  sk.part = a.ws; sk.flags = a.sk_flags;
-  sk.mtiles = cdiv(a.M, NT5_BM); sk.ntiles = cdiv(a.N, NT5_BN);
-  // one workgroup per CU (144 KB of LDS each), a multiple of 8 (workgroup b -> XCD b % 8), at least ~2 iterations per workgroup
-  // Q = G groups x ntiles column tiles per XCD (gemm_sk.cuh), as many whole groups as the XCD has CUs; >= ~2 iterations per workgroup
-  int cus8 = ps_num_cus() / 8;
-  if (cus8 < 1) cus8 = 32;
-  int G = cus8 / sk.ntiles;
-  if (G < 1) return -1;                                     // (more column tiles than CUs per XCD: whole tiles)
-  const long long rb_iters = (long long)(sk.mtiles / 8 > 0 ? sk.mtiles / 8 : 1) * (a.K / NT5_BK);      // per XCD
-  while (G > 1 && rb_iters / G < 2) G /= 2;
-  const int Q = G * sk.ntiles;
-  if (sk.mtiles < 8 || 8 * Q > MPMAE_SK_FLAGS || a.ws_floats < (size_t)8 * Q * SK_SLOT_FLOATS) return -1;
-  LAUNCH(gemm_sk_kernel, dim3(8 * Q), dim3(256), NT5_LDS, st, a, sk);
-  return launch_status();
-}
-
 int mpmae_gemm(int dt, int pro, int epi, const MpmaeGemmArgs* args, mpmae_stream_t s) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return (int)hipErrorInvalidValue;
   if ((epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS) && args->rpg < args->M && args->rpg < 43)
     return (int)hipErrorInvalidValue;   // a 128-row tile may span at most GMAXG statistics groups
-  { const int r = try_nt5(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
-  { const int r = try_sk(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
-  { const int r = try_blaslt(dt, pro, epi, *args, S_(s)); if (r >= 0) return r; }
   if (gemm_fast_ok(dt, pro, epi, *args)) return launch_gemm_fast(epi, *args, S_(s));
   const bool stats = (epi == EPI_GELU_SUMSQ || epi == EPI_DZ_STATS);
   const bool single = stats && args->rpg >= args->M;
@@ -481,32 +300,11 @@ static int launch_nt3_k(const GemmP& a, const Nt3Scales& sc, hipStream_t st) {
   return launch_status();
 }
 
-// 256-row tiles, 8 waves, 32 x 32 x 16 MFMA, DMA double buffer (gemm_nt4.cuh): the decoder / head shapes
-template <int BN>
-static int launch_nt4(const GemmP& a, hipStream_t st) {
-  using Cf = Nt4Cfg<BN>;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_nt4_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS) != hipSuccess)
-      return (int)hipGetLastError();
-    attr = true;
-  }
-  const int tm = cdiv(a.M, NT4_BM), tn = cdiv(a.N, BN);
-  LAUNCH((gemm_nt4_kernel<BN>), dim3(cdiv(tm, 8) * 8 * tn), dim3(512), Cf::LDS, st, a, tm, tn);
-  return launch_status();
-}
-
 static int launch_gemm_fast(int epi, GemmP a, hipStream_t st) {
   if (epi == EPI_STORE) a.R = nullptr;
-  // measured (tools/gemm_probe.py, profiles/r04/gemm_probe.txt): the 256 x 256 tile wins where its tile count fills the 256 CUs in
-  // at most two even rounds (decoder pw1 / pw2.dgrad, N = 2048: 49.5 vs 55.3 us) and loses on 539 tiles (pixel heads, N = 2816:
-  // 73 vs 65 us); the 256 x 128 variant ties with the 128 x 128 kernels (N = 512). NT4 = 2 takes it for every eligible shape.
-  const int nt4 = g_opt[MPMAE_OPT_NT4];
-  if (nt4 && (epi == EPI_STORE || epi == EPI_RESID) && a.K % NT4_BK == 0 && a.M >= 8192 && a.N >= 256 &&
-      !(((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C | (uintptr_t)a.R) & 15) &&
-      (nt4 >= 2 || (a.N % 256 == 0 && a.N >= 1024 && a.N <= 2048))) {
-    return a.N >= 1024 ? launch_nt4<256>(a, st) : launch_nt4<128>(a, st);
-  }
+  // (a 256 x 256-tile 8-wave kernel, a deep-K 128 x 256 ring kernel and a stream-K schedule for these products were built in rounds 4-5, measured
+  //  no faster in the step once the 128 x 128 kernel mapped its tiles XCD-aware, and removed in round 6: profiles/r05/ab_nt4_after_xcd.txt, ab_nt4_nt5.txt,
+  //  stream_k_probe.txt)
   const int w128 = cdiv(a.N, 128) * 128 - a.N, w64 = cdiv(a.N, 64) * 64 - a.N;
   int err = (w64 < w128) ? launch_gemm_fast_bn<64>(epi, a, st) : launch_gemm_fast_bn<128>(epi, a, st);
   if (err) return err;
@@ -608,10 +406,10 @@ static int launch_wgrad_tn2(WgradP a, hipStream_t st, bool qgrn) {
   else { nt = 4; kt = 4; }
   const int tiles = cdiv(WX, 16 * nt) * cdiv(WY, 64 * kt);
   int target = -1, minrows = -1;
-  target = g_opt[MPMAE_OPT_TN_BLOCKS];
-  minrows = g_opt[MPMAE_OPT_TN_MINROWS];
+  target = 512 /* TN_BLOCKS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
+  minrows = 256 /* TN_MINROWS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
   int bigt;
-  bigt = g_opt[MPMAE_OPT_TN_BLOCKS_BIG];   // measured in-step: 512 -> 5.59, 256 -> 5.54, 128 -> 5.86 ms
+  bigt = 512 /* TN_BLOCKS_BIG: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;   // measured in-step: 512 -> 5.59, 256 -> 5.54, 128 -> 5.86 ms
   // large dW (stage 2+, decoder, heads): every split writes and the second stage re-reads a full fp32 copy of dW
   const int tgt = (bigt > 0 && (size_t)a.Nn * a.Kk >= 65536) ? bigt : target;
   int splits = cdiv(tgt, tiles);

@@ -31,23 +31,27 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   const int rowblocks = cdiv(a.M, 64 * RT);
   if (which == 6) {
     // T = dout^T gelu(h) and db2 = sum_rows dout (rst.cuh): A = dout [M][C], R = h [M][H]; ws = one slab row [C * H + C] per persistent workgroup.
-    // With W = staged W2 [C][ldw], v0 = GRN scale, v1 = GRN beta the fold produces what T is for: s0 = S0 [H], s1 = S1 [H], fin_dgamma = dW2 [C][H],
-    // fin_dbeta = db2 [C] (all ADDED to). Without W: s0 = T [C * H], s1 = db2 [C] raw (added to; mpmae_grn_stats_from_wgrad is the separate second step)
+    // With W = staged W2 [C][ldw]: s0 = S0 [H], s1 = S1 [H] (the GRN backward statistics, ADDED to) - see below. Without W: s0 = T [C * H], s1 = db2 [C] raw
+    // (added to; mpmae_grn_stats_from_wgrad is the separate second step)
     if constexpr (KC == 40 || KC == 80) {
       if (!a.A || !a.R || !a.s0 || !a.s1 || !a.ws || HN % 160) return (int)hipErrorInvalidValue;
       if (((uintptr_t)a.A | (uintptr_t)a.R) & 15) return (int)hipErrorInvalidValue;
       const int nw = g_opt[MPMAE_OPT_RST_NW] == 4 ? 4 : 16, ny = HN / 160;
       const int ntiles = cdiv(a.M, 16 * nw);
       // (tools/probes/rst_probe.py. NW = 4: C = 40 flat between 2 and 3 per CU, 33.9-34.5 us; C = 80 best at 2 per CU over both column slices: 27.1 vs 33.4 us at 3)
-      const int wgs = g_opt[MPMAE_OPT_RST_WGS] > 0 ? g_opt[MPMAE_OPT_RST_WGS] : (nw == 16 ? 1 : (KC == 40 ? 3 : 2)) * ps_num_cus();
+      const int wgs = 0 /* RST_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* RST_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : (nw == 16 ? 1 : (KC == 40 ? 3 : 2)) * ps_num_cus();
       int gx = wgs / ny > 0 ? wgs / ny : 1;
       if (gx > ntiles) gx = ntiles;
       const size_t W = (size_t)KC * HN + KC;
       if (a.ws_floats < (size_t)gx * W) return (int)hipErrorInvalidValue;
       constexpr int BXv = ((KC + 15) / 16) * 16;
       const size_t ldst = (size_t)16 * nw * (tn2_ld(BXv) + tn2_ld(160)) * 2;
-      const bool fused = a.W != nullptr;      // the fold goes straight on to S0 / S1 / dW2 / db2 (see the header); without W: raw T / db2 into s0 / s1
-      if (fused && (!a.v0 || !a.v1 || !a.fin_dgamma || !a.fin_dbeta || a.ldw < HN)) return (int)hipErrorInvalidValue;
+      // fused (W = staged W2): every workgroup also writes its share of S0 / S1 as a small slab row [2][H] behind the big ones; only THAT fold runs here
+      // (the next main-lane kernel waits for it); the big slabs [C * H | C] stay in ws for mpmae_rs_wgrad_fold(C, H, ...) -> dW2, db2 on the weight-gradient
+      // lane, *wg_rows = slab rows. Without W: raw T / db2 folded into s0 / s1 here.
+      const bool fused = a.W != nullptr;
+      if (fused && (!a.wg_rows || a.ldw < HN || a.ws_floats < (size_t)gx * (W + 2 * HN))) return (int)hipErrorInvalidValue;
+      if (fused) { p.s0a = a.ws + (size_t)gx * W; *a.wg_rows = gx; }
       if (nw == 16) {
         static bool attr = false;
         if (!attr) { if (hipFuncSetAttribute((const void*)rst_kernel<KC, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldst) != hipSuccess) return (int)hipGetLastError(); attr = true; }
@@ -56,11 +60,11 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         LAUNCH((rst_kernel<KC, 4>), dim3(gx, ny), dim3(256), ldst, st, p, ntiles);
       }
       if (!fused) launch_reduce(3, a.ws, gx, (int)W, a.s0, a.s1, KC * HN, 0, 0, 0, st);
+      else if (a.s1 == a.s0 + HN) launch_reduce(0, p.s0a, gx, 2 * HN, a.s0, nullptr, 0, 0, 0, 0, st);
       else {
-        int R = gx / 4 < 1 ? 1 : (gx / 4 > 64 ? 64 : gx / 4);      // <= 4 slab rows per thread: every load of a thread in flight at once
-        if (g_opt[MPMAE_OPT_DET] > 0) R = 1;      // one row group per column block: plain += in a fixed order
-        LAUNCH((rst_fold_kernel<KC>), dim3(HN / 32, R), dim3(256), 0, st, (const float*)a.ws, gx, (const bf16_t*)a.W, a.ldw, a.v0, a.v1, a.fin_dgamma, a.fin_dbeta,
-               a.s0, a.s1);
+        const long long delta = a.s1 - a.s0;
+        if (delta > 2147483647LL || delta < -2147483647LL) return (int)hipErrorInvalidValue;
+        launch_reduce(1, p.s0a, gx, 2 * HN, a.s0, nullptr, HN, (int)delta, 1, 0, st);
       }
       return launch_status();
     } else {
@@ -70,7 +74,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   if (which == 0 || which == 1) {
     if (a.fin_sum) return (int)hipErrorInvalidValue;
     // split the N range so that ~3 workgroups per CU exist; a split must be a whole number of chunks
-    const int target = g_opt[MPMAE_OPT_RSC_BLOCKS];
+    const int target = 1536 /* RSC_BLOCKS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */;
     int nsplit = 1;
     while (rowblocks * nsplit * 2 <= target && (HN / NC) % (nsplit * 2) == 0) nsplit *= 2;
     const int cps = HN / nsplit;
@@ -91,7 +95,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         constexpr int KPv = ((KC + 31) / 32) * 32;
         const size_t ldsp = (size_t)160 * (KPv + RSC_PAD) * 2 + (size_t)(2 * KPv + 160) * 4 + (size_t)4 * 2 * 160 * 4;
         // (tools/probes/rs1_probe.py small: which 0 best at 3 workgroups per CU - 43.5 / 29.0 us at C = 40 / 80 against 50.6 / 33.6 chunked -, which 1 at 2: 42.1 / 29.3 against 56.0 / 36.8)
-        const int wgs = g_opt[MPMAE_OPT_RSP_WGS] > 0 ? g_opt[MPMAE_OPT_RSP_WGS] : (which == 0 ? 3 : 2) * ps_num_cus();
+        const int wgs = 0 /* RSP_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* RSP_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : (which == 0 ? 3 : 2) * ps_num_cus();
         int gx = wgs / ny > 0 ? wgs / ny : 1;
         if (gx > ntiles) gx = ntiles;
         const size_t needp = (size_t)gx * HN * (which == 1 ? 2 : 1);
@@ -120,10 +124,10 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         // measured (tools/probes/rs1_probe.py, incl. the fold): C = 160: which 0 24.0 (slice 128) / 27.4 (64) vs 29.9 us chunked, which 1 25.7 (128) / 19.1 (64) vs
         // 23.8; C = 320: which 0 25.3 vs 30.8, which 1 18.7 vs 22.5; without the fold launch (atomics) 22.5 / 16.4 at C = 320
         // (tiny widths, BASELINE config 4: C = 192 in 96-column slices, C = 384 in 64-column slices)
-        const int cpsv = (KC == 192) ? 96 : (KC == 384) ? 64 : (g_opt[MPMAE_OPT_RSC1_CPS] > 0 ? g_opt[MPMAE_OPT_RSC1_CPS] : ((KC == 160 && which == 0) ? 128 : 64));
+        const int cpsv = (KC == 192) ? 96 : (KC == 384) ? 64 : (0 /* RSC1_CPS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* RSC1_CPS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : ((KC == 160 && which == 0) ? 128 : 64));
         if (cpsv != 64 && !(KC == 160 && cpsv == 128) && !(KC == 192 && cpsv == 96)) return (int)hipErrorInvalidValue;
         const int ny = HN / cpsv;
-        const int wgs = g_opt[MPMAE_OPT_RSC1_WGS] > 0 ? g_opt[MPMAE_OPT_RSC1_WGS] : 3 * ps_num_cus();
+        const int wgs = 0 /* RSC1_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* RSC1_WGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : 3 * ps_num_cus();
         const int gxmax = wgs / ny > 0 ? wgs / ny : 1;
         const int tpw = cdiv(ntiles, gxmax), gx = cdiv(ntiles, tpw);
         const size_t lds1s = (size_t)cpsv * KC * 2 + (size_t)4 * 2 * cpsv * 4 + (size_t)2 * KC * 4;
@@ -247,7 +251,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
         if (wg && (KC != 40 || which != 5 || nwv != 4 || !a.wg_rows)) return (int)hipErrorInvalidValue;
         const size_t ldsn = ((size_t)NPv * (HN + RSC_PAD) + (which == 5 ? (size_t)HN * (KP2v + RSC_PAD) : 0)) * 2 + (size_t)(2 * HN + NPv + 8) * 4 +
                             (which == 5 ? (size_t)nwv * 2 * NPv * 4 : 0) + (wg ? (size_t)16 * nwv * (tn2_ld(HN) + tn2_ld(NPv)) * 2 : 0);
-        const int wgs = g_opt[MPMAE_OPT_RSP_NWGS] > 0 ? g_opt[MPMAE_OPT_RSP_NWGS] : (int)((160 * 1024) / ldsn > 2 ? 2 : (160 * 1024) / ldsn) * ps_num_cus();
+        const int wgs = 0 /* RSP_NWGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ > 0 ? 0 /* RSP_NWGS: launch shape frozen in round 6 (swept flat, profiles/r05/option_sweep.txt) */ : (int)((160 * 1024) / ldsn > 2 ? 2 : (160 * 1024) / ldsn) * ps_num_cus();
         const int gx = ntiles < wgs ? ntiles : wgs;
         if (ldsn > 160 * 1024 - 512 || (which == 5 && (!a.ws || a.ws_floats < (size_t)gx * 2 * KC))) return (int)hipErrorInvalidValue;
 #define RSP_NARROW(MODE_, NWV_) do { \
@@ -302,11 +306,11 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-int mpmae_rs_wgrad_fold(int C, const float* slabs, int rows, const float* ln_gamma, const float* ln_beta, float* dW1, float* db1, mpmae_stream_t s) {
-  if (C != 40 || !slabs || rows < 1 || !ln_gamma || !ln_beta || !dW1 || !db1) return (int)hipErrorInvalidValue;
+int mpmae_rs_wgrad_fold(int A, int B, const float* slabs, int rows, const float* v0, const float* v1, float* dW, float* db, mpmae_stream_t s) {
+  if (A < 1 || B < 32 || !slabs || rows < 1 || !v0 || !v1 || !dW || !db) return (int)hipErrorInvalidValue;
   int R = rows / 16 < 1 ? 1 : (rows / 16 > 32 ? 32 : rows / 16);
   if (g_opt[MPMAE_OPT_DET] > 0) R = 1;
-  LAUNCH((rsu_fold_kernel<40>), dim3(cdiv(4 * C * C, 64), R), dim3(256), 0, S_(s), slabs, rows, ln_gamma, ln_beta, dW1, db1);
+  LAUNCH(wg_fold_kernel, dim3(cdiv((long long)A * B, 64), R), dim3(256), 0, S_(s), slabs, rows, A, B, v0, v1, dW, db);
   RET();
 }
 

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const uint8_t* __restrict__ decay, float* __restrict__ gnorm2,
                                                     int slot0, int nslots) {
   // (slot0, nslots): this launch's place among the per-workgroup partials of the step's gradient norm - one launch over the whole
-  // buffer (0, gridDim.x) or one launch per gradient bucket (mpmae_adamw_part: the buckets' updates run as their gradients become final)
+  // buffer: (0, gridDim.x) (a per-gradient-bucket form, mpmae_adamw_part, was built in round 5, did not move the step and was removed in round 6)
   if (hp[4] != 0.f) return;      // non-finite loss this step (hp_fetch): the update is skipped, p / m / v stay intact
   const float lr = hp[0], ibc1 = hp[1], isbc2 = hp[2], gs = hp[3];
   float gsq = 0.f;               // sum g^2 (unscaled): the global gradient norm rides in the pass that reads every gradient anyway

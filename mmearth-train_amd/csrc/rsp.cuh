@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
   // gamma[c] * U[j][c] + beta[c] * db1[j] with U = dh^T x-hat and db1 = sum_rows dh - and dh and x-hat are both in this kernel's registers. The 64 rows
   // of a workgroup iteration go to LDS row-major (dh [64][LDG], x-hat [64][LDX]; odd multiples of 16 elements like gemm_tn2's slabs), the transposing
   // LDS read hands a lane 4 consecutive rows of one column, and wave w accumulates the U tiles of hidden-column tiles w, w + 4, ... for all C over ALL
-  // tiles of the persistent workgroup (9 + 3 accumulator tiles at C = 40); one slab row [H * C | H] per workgroup in p.wg_ws, folded by rsu_fold_kernel.
+  // tiles of the persistent workgroup (9 + 3 accumulator tiles at C = 40); one slab row [H * C | H] per workgroup in p.wg_ws, folded by wg_fold_kernel (rst.cuh).
   // dh is then never written to HBM (100 MB per stage-0 block), the transpose-read GEMM over dh and xn and its fold leave the weight-gradient lane,
   // and the forward need not store xn.
   constexpr int NJT = HN / 16, JU = (NJT + 3) / 4, LDG = tn2_ld(HN), LDXH = tn2_ld(NP);
@@ -597,37 +597,3 @@ __global__ __launch_bounds__(64 * NWV) void rsp_narrow_kernel(const RsP p, int n
   }
 }
 
-// Second stage of the fused pwconv1 weight gradient (rsp_narrow_kernel<.., WG = true>): slab rows [P][H * C | H] of U = dh^T x-hat and db1 = sum_rows dh ->
-//     dW1[j][c] += gamma[c] * U[j][c] + beta[c] * db1[j]          db1[j] += db1[j]
-// (xn = x-hat * gamma + beta is never needed as a tensor). grid = (ceil(H C / 64), R row chunks); block = 64 elements x 4 row lanes, like reduce_partials.
-template <int KC>
-__global__ __launch_bounds__(256) void rsu_fold_kernel(const float* __restrict__ part, int P, const float* __restrict__ lng, const float* __restrict__ lnb,
-                                                       float* __restrict__ dW1, float* __restrict__ db1) {
-  constexpr int HN = 4 * KC, NE = HN * KC, NJB = 64 / KC + 2;
-  constexpr size_t W = (size_t)NE + HN;
-  __shared__ float red[4][64];
-  __shared__ float dred[4][NJB];
-  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int e = blockIdx.x * 64 + col, j0 = (blockIdx.x * 64) / KC;
-  const int chunk = (P + gridDim.y - 1) / gridDim.y;
-  const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
-  float s = 0.f;
-  if (e < NE) {
-#pragma unroll 4
-    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
-  }
-  if (col < NJB) {
-    float d = 0.f;
-    if (j0 + col < HN) for (int p = p0 + rl; p < p1; p += 4) d += part[(size_t)p * W + NE + j0 + col];
-    dred[rl][col] = d;
-  }
-  red[rl][col] = s;
-  __syncthreads();
-  if (rl != 0 || e >= NE) return;
-  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
-  const int j = e / KC, c = e - j * KC;
-  const float d = dred[0][j - j0] + dred[1][j - j0] + dred[2][j - j0] + dred[3][j - j0];
-  const float g = lng[c] * s + lnb[c] * d;
-  if (gridDim.y == 1) { dW1[e] += g; if (c == 0) db1[j] += d; }
-  else { atomicAdd(dW1 + e, g); if (c == 0) atomicAdd(db1 + j, d); }
-}

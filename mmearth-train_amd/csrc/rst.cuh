@@ -15,8 +15,8 @@
 // transposing LDS read (ds_read_b64_tr_b16) hands every lane its 4 consecutive m of one column; LDS rows are an odd multiple of 16 elements
 // (tn2_ld) so the 8 rows a half-wave touches fall into 8 distinct bank groups. One MFMA per (16 c, 16 j, 32 m); a wave owns every third-ish
 // j tile of the workgroup's 160-column slice for ALL c tiles and keeps those accumulators for the whole kernel (9 / 15 tiles at C = 40 / 80);
-// the idle slot of wave 3 carries the bias gradient (dout^T ones). One slab row [C * 4C | C] per workgroup, folded by rst_fold_kernel (below), which
-// goes straight on to the statistics and the parameter gradients.
+// the idle slot of wave 3 carries the bias gradient (dout^T ones). One slab row [C * 4C | C] per workgroup (-> dW2, db2 on the
+// weight-gradient lane: wg_fold_kernel below) and one small row [2][4C] of the workgroup's share of S0 / S1 (-> the main lane's next kernel).
 // Workgroup shape (NW waves, 16 NW rows per tile): every workgroup ends with a slab row of 25-100 KB that a second stage must read again, so FEW, FAT
 // workgroups: NW = 16 (1024 threads, 256-row tiles, one workgroup per CU, 100 KB of rows in flight per CU) writes 256 slab rows where NW = 4 at three
 // workgroups per CU wrote 768 (the fold of those cost 22 / 50 us at C = 40 / 80 in the step - more than the product itself at C = 80).
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(64 * NW) void rst_kernel(const RsP p, int ntiles) {
   typedef __attribute__((ext_vector_type(8))) short s16x8_t;
   const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
   const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
-  const bool do_db = blockIdx.y == 0 && wave == NW - 1;      // (a wave with an idle tile slot: 10 column tiles over 4 / 16 waves)
+  const bool db_wave = wave == NW - 1, do_db = blockIdx.y == 0 && db_wave;      // (a wave with an idle tile slot; every column slice needs db2 for S0, slice 0 stores it)
   const int xoff = (lg * 4 + (lr >> 2)) * LDX + 4 * (lr & 3);
   const int yoff = (lg * 4 + (lr >> 2)) * LDY + 4 * (lr & 3);
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64 * NW) void rst_kernel(const RsP p, int ntiles) {
           const bf16x8_t yf = tn2_frag(ys + jt * 16, 16 * LDY);
 #pragma unroll
           for (int i = 0; i < NX; ++i) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], yf, acc[i][u], 0, 0, 0);
-        } else if (u == JU - 1 && do_db) {
+        } else if (u == JU - 1 && db_wave) {
 #pragma unroll
           for (int i = 0; i < NX; ++i) acc[i][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i], ones, acc[i][u], 0, 0, 0);
         }
@@ -141,61 +141,76 @@ __global__ __launch_bounds__(64 * NW) void rst_kernel(const RsP p, int ntiles) {
         if (c < KC) slab[(size_t)KC * HN + c] = acc[i][JU - 1][r];
       }
   }
+  // ---- this workgroup's share of the GRN backward statistics, straight from the accumulators (everything downstream is linear in T):
+  //   S1'[j] = sum_c W2[c][j] T'[c][j],  S0'[j] = sum_c W2[c][j] db2'[c]  ->  small slab row [2][HN] behind the big slabs (p.s0a): the fold the NEXT
+  // main-lane kernel waits for reads gridDim.x * 2 HN floats instead of gridDim.x * (KC HN + KC); the big slabs fold into dW2 / db2 on the weight-gradient lane
+  if (p.s0a) {
+    float* dbs = reinterpret_cast<float*>(rsc_smem);               // (the row tiles are dead: last barrier of the loop)
+    if (wave == NW - 1 && lr == 0) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbs[i * 16 + lg * 4 + r] = acc[i][JU - 1][r];
+    }
+    __syncthreads();
+    float* srow = p.s0a + (size_t)blockIdx.x * 2 * HN;
+#pragma unroll
+    for (int u = 0; u < JU; ++u) {
+      const int jt = wave + NW * u;
+      if (jt < NJ) {
+        const int j = n_begin + jt * 16 + lr;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NX; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int c = i * 16 + lg * 4 + r;
+            const float w = c < KC ? bf2f(p.W[(size_t)min(c, KC - 1) * p.ldw + j]) : 0.f;
+            s0 += w * dbs[c];
+            s1 += w * acc[i][u][r];
+          }
+        s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        if (lg == 0) { srow[j] = s0; srow[HN + j] = s1; }
+      }
+    }
+  }
 }
 
-// Second stage of rst_kernel fused with what its result is FOR (rows.cuh: grn_stats_from_wgrad_kernel is the same algebra on a folded T): every
-// product below is linear in T / db2, so a workgroup that has summed its chunk of slab rows for 32 columns j and all C rows adds its share of
-//     dW2[c][j] += scale[j] T'[c][j] + beta[j] d'[c]      S1[j] += sum_c W2[c][j] T'[c][j]      S0[j] += sum_c W2[c][j] d'[c]      db2[c] += d'[c]
-// straight into the outputs (<= gridDim.y-way float atomics per address, as reduce_partials does): T is never stored and the separate statistics
-// launch - 11 us in the step for 6 400 products, a dependent small kernel on the main lane in front of the fused backward kernel - is gone.
-// grid = (H / 32, R row chunks); block = 256 = 32 columns x 8 c-lanes (c = cl + 8 u, u < C / 8)
-template <int KC>
-__global__ __launch_bounds__(256) void rst_fold_kernel(const float* __restrict__ part, int P, const bf16_t* __restrict__ W2s, int ldw,
-                                                       const float* __restrict__ scale, const float* __restrict__ beta, float* __restrict__ dW2,
-                                                       float* __restrict__ db2, float* __restrict__ S0, float* __restrict__ S1) {
-  constexpr int HN = 4 * KC, NU = KC / 8;
-  constexpr size_t W = (size_t)KC * HN + KC;
-  __shared__ float dsh[KC];
-  __shared__ float red[2][8][33];
-  const int jl = threadIdx.x & 31, cl = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + jl;
+// Second stage of the weight gradients that are accumulated INSIDE main-lane kernels (rst_kernel: T = dout^T gelu(h) | db2; rsp_narrow_kernel<.., WG>:
+// U = dh^T x-hat | db1): slab rows [P][A * B | A] -> the parameter gradients with the per-column affine applied by linearity,
+//     dW[a][b] += v0[b] * sum_p X_p[a][b] + v1[b] * sum_p d_p[a]          db[a] += sum_p d_p[a]
+// pwconv2: (A, B) = (C, H), v0 = GRN scale, v1 = GRN beta (z = gelu(h) * scale + beta is never needed as a tensor);
+// pwconv1: (A, B) = (H, C), v0 / v1 = LayerNorm gamma / beta (xn = x-hat * gamma + beta is never needed as a tensor).
+// grid = (ceil(A B / 64), R row chunks); block = 64 elements x 4 row lanes, like reduce_partials; B >= 32
+__global__ __launch_bounds__(256) void wg_fold_kernel(const float* __restrict__ part, int P, int A, int B, const float* __restrict__ v0, const float* __restrict__ v1,
+                                                      float* __restrict__ dW, float* __restrict__ db) {
+  constexpr int NJB = 4;                       // rows a touched by 64 consecutive elements: <= 64 / B + 2
+  const int NE = A * B;
+  const size_t W = (size_t)NE + A;
+  __shared__ float red[4][64];
+  __shared__ float dred[4][NJB];
+  const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int e = blockIdx.x * 64 + col, a0 = (blockIdx.x * 64) / B;
   const int chunk = (P + gridDim.y - 1) / gridDim.y;
   const int p0 = blockIdx.y * chunk, p1 = min(P, p0 + chunk);
-  float t[NU];
-#pragma unroll
-  for (int u = 0; u < NU; ++u) t[u] = 0.f;
-#pragma unroll 2
-  for (int p = p0; p < p1; ++p) {
-    const float* row = part + (size_t)p * W + j;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) t[u] += row[(size_t)(cl + 8 * u) * HN];
+  float s = 0.f;
+  if (e < NE) {
+#pragma unroll 4
+    for (int p = p0 + rl; p < p1; p += 4) s += part[(size_t)p * W + e];
   }
-  if (threadIdx.x < KC) {                     // this chunk's share of db2
+  if (col < NJB) {
     float d = 0.f;
-    for (int p = p0; p < p1; ++p) d += part[(size_t)p * W + (size_t)KC * HN + threadIdx.x];
-    dsh[threadIdx.x] = d;
-    if (blockIdx.x == 0) { if (gridDim.y == 1) db2[threadIdx.x] += d; else atomicAdd(db2 + threadIdx.x, d); }
+    if (a0 + col < A) for (int p = p0 + rl; p < p1; p += 4) d += part[(size_t)p * W + NE + a0 + col];
+    dred[rl][col] = d;
   }
+  red[rl][col] = s;
   __syncthreads();
-  const float sc = scale[j], bt = beta[j];
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int u = 0; u < NU; ++u) {
-    const int c = cl + 8 * u;
-    const float w = bf2f(W2s[(size_t)c * ldw + j]), d = dsh[c];
-    s0 += w * d;
-    s1 += w * t[u];
-    const float g = sc * t[u] + bt * d;
-    if (gridDim.y == 1) dW2[(size_t)c * HN + j] += g; else atomicAdd(dW2 + (size_t)c * HN + j, g);
-  }
-  red[0][cl][jl] = s0; red[1][cl][jl] = s1;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int q = threadIdx.x >> 5;
-    float a = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) a += red[q][r][jl];
-    float* dst = (q == 0 ? S0 : S1) + j;
-    if (gridDim.y == 1) *dst += a; else atomicAdd(dst, a);
-  }
+  if (rl != 0 || e >= NE) return;
+  s = red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  const int a = e / B, b = e - a * B;
+  const float d = dred[0][a - a0] + dred[1][a - a0] + dred[2][a - a0] + dred[3][a - a0];
+  const float g = v0[b] * s + v1[b] * d;
+  if (gridDim.y == 1) { dW[e] += g; if (b == 0) db[a] += d; }
+  else { atomicAdd(dW + e, g); if (b == 0) atomicAdd(db + a, d); }
 }

@@ -213,9 +213,7 @@ class StepRunner:
                                    loss_scale=1.0 / self.update_freq,
                                    # data parallel: the non-finite guard reads the ALL-REDUCED loss, so every rank skips (or applies) the
                                    # same update; with a rank-local guard one rank skipped while the others applied NaN-poisoned gradients
-                                   guard_loss=self.loss_buf if self.exchange else None,
-                                   # (the bucket-wise optimizer of the plain step; an accumulation window applies ONE update at its end)
-                                   adamw_split=not self.exchange and self.update_freq == 1))
+                                   guard_loss=self.loss_buf if self.exchange else None))
             self.graph_mode = "program"
             # "inputs free" point of the step (Engine.set_inputs_async): exported so that a stream outside the program can wait for it
             self.inputs_free_signal = None

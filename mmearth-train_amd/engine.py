@@ -36,7 +36,6 @@ F32, BF16 = 0, 1
 # (the C library itself reads no environment, include/mpmae_hip.h mpmae_set_option).
 ENGINE_OPTIONS = dict(
     down_grouped=1,         # LayerNorm writes the grouped operand of the 2x2/2 convolution
-    grouped_epi=0,          # per-sample GRN sums of the decoder in the GEMM epilogues (measured slower)
     rsc_small=1,            # chunked row-streaming kernels at C = 40 / 80 too
     grn_fold=1,             # GRN finalisation recomputed in the fused kernels' prologues
     rsc_pf=1,               # LDS-staged GRN vectors in the narrow kernels (needed by grn_fold)
@@ -50,11 +49,8 @@ ENGINE_OPTIONS = dict(
     loss_rows=1,            # continuous pixel losses: row-band forward kernel
     loss_rows_bwd=1,        # ... and its gradient twin
     img_side=1,             # image-level head chain on the side lane
-    ps_ng=4,                # accumulator copies of each GRN statistics vector of the persistent stage kernels (workgroup n adds into copy n % ps_ng)
-    adamw_split=0,          # round 5: the optimizer of the plain single-GPU step cut along the gradient buckets (dist.plan_buckets, mpmae_adamw_part): hp_fetch in front of the backward, a bucket's AdamW on the weight-gradient lane as soon as its gradients are final, only the last bucket's (stem, stages 0-1: 6 % of the parameters) behind the backward. The step boundary shrinks from 71 to 11 us in the kernel trace and the step does not move (3.653 / 3.656 vs 3.650 / 3.647 ms, profiles/r05/ab_adamw_split.txt): the 224 MB the update streams now compete inside the two-lane backward, which is throughput-bound
     tail_fold_group=1,      # the LayerNorm-gradient fold group that runs in order on the main lane (tail_main) as ONE launch, like the stem kernel's three folds (library: FOLD_GROUP >= 0)
     img_dgrad_side=1,       # round 5: the image-level heads' data-gradient GEMM (eight workgroups, pure latency) on the weight-gradient lane in front of the heads' weight gradients
-    cat_side=0,             # round 5: the categorical pixel loss of the one-pass program behind the image-head chain on the side lane (idle in the forward), next to the continuous one on the main lane
     prep_side=1,            # weight staging of the forward on the side lane
     prep_late=1,            # the side lane runs activity + poolings FIRST and the weight staging behind them: the first stage-0 kernel (depthwise, fp32 taps) only waits for the poolings, the first staged weight is needed 50 us later
     front_side=1,           # ... followed there by the pixel-activity map and its poolings (main lane: mask -> im2col)
@@ -66,24 +62,19 @@ ENGINE_OPTIONS = dict(
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
     ps=2,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage. 2 since late round 4: with the decoder / head GEMMs on the vendor route the per-block kernels at stage 3 (2 blocks, M = 3584) measure 3.868-3.873 vs 3.892-3.897 ms for 3 in three interleaved pairs (a tie in round 3); 1: 4.04
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
-    dw_lane=1,              # lane of the depthwise weight gradients
     act_in_stem=1,          # the fused stem kernel writes the pixel-activity bytes itself (it computes them anyway): no activity launch, the first stage-0 op waits for nothing on the side lane, the poolings run behind the stem
-    tail_main=1,            # the LAST depthwise weight gradient of the backward (stage 0, block 0) on the main lane behind its data gradient: the weight-gradient lane ends 115 us after the main lane (profiles/r04/lanes_one_step.txt); 2: its pointwise pw1 weight gradient too (measured slower: 4.11 vs 4.07 ms same box)
+    tail_main=0,            # 1: the LAST depthwise weight gradient of the backward (stage 0, block 0) and its fused pwconv1 fold on the main lane behind the data gradient (round 4: the weight-gradient lane ended 115 us after the main lane, 4.06 -> 4.02 ms). Round 6: with pwconv1 / pwconv2's weight gradients of stages 0-1 gone from that lane it has slack again: 0 measures 3.435 / 3.451 vs 3.462 / 3.467 ms (profiles/r06/option_sweep.txt); 2: the pointwise pw1 weight gradient too (unfused blocks)
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
-    rs_maxc=100000,         # largest C on the row-streaming kernels
     rsn_maxc=192,           # largest C with the GRN application / its backward fused into the NARROW row-streaming kernels (beyond: tiled GEMMs + element-wise kernels; 384 on tiny 112/16: 16.64 vs 15.15 ms)
-    grn_fold_minc=0,        # smallest C with folded GRN finalisation
-    hr_maxc=0,              # largest C recomputing h in the forward (0 = never)
     dzr_maxc=80,            # largest C recomputing dz
     dw_group=1,             # ... and ONE launch for its depthwise weight gradients (mpmae_dwconv7_wgrad_group), from this stage index on (stage 0 stays per block: its weight gradients are the tail of the backward; 9 = never)
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
     wg_fused=1,             # round 6: pwconv1's weight gradient of the stage-0 blocks (C = 40, dz recomputed) INSIDE the fused backward kernel (MpmaeRsArgs.wg_ws: U = dh^T x-hat and db1 per persistent workgroup, folded by mpmae_rs_wgrad_fold with the LayerNorm affine applied by linearity): dh is never stored (100 MB per block), the transpose-read product over dh and xn and its fold leave the weight-gradient lane, the forward does not store xn
-    stats_wgrad=1,          # blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient - T = dout^T gelu(h) on the MAIN lane (mpmae_rs which = 6, csrc/rst.cuh: one read of dout and h at the price of the statistics-only pass it replaces, 33.9 vs 34.7 us at stage 0), then mpmae_grn_stats_from_wgrad -> S0, S1, dW2, db2: the weight-gradient lane loses pwconv2's transpose-read product and fold over the same two tensors (72 + 12 us per stage-0 block), the forward never stores z at those widths. Round 6: 3.471 vs 3.569 ms (profiles/r06/ab_stats_wgrad.txt). 2 = round 5's route (T through the generic gemm_tn2 kernel: 3.65 ms, slower than off); 0 = statistics pass + separate weight gradient
+    stats_wgrad=1,          # blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient - T = dout^T gelu(h) on the MAIN lane (mpmae_rs which = 6, csrc/rst.cuh: one read of dout and h at the price of the statistics-only pass it replaces, 33.9 vs 34.7 us at stage 0), then mpmae_grn_stats_from_wgrad -> S0, S1, dW2, db2: the weight-gradient lane loses pwconv2's transpose-read product and fold over the same two tensors (72 + 12 us per stage-0 block), the forward never stores z at those widths. Round 6: 3.471 vs 3.569 ms (profiles/r06/ab_stats_wgrad.txt). 0 = statistics pass + separate weight gradient (round 5's route to the same T - the generic gemm_tn2 kernel on the main lane - measured 3.65 ms, slower than off, and is removed)
     grn_apply_fin=1,        # unfused sparse blocks (C = 320: tiled GEMMs + element-wise GRN passes): the GRN finalisation runs in the prologue of the element-wise pass (mpmae_grn_apply_fin / _bwd_apply_fin) - two launches fewer per block on the main lane
-    loss_rowsplit=0,        # k > 1: continuous pixel losses with k workgroups per sample, each walking ceil(grid / k) patch rows (k = grid, one row per workgroup, measured SLOWER: 3.69 vs 3.64 ms - the per-workgroup set-up, index tables and a cold band, is paid 7 times)
     loss_onepass=1,         # pixel losses in ONE pass (round 5): the forward kernels also write the loss gradient without its per-modality scalar; the scalar is folded into the heads' data-gradient weights (mpmae_head_scale) and weight-gradient fold (rowscale): the dloss:pix_* kernels (69 us of the main lane, a second pass over predictions and targets) leave the step
     det=0,                  # 1 = reproducible forward: no persistent stage kernel (its GRN exchange is float atomics), library option DET = 1 (every fold as one ordered row group - parameter-gradient folds included); 4.53-4.55 vs 3.89-3.90 ms
 )
@@ -118,7 +109,7 @@ class Engine:
             k, v = kv.split("=")
             if k.strip() in _lib.OPT:           # upper-case names are library options (process-wide, mpmae_set_option)
                 _lib.check(self.lib.mpmae_set_option(_lib.OPT[k.strip()], int(v)), "set_option " + k)
-                if k.strip() in ("RSC_PF", "RSC_SMALL"):      # the engine plans around these two (grn_fold needs the staged GRN prologue)
+                if k.strip() == "RSC_PF":      # the engine plans around this one (grn_fold needs the staged GRN prologue)
                     self.opt[k.strip().lower()] = int(v)
             else:
                 self.opt[k.strip()] = int(v)
@@ -151,10 +142,6 @@ class Engine:
         self.disable_rs = False                    # tests: force the unfused kernels for the small-C stages
         self.disable_rsc = (not self.opt["rsc"])
         self.down_grouped = bool(self.opt["down_grouped"])
-        # per-sample GRN sums of the dense decoder block in the GEMM epilogues instead of separate colstats passes: works
-        # (parity-tested) but measured SLOWER, 5.50 vs 5.42 ms/step - the statistics epilogue costs the 1568-workgroup
-        # decoder GEMMs more than the two column passes it removes; off by default
-        self.grouped_epi = self.dt == BF16 and bool(self.opt["grouped_epi"]) and cfg.num_patches >= 43
         self.rsc_small = bool(self.opt["rsc_small"])     # fused GRN prologues at C = 40 / 80 too
         # GRN finalisation recomputed in the prologue of the fused kernels (no separate launches on the main lane)
         self.grn_fold = bool(self.opt["grn_fold"]) and bool(self.opt["rsc_pf"])
@@ -164,7 +151,6 @@ class Engine:
                            and (lanes is None or bool(lanes)))
         self.single_stream = False                 # set while capturing HIP graphs (see dist.StepRunner._capture)
         self.lanes = self.concurrent and (block_mode or ("mat" if self.dt == BF16 else "fused")) == "mat"
-        self.dw_lane = int(self.opt["dw_lane"])
         self._side_readers = {}
         self._evseq = 0
         self._ext_buffers = param_buffers          # optional (pflat, gflat) owned by the caller (FCMAE module)
@@ -370,11 +356,10 @@ class Engine:
         T = len(cfg.out_mods)
         self.n_stats = sum(self._stat_sizes)
         # persistent stage kernels: PS_NG accumulator copies of each statistics vector (same arena: zeroed once per step)
-        self.PS_NG = max(1, min(16, int(self.opt["ps_ng"])))
+        self.PS_NG = 4      # (workgroup n adds into copy n % 4: 1 / 2 / 8 copies measured within noise, profiles/r05/ab_ps_ng.txt)
         ps_blocks = [blk for blk in self.blocks if self._ps_ok(blk["stage"])]
         sw_blocks = [blk for blk in self.blocks if blk["sparse"] and blk["C"] <= int(self.opt["dzr_maxc"]) and bool(self.opt["stats_wgrad"]) and self.dt == BF16]
-        sw_floats = sum(-(-(b["C"] * b["H"] + b["C"]) // 64) * 64 for b in sw_blocks)
-        self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks) + sw_floats, dtype=f32, device=dev)
+        self.stats = torch.zeros(self.n_stats + 3 * self.PS_NG * sum(b["H"] for b in ps_blocks), dtype=f32, device=dev)
         off = 0
         for blk in self.blocks + self.decs:
             G, H = blk["G"], blk["H"]
@@ -386,14 +371,11 @@ class Engine:
             for nm in ("G2", "S0", "S1"):
                 blk["ps_" + nm] = self.stats[off:off + self.PS_NG * blk["H"]]
                 off += self.PS_NG * blk["H"]
-        for blk in sw_blocks:        # scratch of the weight-gradient-derived statistics (same arena: zeroed once per step)
-            blk["Tw2"] = self.stats[off:off + blk["C"] * blk["H"]]
-            blk["dbt"] = self.stats[off + blk["C"] * blk["H"]:off + blk["C"] * blk["H"] + blk["C"]]
-            off += -(-(blk["C"] * blk["H"] + blk["C"]) // 64) * 64
+        for blk in sw_blocks:        # candidates for statistics-from-the-weight-gradient (stats_wgrad; decided per block in _block_fwd_mat)
+            blk["sw_cand"] = True
         # per-sample {sum, count} partials; with the row-split continuous losses N * grid slots per modality (slot n * grid + row; the kernels that
         # write one partial per sample use the first N slots, the rest stay zero: the finalisation folds all of them in a fixed order)
-        self.loss_parts = min(self.grid, int(self.opt["loss_rowsplit"])) if (int(self.opt["loss_rowsplit"]) > 1 and bool(self.opt["loss_rows"]) and bool(self.opt["loss_multi"])) else 1
-        self.loss_slots = N * self.loss_parts
+        self.loss_slots = N
         self.loss_acc = torch.zeros(T, self.loss_slots, 2, dtype=f32, device=dev)
         self.losses = torch.zeros(T, dtype=f32, device=dev)
         self.weighted = torch.zeros(T, dtype=f32, device=dev)
@@ -420,7 +402,6 @@ class Engine:
         self.ws = torch.empty(self.ws_floats, dtype=f32, device=dev)
         self.ws2 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # side-lane (weight-gradient) scratch
         self.ws3 = torch.empty(self.ws_floats, dtype=f32, device=dev)     # second side lane (depthwise weight gradients)
-        self.sk_flags = torch.zeros(_lib.SK_FLAGS, dtype=torch.int32, device=dev)      # MpmaeGemmArgs.sk_flags (main lane: every mpmae_gemm of the step is issued there or, for the tiny image-head products, never takes the stream-K kernel)
 
     def _alloc_block(self, prefix, M, Cc, G, stage, sparse, rpg=None):
         H = 4 * Cc
@@ -683,7 +664,6 @@ class Engine:
         if not kw.get("rpg"):
             a.rpg = max(int(a.M), 1)
         a.ws, a.ws_floats = self.ws.data_ptr(), self.ws_floats
-        a.sk_flags = self.sk_flags.data_ptr()      # stream-K hand-off flags of the main lane (self-resetting, gemm_sk.cuh)
         self._keepalive.append(a)
         esz = 4 if self.dt == F32 else 2
         M_, N_, K_ = int(a.M), int(a.N), int(a.K)
@@ -736,7 +716,7 @@ class Engine:
                  kind=f"gemm_mx<{epi}>", nbytes=M_ * K_ + N_ * K_ + M_ * N_ * 2 * (2 if epi == "RESID" else 1), flops=2 * M_ * N_ * K_)
 
     def _mx_block(self, blk):
-        return self.fp8 and not blk["sparse"] and blk["C"] % 128 == 0 and not self.grouped_epi
+        return self.fp8 and not blk["sparse"] and blk["C"] % 128 == 0
 
     def _mx_weight(self, wname):
         """Staged bf16 weight [N][K] -> e4m3 + scales, re-quantised once per step right after weight staging (fwd op list)."""
@@ -754,7 +734,7 @@ class Engine:
         their GRN statistics (which 0/1); narrow: None (tiled GEMMs + element-wise kernels) or "fused" (which 4/5, GRN application
         and its backward in the operand prologue). Measured on MI355X at bs 256: fused wins for C <= 192; at C = 320 (M = 4864 rows,
         76 workgroups) the tiled GEMMs are faster than the narrow row-streaming kernel."""
-        if not self._rs_ok(blk) or blk["C"] > int(self.opt["rs_maxc"]):
+        if not self._rs_ok(blk):
             return False, None
         return True, ("fused" if blk["C"] <= int(self.opt["rsn_maxc"]) else None)      # (C = 320 / 384: the narrow kernels need 250 VGPRs - tiled GEMMs)
 
@@ -881,7 +861,7 @@ class Engine:
                 blk["xn"] = self._t(M, Cc)
                 blk["z"] = self._t(M, H)
             blk["rs"], blk["rs_n"] = self._rs_plan(blk)
-            blk["grn_fold"] = (blk["rs_n"] == "fused" and blk["G"] == 1 and self.grn_fold and Cc >= int(self.opt["grn_fold_minc"]))
+            blk["grn_fold"] = (blk["rs_n"] == "fused" and blk["G"] == 1 and self.grn_fold)
             b = a.blk[i]
             b.dw_w, b.dw_b = P[tag + ".dwconv.kernel"].data_ptr(), P[tag + ".dwconv.bias"].data_ptr()
             b.ln_g, b.ln_b = P[nm["ln_w"]].data_ptr(), P[nm["ln_b"]].data_ptr()
@@ -916,8 +896,8 @@ class Engine:
         blk["rs"], blk["rs_n"] = rs, rs_n
         # pwconv1's weight gradient inside the fused backward kernel (wg_fused): the same conditions as the dz recomputation it rides on, C = 40
         blk["wgf"] = (bool(self.opt["wg_fused"]) and rs and rs_n == "fused" and Cc == 40 and blk["sparse"] and G == 1 and self.grn_fold
-                      and Cc >= int(self.opt["grn_fold_minc"]) and Cc <= int(self.opt["dzr_maxc"]) and self.dz_recompute
-                      and Cc > int(self.opt["hr_maxc"]) and bool(self.opt["rsc_pf"])
+                      and Cc <= int(self.opt["dzr_maxc"]) and self.dz_recompute
+                      and bool(self.opt["rsc_pf"])
                       # (it lives in the persistent 4-wave backward kernel of rsp.cuh: the library switches that select another kernel switch it off)
                       and lib.mpmae_get_option(_lib.OPT["RSP"]) > 0 and (lib.mpmae_get_option(_lib.OPT["RSP_NARROW"]) & 2)
                       and lib.mpmae_get_option(_lib.OPT["RSP_NWV"]) in (0, 4) and lib.mpmae_get_option(_lib.OPT["RSC_PF"]) > 0)
@@ -932,7 +912,7 @@ class Engine:
                      nbytes=3 * M * Cc * esz)
         if rs:
             pass
-        elif blk["sparse"] or self.grouped_epi:      # column sums ride in the GEMM epilogue (per-sample groups: bf16 fast kernel)
+        elif blk["sparse"]:      # column sums ride in the GEMM epilogue
             self._gemm(lst, tag + ":pw1", "NONE", "GELU_SUMSQ", A=blk["xn"], B=self.w[tag + ".W1"]["t"],
                        bias=P[nm["b1"]], C=blk["h"], M=M, N=H, K=Cc, lda=Cc, ldb=self.w[tag + ".W1"]["ld"], ldc=H,
                        rpg=rpg, s0=blk["G2"], act=act)
@@ -948,8 +928,8 @@ class Engine:
             self._op(lst, tag + ":grn.stats", self._colstats_fn, dt, _p(blk["h"]), None, 0, _p(blk["G2"]), None, M, H,
                      rpg, kind="colstats", nbytes=M * H * esz)
         fold = blk["grn_fold"] = (rs_n == "fused" and G == 1 and self.grn_fold
-                                  and Cc >= int(self.opt["grn_fold_minc"]))
-        gg = blk["grn_group"] = (not rs and not blk["sparse"] and not self.grouped_epi and bool(self.opt["grn_group"])
+                                 )
+        gg = blk["grn_group"] = (not rs and not blk["sparse"] and bool(self.opt["grn_group"])
                                  and bool(lib.mpmae_grn_group_ok(dt, M, H, rpg)))
         if gg:      # the three GRN launches (statistics just appended, finalisation, application) as one
             assert lst[-1][0] == tag + ":grn.stats"
@@ -968,20 +948,18 @@ class Engine:
         blk["z_free"] = (rs_n == "fused" and G == 1 and bool(self.opt["z_free"])
                          and Cc % 8 == 0 and Cc <= int(self.opt["z_free_maxc"]) and blk["sparse"])
         # statistics from the weight gradient (stats_wgrad): the blocks whose backward recomputes dz; z is then never needed (T = dout^T gelu(h))
-        blk["sw"] = ("Tw2" in blk and rs and rs_n == "fused" and Cc <= int(self.opt["dzr_maxc"]) and fold and self.dz_recompute and G == 1
+        blk["sw"] = (bool(blk.get("sw_cand")) and rs and rs_n == "fused" and Cc <= int(self.opt["dzr_maxc"]) and fold and self.dz_recompute and G == 1
                      and Cc % 8 == 0 and self.lanes)
         if blk["sw"]:
             blk["z_free"] = True
         if rs_n == "fused":   # z = GRN(gelu(h)) computed in the pw2 operand prologue (and stored for pw2.wgrad)
             fin = dict(fin_sum=blk["G2"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"], fin_ainv=blk["Ainv"],
                        fin_out=blk["scale"], fin_eps=eps) if fold else {}   # GRN finalisation folded into the prologue
-            # optional (off: 5.146 vs 5.152 ms, noise): h recomputed from xn, 26 MB instead of 105 MB read per stage-0 block
-            hr = fold and Cc <= int(self.opt["hr_maxc"])
-            hkw = dict(dz_dout=blk["xn"], dz_w2t=self.w[tag + ".W1"]["t"], dz_ldw2=self.w[tag + ".W1"]["ld"], dz_bias=P[nm["b1"]]) if hr else {}
-            self._rs(lst, tag + ":grn.apply+pw2", 4, blk, ((1 if hr else 2) * M * H + (3 if hr else 2) * M * Cc) * esz,
-                     (4 if hr else 2) * M * Cc * H, A=blk["h"],
+            # (h recomputed from xn in this kernel - 26 MB instead of 105 MB read per stage-0 block - measured as noise in round 2, 5.146 vs 5.152 ms; the
+            #  engine route is removed in round 6, the kernel form stays pinned by test_dz_recomputation_matches_the_materialised_path)
+            self._rs(lst, tag + ":grn.apply+pw2", 4, blk, (2 * M * H + 2 * M * Cc) * esz, 2 * M * Cc * H, A=blk["h"],
                      W=self.w[tag + ".W2"]["t"], ldw=self.w[tag + ".W2"]["ld"], bias=P[nm["b2"]], v0=blk["scale"],
-                     v1=P[nm["gb"]], out=blk["out"], xn=None if blk["z_free"] else blk["z"], R=x, act=act, rpg=0, **fin, **hkw)
+                     v1=P[nm["gb"]], out=blk["out"], xn=None if blk["z_free"] else blk["z"], R=x, act=act, rpg=0, **fin)
             return blk["out"]
         if afin:
             self._op(lst, tag + ":grn+apply", lib.mpmae_grn_apply_fin, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["G2"]), _p(P[nm["gg"]]), _p(P[nm["gb"]]),
@@ -1018,30 +996,32 @@ class Engine:
                and self.dz_recompute)
         sw = bool(blk.get("sw")) and dzr
         if sw:
-            # T = dout^T gelu(h) and db2 into zeroed scratch (GELU-only operand prologue = the GRN prologue with scale 1, beta 0), in order on
-            # the main lane; then statistics + parameter gradients from T (mpmae_grn_stats_from_wgrad)
-            if not hasattr(self, "_sw_ones"):
-                self._sw_ones, self._sw_zeros = {}, {}
-            if H not in self._sw_ones:
-                self._sw_ones[H] = torch.ones(H, dtype=torch.float32, device=self.device)
-                self._sw_zeros[H] = torch.zeros(H, dtype=torch.float32, device=self.device)
-            if int(self.opt["stats_wgrad"]) == 2:      # (round 5's route: the generic transpose-read weight-gradient kernel with a GELU-only prologue)
-                self._wgrad(lst, tag + ":pw2.wgrad(T)", "NONE", "GRN", P=dout, Q=blk["h"], qp0=self._sw_ones[H], qp1=self._sw_zeros[H], M=M, Nn=Cc, Kk=H,
-                            ldp=Cc, ldq=H, dW=blk["Tw2"], sn=H, sk=1, db=blk["dbt"])
-            else:                                       # round 6: the persistent T kernel (csrc/rst.cuh) at the statistics pass's price
-                w2s_ = self.w[tag + ".W2"]
-                self._rs(lst, tag + ":pw2.wgrad(T)+stats", 6, blk, (M * Cc + M * H) * esz + Cc * H * 4, 2 * M * Cc * H, A=dout, R=blk["h"],
-                         W=w2s_["t"], ldw=w2s_["ld"], v0=blk["scale"], v1=P[nm["gb"]], s0=blk["S0"], s1=blk["S1"],
-                         fin_dgamma=Gd[nm["w2"]], fin_dbeta=Gd[nm["b2"]])
-            w2s = self.w[tag + ".W2"]
-            if int(self.opt["stats_wgrad"]) == 2:
-              self._op(lst, tag + ":grn.stats(T)", lib.mpmae_grn_stats_from_wgrad, dt, _p(blk["Tw2"]), _p(blk["dbt"]), _p(w2s["t"]), w2s["ld"],
-                     _p(blk["scale"]), _p(P[nm["gb"]]), _p(Gd[nm["w2"]]), _p(Gd[nm["b2"]]), _p(blk["S0"]), _p(blk["S1"]), Cc, H,
-                     kind="grn_stats_wgrad", nbytes=3 * Cc * H * 4)
+            # round 6: T = dout^T gelu(h) by the persistent kernel of csrc/rst.cuh at the statistics pass's price (round 5's route - T through the generic
+            # gemm_tn2 kernel on the main lane - lost: 3.65 ms). The kernel leaves one slab row [C H | C] per workgroup plus a small one [2 H] with the workgroup's
+            # share of S0 / S1: only the small ones are folded here (the fused backward kernel waits for them); the big ones become dW2 / db2 on the
+            # weight-gradient lane
+            w2s_ = self.w[tag + ".W2"]
+            if "t_slab" not in blk:
+                cus = torch.cuda.get_device_properties(self.device).multi_processor_count if self.device.type == "cuda" else 256
+                blk["t_slab"] = torch.empty(3 * cus * (Cc * H + Cc + 2 * H), dtype=torch.float32, device=self.device)
+                blk["t_rows"] = C.c_int(0)
+            self._rs(lst, tag + ":pw2.wgrad(T)+stats", 6, blk, (M * Cc + M * H) * esz + Cc * H * 4, 2 * M * Cc * H, A=dout, R=blk["h"],
+                     W=w2s_["t"], ldw=w2s_["ld"], s0=blk["S0"], s1=blk["S1"], ws=blk["t_slab"], ws_floats=blk["t_slab"].numel(),
+                     wg_rows=C.addressof(blk["t_rows"]))
+
+            def tfold(stream, _b=blk, _c=Cc, _h=H, _g=P[nm["gb"]], _dw=Gd[nm["w2"]], _db=Gd[nm["b2"]]):
+                return lib.mpmae_rs_wgrad_fold(_c, _h, _p(_b["t_slab"]), _b["t_rows"].value, _p(_b["scale"]), _p(_g), _p(_dw), _p(_db), stream)
+            if self.lanes:
+                k = self._after(lst)
+                self._evseq += 1
+                self._op(lst, tag + ":pw2.wgrad.fold", tfold, kind="rs_wgrad_fold", nbytes=blk["t_slab"].numel() * 4 // 3, lane=1, wait=(k,) if k else (),
+                         signal=f"s{self._evseq}")
+            else:
+                self._op(lst, tag + ":pw2.wgrad.fold", tfold, kind="rs_wgrad_fold", nbytes=blk["t_slab"].numel() * 4 // 3)
         elif rs:
             self._rs(lst, tag + ":pw2.dgrad", 1, blk, (M * Cc + (1 if dzr else 2) * M * H) * esz, 2 * M * Cc * H, A=dout,
                      W=w2t["t"], ldw=w2t["ld"], out=None if dzr else dz, R=blk["h"], s0=blk["S0"], s1=blk["S1"])
-        elif blk["sparse"] or self.grouped_epi:
+        elif blk["sparse"]:
             self._gemm(lst, tag + ":pw2.dgrad", "NONE", "DZ_STATS", A=dout, B=w2t["t"], C=dz, R=blk["h"], M=M, N=H,
                        K=Cc, lda=Cc, ldb=w2t["ld"], ldc=H, ldr=H, rpg=rpg, s0=blk["S0"], s1=blk["S1"])
         elif self._mx_block(blk):
@@ -1083,7 +1063,7 @@ class Engine:
             if not hasattr(self, "_fold_pending"):
                 self._fold_pending = []
             self._fold_pending.append(fd)
-        elif not blk["sparse"] and not self.grouped_epi:
+        elif not blk["sparse"]:
             self._op(lst, tag + ":grn.bstats", self._colstats_fn, dt, _p(blk["h"]), _p(dz), 1, _p(blk["S0"]),
                      _p(blk["S1"]), M, H, rpg, kind="colstats", nbytes=2 * M * H * esz)
         fold = blk.get("grn_fold", False)
@@ -1140,8 +1120,8 @@ class Engine:
         w1_args = dict(P=dz, Q=blk["xn"], M=M, Nn=H, Kk=Cc, ldp=H, ldq=Cc, dW=Gd[nm["w1"]], sn=Cc, sk=1, db=Gd[nm["b1"]])
         if rsc and bool(blk.get("wgf")) and dzr:
             # second stage of the weight gradient the fused kernel accumulated (LayerNorm affine applied by linearity): nothing on the chain reads it
-            def wfold(stream, _b=blk, _c=Cc, _g=P[nm["ln_w"]], _bt=P[nm["ln_b"]], _dw=Gd[nm["w1"]], _db=Gd[nm["b1"]]):
-                return lib.mpmae_rs_wgrad_fold(_c, _p(_b["wg_slab"]), _b["wg_rows"].value, _p(_g), _p(_bt), _p(_dw), _p(_db), stream)
+            def wfold(stream, _b=blk, _c=Cc, _h=H, _g=P[nm["ln_w"]], _bt=P[nm["ln_b"]], _dw=Gd[nm["w1"]], _db=Gd[nm["b1"]]):
+                return lib.mpmae_rs_wgrad_fold(_h, _c, _p(_b["wg_slab"]), _b["wg_rows"].value, _p(_g), _p(_bt), _p(_dw), _p(_db), stream)
             if self.lanes and not (int(self.opt["tail_main"]) >= 1 and tag == "encoder.stages.0.0"):
                 k = self._after(lst)
                 self._evseq += 1
@@ -1206,7 +1186,7 @@ class Engine:
             self._evseq += 1
             key = f"s{self._evseq}"
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
-                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc, lane=self.dw_lane, wait=(k,), signal=key)
+                     nbytes=2 * M * Cc * (4 if dt == F32 else 2), flops=2 * 49 * M * Cc, lane=1, wait=(k,), signal=key)
             self._side_read(key, dd)
         else:
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
@@ -1224,7 +1204,7 @@ class Engine:
         self._evseq += 1
         key = f"s{self._evseq}"
         self._op(lst, f"{stage}:dw.wgrad[{len(pend)}]", self.lib.mpmae_dwconv7_wgrad_group, self.dt, arr, len(pend), _p(self.ws3), self.ws_floats,
-                 kind="dwconv7_wgrad_group", nbytes=sum(p_[3] for p_ in pend), flops=sum(p_[4] for p_ in pend), lane=self.dw_lane,
+                 kind="dwconv7_wgrad_group", nbytes=sum(p_[3] for p_ in pend), flops=sum(p_[4] for p_ in pend), lane=1,
                  wait=(k,) if k else (), signal=key)
         self._side_read(key, *[p_[2] for p_ in pend])
 
@@ -1552,12 +1532,8 @@ class Engine:
                         and -(-(maxc * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(maxc * self.p * self.p // 4) // 64) <= 12):
                     # row-band forward: a workgroup per sample walks its patch rows with the target band in LDS (loss.cuh)
                     self._cont_rows = maxc
-                    if self.loss_slots > N:
-                        self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_split, dt, 2 if onepass else 0, _p(tab), len(mods), N, maxc,
-                                 self.p, cfg.img_size, self.loss_parts, kind=f"loss_{kind}_fwd")
-                    else:
-                        self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
-                                 dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
+                    self._op(f, f"loss:{kind}[{len(mods)}]", lib.mpmae_loss_pix_cont_rows_fused if onepass else lib.mpmae_loss_pix_cont_rows,
+                             dt, _p(tab), len(mods), N, maxc, self.p, cfg.img_size, kind=f"loss_{kind}_fwd")
                     continue
                 ldp_ = self.pred_pix.shape[1] if cfg.pix_mods else 0
                 cat_waves = (kind == "pix_cat" and bool(self.opt["loss_rows"]) and maxc <= 16 and ldp_ % 4 == 0
@@ -1587,22 +1563,8 @@ class Engine:
                     m["lane"] = 1
                     if j == 0:
                         m["wait"] = tuple(m["wait"]) + (prod["signal"],)
-                cat = [i for i, n in enumerate(names) if n.startswith("loss:pix_cat")]
-                if cat and bool(self.opt["cat_side"]) and self.loss_onepass and any(n.startswith("loss:pix_cont") for n in names):
-                    hp = f[names.index("head:pix")][3]          # the predictions the loss reads
-                    if hp["signal"] is None:
-                        hp["signal"] = "pred_pix"
-                    for i in cat:
-                        f[i][3]["lane"] = 1
-                        f[i][3]["wait"] = tuple(f[i][3]["wait"]) + (hp["signal"],)
-                    # the side lane is an in-order stream: the loss goes behind the image-head chain in the op list as well
-                    moved = [f[i] for i in cat]
-                    for i in reversed(cat):
-                        del f[i]
-                    names = [op[0] for op in f]
-                    at = max(i for i, n in enumerate(names) if n in side_names) + 1
-                    f[at:at] = moved
-                    idx = [i for i, op in enumerate(f) if op[3]["lane"] == 1 and (op[0] in side_names or op[0].startswith("loss:pix_cat"))]
+                # (the categorical pixel loss on this lane too, next to the continuous one: two cross-lane events cost more than the overlap returns,
+                #  3.645 / 3.641 vs 3.626 / 3.620 ms - profiles/r05/ab_cat_side.txt; removed)
                 f[idx[-1]][3]["signal"] = "img_side_done"
                 self._fwd_join_keys = ["img_side_done"]
         if self._front_rest is not None:          # the first main-lane op behind the fused stem kernel waits for the rest of the side-lane front
@@ -2214,8 +2176,7 @@ class Engine:
             out[c] = dict(value=float(win[0]), median=float(win.median()), avg=float(win.mean()), global_avg=float(sums[i]) / n)
         return out
 
-    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None,
-                    adamw_split=False):
+    def step_pieces(self, bwd_segments=None, weight_decay=0.05, beta1=0.9, beta2=0.95, eps=1e-8, loss_scale=1.0, guard_loss=None):
         """The whole micro-step as op tuples, grouped into the pieces a data-parallel / gradient-accumulating
         runner issues separately: [forward + loss], [gradient zeroing], [backward segment 0], [segment 1], ...,
         [AdamW]. Consecutive pieces are contiguous in the recorded program, so any run of them is ONE
@@ -2233,13 +2194,6 @@ class Engine:
                     (a[0], self.loss_slots, a[1], a[2], float(loss_scale), a[3], a[4], a[5], a[6], a[7] if dlv else None) + tuple(self._err_words()), m)
 
         segs = bwd_segments if bwd_segments is not None else [self.bwd_ops]
-        split = bool(adamw_split) and bwd_segments is None and self.lanes and bool(self.opt["adamw_split"])
-        if split:
-            from .dist import plan_buckets, split_bwd_segments
-            try:
-                cut, rng = split_bwd_segments(self.bwd_ops), plan_buckets(self.offsets, self.n_params)
-            except (StopIteration, AssertionError):
-                split = False
         # zero fills: with `zero_side` they run on the side lane, which is idle in the forward (the main lane's first wait for a side-lane
         # event - the stem GEMM waiting for the weight staging - covers the statistics; the gradient finalisation waits for "grads_zero")
         fwd = [("stats.zero", lib.mpmae_memset_async, (_p(self.stats), 0, self.stats.numel() * 4), dict(zl, signal="stats_zero") if zs else zl)]
@@ -2273,44 +2227,8 @@ class Engine:
             joins.append(op[3]["signal"])
         fetch = ("hp.fetch", lib.mpmae_hp_fetch, (C.c_void_p(self.hp_ring.data_ptr()), self.HP_SLOTS, _p(self.hp_counter),
                                                   _p(self.hp), _p(guard_loss if guard_loss is not None else self.total), self._meters()))
-        if split:
-            # The optimizer cut along the gradient buckets. hp.fetch moves in front of the backward (the loss it guards, the error words of
-            # the forward's persistent kernels and the previous update's gradient-norm partials all exist there); bucket b's update is a
-            # weight-gradient-lane op behind the bucket's last weight gradient / fold (in-order lane) that waits for the segment's last
-            # main-lane op - the last reader of the bucket's fp32 parameters (LayerNorm / GRN vectors, depthwise taps, biases; the
-            # GEMMs read the bf16 copies staged at the step front). Only the last bucket's update stays behind the backward.
-            nsl, tot = [], 0
-            for lo, hi in rng:
-                nsl.append(max(1, min(1024, -(-(hi - lo) // 2048))))
-            tot = sum(nsl)
-            slot0 = [sum(nsl[:i]) for i in range(len(nsl))]
-
-            def part(i, meta):
-                lo, hi = rng[i]
-                return (f"adamw.part{i}", lib.mpmae_adamw_part,
-                        (_p(self.pflat[lo:hi]), _p(self.gflat[lo:hi]), _p(self.mflat[lo:hi]), _p(self.vflat[lo:hi]), _p(self.hp), beta1, beta2,
-                         eps, weight_decay, hi - lo, _p(self.decay_mask[lo:hi]), _p(self.gnorm2), slot0[i], nsl[i], tot), meta)
-            bw = [fin(True), fetch + (dict(lane=0, wait=(), signal=None),)]
-            for i, sg in enumerate(cut):
-                bw += list(sg)
-                if i + 1 < len(cut):
-                    mains = [op for op in sg if op[3]["lane"] == 0]
-                    if mains[-1][3]["signal"] is None:
-                        self._evseq += 1
-                        mains[-1][3]["signal"] = f"o{self._evseq}"
-                    bw.append(part(i, dict(lane=1, wait=(mains[-1][3]["signal"],), signal=None)))
-            last_side = {}
-            for op in bw:
-                if op[3]["lane"] != 0:
-                    last_side[op[3]["lane"]] = op
-            joins = []
-            for ln, op in sorted(last_side.items()):
-                if op[3]["signal"] is None:
-                    self._evseq += 1
-                    op[3]["signal"] = f"j{self._evseq}"
-                joins.append(op[3]["signal"])
-            self._bucket_keys = []
-            return [fwd, zero, bw, [part(len(cut) - 1, dict(lane=0, wait=tuple(joins), signal=None))]]
+        # (the optimizer cut along the gradient buckets - a bucket's AdamW on the weight-gradient lane as soon as its gradients are final - was built in
+        #  round 5, did not move the step (3.653 / 3.656 vs 3.650 / 3.647 ms, profiles/r05/ab_adamw_split.txt) and is removed)
         opt = [fetch + (dict(lane=0, wait=tuple(joins), signal=None),),
                ("adamw", lib.mpmae_adamw, (_p(self.pflat), _p(self.gflat), _p(self.mflat), _p(self.vflat), _p(self.hp),
                                            beta1, beta2, eps, weight_decay, self.n_params, _p(self.decay_mask), _p(self.gnorm2)), m0)]
@@ -2383,9 +2301,6 @@ class Engine:
         # backward-only replays) must start from zero again, like the gradient buffer (the step programs zero the whole arena once per step)
         for blk in self.blocks + self.decs:
             blk["S01"].zero_()
-            for k in ("Tw2", "dbt"):
-                if k in blk:
-                    blk[k].zero_()
         # d(total)/d(log_vars) and the per-modality coefficients (second finalize pass adds dlog_vars)
         self.finalize_loss(st, True, self._loss_scale)
         self._run(self.bwd_ops, st)

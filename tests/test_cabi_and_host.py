@@ -224,10 +224,10 @@ def test_bench_refuses_timing_experiment_variables_and_stamps_options():
                            cwd=ROOT, env=dict(base, **{var: ".wgrad"}))
         assert r.returncode == 3 and "refusing" in r.stderr, (r.returncode, r.stderr[-500:])
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=600,
-                       cwd=ROOT, env=dict(base, MPMAE_ENGINE_OPTS="tail_main=0,TN3_BLOCKS=64"))
+                       cwd=ROOT, env=dict(base, MPMAE_ENGINE_OPTS="tail_main=1,TN3_BLOCKS=64"))
     assert r.returncode == 0, r.stderr[-1500:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert d["config"]["options"] == {"engine": {"tail_main": 0}, "library": {"TN3_BLOCKS": 64}}
+    assert d["config"]["options"] == {"engine": {"tail_main": 1}, "library": {"TN3_BLOCKS": 64}}
     src = open(os.path.join(ROOT, "mmearth-train_amd", "engine.py")).read()
     assert "MPMAE_SKIP_OPS" not in src and "MPMAE_DEFER_EXPERIMENT" not in src
 

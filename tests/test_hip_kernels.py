@@ -331,112 +331,9 @@ def test_direct_to_lds_gemm_matches_torch(M, N, K, resid):
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
     if resid:
         g.R, g.ldr = r.data_ptr(), N
-    assert lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0       # this library's kernel (the deep-K case would go to the vendor route)
-    try:
-        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-    finally:
-        lib.mpmae_set_option(L.OPT["BLASLT"], 0)      # (the default since round 5)
+    assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
     ref = a.float() @ w.float().t() + bias + (r.float() if resid else 0)
     assert _rel(c, ref) < 6e-3
-
-
-@pytest.mark.parametrize("M,N,K,resid,bias_on,act_on", [(12544, 2048, 512, False, True, False), (12544, 512, 2048, True, True, True),
-                                                        (8300, 2816, 512, False, True, True), (9000, 520, 2816, True, False, False),
-                                                        (8192, 264, 64, False, False, True), (10000, 1032, 128, True, True, False)])
-def test_256_row_tile_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
-    """mpmae_gemm bf16 NT with M >= 8192, N >= 256, K % 64 == 0 takes the 256-row-tile kernel (gemm_nt4.cuh: 8 waves of 32 x 32 x 16
-    MFMA, DMA double buffer, transposed issue with permuted B rows, XCD-aware tile order): both tile widths, ragged last row / column
-    tiles (N % 16 == 8 cuts a lane's 16-column group in half), optional bias / residual / row mask; against an fp32 matmul of the
-    same bf16 operands, and bit-for-bit against the 128 x 128 kernels' rounding contract (one bf16 rounding of the fp32 sum)."""
-    L, lib = _lib()
-    dev = "cuda"
-    torch.manual_seed(M + N + K)
-    a = torch.randn(M, K, device=dev).to(bf)
-    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
-    bias = torch.randn(N, device=dev)
-    r = torch.randn(M, N, device=dev).to(bf)
-    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
-    c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-    g = L.GemmArgs()
-    g.A, g.B, g.C = a.data_ptr(), w.data_ptr(), c.data_ptr()
-    g.bias = bias.data_ptr() if bias_on else 0
-    g.act = act.data_ptr() if act_on else 0
-    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
-    if resid:
-        g.R, g.ldr = r.data_ptr(), N
-    nt4_0, blas_0 = lib.mpmae_get_option(L.OPT["NT4"]), lib.mpmae_get_option(L.OPT["BLASLT"])
-    assert lib.mpmae_set_option(L.OPT["NT4"], 2) == 0          # every eligible shape (1: only the shapes where it once measured faster; default 0 since round 5)
-    assert lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0       # (no vendor route: this test pins gemm_nt4_kernel)
-    try:
-        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-    finally:
-        lib.mpmae_set_option(L.OPT["NT4"], nt4_0)
-    ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
-    if act_on:
-        ref = ref * act.bool()[:, None]
-    assert _rel(c, ref) < 6e-3
-    if act_on:
-        assert (c[~act.bool()] == 0).all()
-    c2 = torch.empty_like(c)
-    g.C = c2.data_ptr()
-    assert lib.mpmae_set_option(L.OPT["NT4"], 0) == 0
-    try:
-        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-    finally:
-        lib.mpmae_set_option(L.OPT["NT4"], nt4_0)
-        lib.mpmae_set_option(L.OPT["BLASLT"], blas_0)
-    torch.cuda.synchronize()
-    d = (c.float() - c2.float()).abs()
-    assert (d <= 2.0 ** -7 * c2.float().abs() + 1e-6).all(), float(d.max())      # same operands, fp32 accumulation order differs: <= 1 bf16 ulp
-
-
-@pytest.mark.parametrize("M,N,K,resid,bias_on", [(12544, 512, 2048, True, True), (12544, 2816, 512, False, True), (12544, 512, 2816, False, False),
-                                                 (4100, 384, 1408, True, False)])
-def test_vendor_blas_route_for_plain_gemms_matches_torch_and_own_kernels(M, N, K, resid, bias_on):
-    """mpmae_gemm bf16, no prologue, epilogue = (+ bias) (+ residual), no row mask, M >= 4096, N K >= 512 Ki: the hipBLASLt route
-    (MPMAE_OPT_BLASLT = 1; OFF by default since round 5 - a yardstick; capi_gemm.hip: try_blaslt - row-major C = A W^T as the column-major product with op(T) on the
-    weight, fp32 bias through HIPBLASLT_EPILOGUE_BIAS, the residual as C with beta = 1). Against an fp32 matmul of the same bf16 operands
-    (6e-3 relative to the tensor), against this library's own kernel on the same operands (one bf16 rounding of an fp32 sum whose order
-    differs: <= 1 bf16 ulp), and a row mask must NOT take the route (masked rows come back zero)."""
-    L, lib = _lib()
-    dev = "cuda"
-    assert lib.mpmae_get_option(L.OPT["BLASLT"]) == 0      # the default: every kernel of the step is this library's own
-    torch.manual_seed(M + N + K)
-    a = torch.randn(M, K, device=dev).to(bf)
-    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
-    bias = torch.randn(N, device=dev)
-    r = torch.randn(M, N, device=dev).to(bf)
-    g = L.GemmArgs()
-    g.A, g.B = a.data_ptr(), w.data_ptr()
-    g.bias = bias.data_ptr() if bias_on else 0
-    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
-    if resid:
-        g.R, g.ldr = r.data_ptr(), N
-    outs = []
-    for opt in (1, 0):
-        c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-        g.C = c.data_ptr()
-        assert lib.mpmae_set_option(L.OPT["BLASLT"], opt) == 0
-        try:
-            assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-        finally:
-            lib.mpmae_set_option(L.OPT["BLASLT"], 0)      # (the default since round 5)
-        torch.cuda.synchronize()
-        outs.append(c)
-    ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
-    assert _rel(outs[0], ref) < 6e-3 and _rel(outs[1], ref) < 6e-3
-    d = (outs[0].float() - outs[1].float()).abs()
-    assert (d <= 2.0 ** -7 * outs[1].float().abs() + 1e-6).all(), float(d.max())
-    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
-    c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-    g.C, g.act = c.data_ptr(), act.data_ptr()
-    assert lib.mpmae_set_option(L.OPT["BLASLT"], 1) == 0
-    try:
-        assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-    finally:
-        lib.mpmae_set_option(L.OPT["BLASLT"], 0)
-    torch.cuda.synchronize()
-    assert (c[~act.bool()] == 0).all() and _rel(c, ref * act.bool()[:, None]) < 6e-3
 
 
 @pytest.mark.parametrize("M,Cc", [(1000, 40), (333, 80)])
@@ -504,115 +401,6 @@ def test_dz_recomputation_matches_the_materialised_path(M, Cc):
     assert _rel(dh1, r_dh) < 1.5e-2
 
 
-@pytest.mark.parametrize("M,N,K,resid,bias_on,act_on", [(12544, 512, 2048, True, True, False), (4100, 392, 1408, True, True, True),
-                                                        (3584, 320, 1280, False, False, True), (8200, 520, 2816, False, True, False)])
-def test_deep_k_ring_gemm_matches_torch(M, N, K, resid, bias_on, act_on):
-    """MPMAE_OPT_NT5 = 1 (not the default): the deep-K NT kernel of csrc/gemm_nt5.cuh - 128 x 256 tile, 64 x 128 wave tiles, three-stage
-    DMA ring with counted vmcnt waits and inline-asm fragment reads, XCD-aware tile order - on plain products with K >= 1024: ragged
-    last row / column tiles, optional bias / residual / row mask; against an fp32 matmul of the same bf16 operands and within one bf16
-    ulp of the 128 x 128 kernel (same rounding contract: one bf16 rounding of the fp32 sum)."""
-    L, lib = _lib()
-    dev = "cuda"
-    torch.manual_seed(M + N + K)
-    a = torch.randn(M, K, device=dev).to(bf)
-    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
-    bias = torch.randn(N, device=dev)
-    r = torch.randn(M, N, device=dev).to(bf)
-    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
-    g = L.GemmArgs()
-    g.A, g.B = a.data_ptr(), w.data_ptr()
-    g.bias = bias.data_ptr() if bias_on else 0
-    g.act = act.data_ptr() if act_on else 0
-    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
-    if resid:
-        g.R, g.ldr = r.data_ptr(), N
-    outs = []
-    for nt5 in (1, 0):
-        c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-        g.C = c.data_ptr()
-        assert lib.mpmae_set_option(L.OPT["NT5"], nt5) == 0 and lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0
-        try:
-            assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-        finally:
-            lib.mpmae_set_option(L.OPT["NT5"], 0)
-        torch.cuda.synchronize()
-        outs.append(c)
-    ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
-    if act_on:
-        ref = ref * act.bool()[:, None]
-        assert (outs[0][~act.bool()] == 0).all()
-    assert _rel(outs[0], ref) < 6e-3
-    d = (outs[0].float() - outs[1].float()).abs()
-    assert (d <= 2.0 ** -7 * outs[1].float().abs() + 1e-6).all(), float(d.max())
-
-
-@pytest.mark.parametrize("M,N,K,resid,bias_on,act_on,lvl", [(12544, 512, 2048, True, True, False, 1), (12544, 512, 2816, False, False, False, 1),
-                                                            (4864, 320, 1280, True, True, True, 1), (4100, 392, 1408, True, True, True, 1),
-                                                            (2048, 256, 1024, False, True, False, 1), (12544, 2048, 512, False, True, False, 2),
-                                                            (12544, 2816, 512, False, True, False, 2)])
-def test_stream_k_gemm_matches_torch_and_leaves_its_flags_zero(M, N, K, resid, bias_on, act_on, lvl):
-    """MPMAE_OPT_SK (not the default: measured slower than whole tiles; round 5): the stream-K NT kernel of csrc/gemm_sk.cuh - gemm_nt5's 128 x 256 tile cut into 64-deep K
-    iterations, every workgroup the same number of iterations, partial tiles fixed up through write-through fp32 slots and relaxed
-    agent-scope flags - on the decoder / head / stage-3 shapes, ragged row / column tiles, optional bias / residual / row mask:
-    (a) against an fp32 matmul of the same bf16 operands and within one bf16 ulp of the 128 x 128 whole-tile kernel; (b) the hand-off
-    under UNEVEN load (a second stream keeps part of the GPU busy with matmuls of its own, so workgroups of one launch start at
-    different times) repeated 12 times: bit-identical to the first result every time (fp32 partials added in a fixed order);
-    (c) the flags are all zero after every launch (self-resetting: no memset between launches)."""
-    L, lib = _lib()
-    dev = "cuda"
-    torch.manual_seed(M + N + K)
-    a = torch.randn(M, K, device=dev).to(bf)
-    w = (torch.randn(N, K, device=dev) / math.sqrt(K)).to(bf)
-    bias = torch.randn(N, device=dev)
-    r = torch.randn(M, N, device=dev).to(bf)
-    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
-    ws = torch.empty(256 * 128 * 256, dtype=torch.float32, device=dev)
-    flags = torch.zeros(L.SK_FLAGS, dtype=torch.int32, device=dev)
-    g = L.GemmArgs()
-    g.A, g.B = a.data_ptr(), w.data_ptr()
-    g.bias = bias.data_ptr() if bias_on else 0
-    g.act = act.data_ptr() if act_on else 0
-    g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.rpg = M, N, K, K, K, N, M
-    g.ws, g.ws_floats, g.sk_flags = ws.data_ptr(), ws.numel(), flags.data_ptr()
-    if resid:
-        g.R, g.ldr = r.data_ptr(), N
-    outs = []
-    try:
-        for sk in (lvl, 0):
-            c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-            g.C = c.data_ptr()
-            assert lib.mpmae_set_option(L.OPT["SK"], sk) == 0 and lib.mpmae_set_option(L.OPT["BLASLT"], 0) == 0
-            assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-            torch.cuda.synchronize()
-            outs.append(c)
-            assert int(flags.abs().sum()) == 0
-        ref = a.float() @ w.float().t() + (bias if bias_on else 0) + (r.float() if resid else 0)
-        if act_on:
-            ref = ref * act.bool()[:, None]
-            assert (outs[0][~act.bool()] == 0).all()
-        assert _rel(outs[0], ref) < 6e-3
-        # one bf16 ulp + the fp32 summation-order noise of the split sums (partials of magnitude ~8: a few 2^-23 steps each; the whole-tile
-        # kernels all accumulate k in the same order and agree bit for bit among themselves, which the 1e-6 of the test above relies on)
-        d = (outs[0].float() - outs[1].float()).abs()
-        assert (d <= 2.0 ** -7 * outs[1].float().abs() + 2e-5).all(), float(d.max())
-        # (b) uneven load, repeated
-        assert lib.mpmae_set_option(L.OPT["SK"], lvl) == 0
-        side = torch.cuda.Stream()
-        xs = torch.randn(4096, 4096, device=dev, dtype=bf)
-        for it in range(12):
-            c = torch.full((M, N), 7.0, device=dev, dtype=bf)
-            g.C = c.data_ptr()
-            with torch.cuda.stream(side):
-                for _ in range(1 + it % 3):
-                    xs @ xs
-            assert lib.mpmae_gemm(1, 0, 2 if resid else 0, C.byref(g), _st()) == 0
-            torch.cuda.synchronize()
-            assert torch.equal(c, outs[0]), f"repeat {it}: {float((c.float() - outs[0].float()).abs().max())}"
-            assert int(flags.abs().sum()) == 0
-    finally:
-        lib.mpmae_set_option(L.OPT["SK"], 0)
-
-
 @pytest.mark.parametrize("M,Cc", [(1000, 40), (64, 40), (333, 80), (77824, 80), (100000, 40)])
 def test_weight_gradient_as_statistics_pass_matches_torch_and_the_statistics_kernel(M, Cc):
     """mpmae_rs which = 6 (csrc/rst.cuh, round 6): T = dout^T gelu(h), db2 = sum_rows dout in ONE read of dout and h, against fp32 matmuls on the
@@ -660,9 +448,13 @@ def test_weight_gradient_as_statistics_pass_matches_torch_and_the_statistics_ker
     assert (S1 - u1).abs().max().item() <= 6e-3 * u1.abs().max().item() + 1e-4
     z = (g * scale + beta)
     assert _rel(dW2, dout.float().t() @ z) < 3e-3 and _rel(db2, dbref) < 1e-4
-    # the fused form (what the engine issues): the slab fold adds straight into S0 / S1 / dW2 / db2, T is never stored
+    # the fused form (what the engine issues): every workgroup emits its share of S0 / S1 (folded by the call itself); the big slabs stay in ws for
+    # mpmae_rs_wgrad_fold -> dW2, db2 (the weight-gradient lane's op); T is never stored
     f0, f1, fW, fb = torch.ones(H, device=dev), torch.ones(H, device=dev), torch.ones(Cc, H, device=dev), torch.ones(Cc, device=dev)
-    assert lib.mpmae_rs(6, C.byref(args(A=dout, R=h, W=W2, ldw=H, v0=scale, v1=beta, s0=f0, s1=f1, fin_dgamma=fW, fin_dbeta=fb)), _st()) == 0
+    rows = C.c_int(0)
+    assert lib.mpmae_rs(6, C.byref(args(A=dout, R=h, W=W2, ldw=H, s0=f0, s1=f1, wg_rows=C.addressof(rows))), _st()) == 0
+    assert rows.value >= 1
+    assert lib.mpmae_rs_wgrad_fold(Cc, H, ws.data_ptr(), rows.value, scale.data_ptr(), beta.data_ptr(), fW.data_ptr(), fb.data_ptr(), _st()) == 0
     torch.cuda.synchronize()
     for got, ref in ((f0 - 1, S0), (f1 - 1, S1), (fW - 1, dW2), (fb - 1, db2)):
         assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5      # (same products, another summation order)
@@ -705,7 +497,7 @@ def test_pointwise1_weight_gradient_inside_the_fused_backward_kernel(M):
                         _st()) == 0
     dW1, db1 = torch.full((H, Cc), 0.25, device=dev), torch.full((H,), 0.25, device=dev)
     assert rows.value >= 1
-    assert lib.mpmae_rs_wgrad_fold(Cc, ws2.data_ptr(), rows.value, lng.data_ptr(), lnb.data_ptr(), dW1.data_ptr(), db1.data_ptr(), _st()) == 0
+    assert lib.mpmae_rs_wgrad_fold(H, Cc, ws2.data_ptr(), rows.value, lng.data_ptr(), lnb.data_ptr(), dW1.data_ptr(), db1.data_ptr(), _st()) == 0
     torch.cuda.synchronize()
     assert torch.equal(dd1, dd0) and _rel(g1, g0) < 1e-5
     assert (dh1 == 7.0).all(), "dh must not be written in the fused form"

@@ -14,12 +14,12 @@ import sys
 # weight-gradient GEMMs and wgrad_group_fold belong to "wgrad"; reduce_partials<2> / group2 to "dwconv7_wgrad"; reduce_partials<0> (GRN
 # column statistics) and <1> (LayerNorm gamma / beta partials) are launched by the fused pointwise entry points: "rs".
 FAMILIES = collections.OrderedDict([
-    ("rs", r"rsc_wide_kernel|rsc_wide1_kernel|rsp_wide_kernel|rsc_narrow_kernel|rsp_narrow_kernel|rsn3_bwd_kernel|rs_kernel|reduce_partials_kernel<0>|reduce_partials_kernel<1>"),
-    ("wgrad", r"gemm_tn2_kernel|gemm_tn3_kernel|gemm_tng_kernel|gemm_tng48_kernel|gemm_tn_bf16_kernel|wgrad_kernel|wgrad_group_fold_kernel|reduce_partials_kernel<3>"),
+    ("rs", r"rsc_wide_kernel|rsc_wide1_kernel|rsp_wide_kernel|rsc_narrow_kernel|rsp_narrow_kernel|rsn3_bwd_kernel|rst_kernel|rs_kernel|reduce_partials_kernel<0>|reduce_partials_kernel<1>"),
+    ("wgrad", r"gemm_tn2_kernel|gemm_tn3_kernel|gemm_tng_kernel|gemm_tng48_kernel|gemm_tn_bf16_kernel|wgrad_kernel|wgrad_group_fold_kernel|wg_fold_kernel|reduce_partials_kernel<3>"),
     ("dwconv7", r"dwconv7_mfma_kernel|dwconv7_v6_kernel|dwconv7_v6s1_kernel|dwconv7_v5_kernel"),
     ("dwconv7_wgrad", r"dwconv7_wgrad|reduce_partials_kernel<2>|reduce_partials_group2_kernel"),
     ("ps_fwd", r"ps_fwd_kernel"),
-    ("gemm_nt", r"gemm_nt_bf16_kernel|gemm_nt4_kernel|gemm_nt3_kernel|gemm_kernel|^Cijk_|Cijk_Alik"),      # (Cijk_*: hipBLASLt kernels of the plain decoder / head GEMMs)
+    ("gemm_nt", r"gemm_nt_bf16_kernel|gemm_nt3_kernel|gemm_kernel"),
     ("loss", r"loss_"),
     ("ln", r"ln_fwd|ln_bwd"),
     ("stem", r"stem_front_kernel|stem_tail|im2col3_kernel|dwstride2_"),

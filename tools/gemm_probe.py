@@ -45,12 +45,7 @@ for M, N, K, name in shapes:
     assert lib.mpmae_gemm(1, 0, 0, C.byref(g), st) == 0
     err0 = rel(c.float(), ref)
     us = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
-    lib.mpmae_set_option(_lib.OPT["NT4"], 0)
-    us0 = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
-    lib.mpmae_set_option(_lib.OPT["NT4"], 2)
-    us2 = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
-    lib.mpmae_set_option(_lib.OPT["NT4"], 1)
-    print(f"{'':15s} tiles: 128x128 {us0:6.1f} us | 256x256 / 256x128 8-wave (NT4=2) {us2:6.1f} us")
+    us0 = us
     usv = t(lambda: torch.nn.functional.linear(a, w))
     print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF (128-row tiles {us0:6.1f} us) | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}", flush=True)
     if os.environ.get("BRIEF"):

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Stand-alone time and agreement of the one-shot wide fused pointwise kernels (csrc/rsc1.cuh, MPMAE_OPT_RSC1) against the chunk-streaming
+"""(Round 6: the workgroup-count options this probe swept - RSP_WGS, RSP_NWGS, RSC1_WGS, RSC1_CPS - are frozen at the values it found; the sweep below
+fails with KeyError on those names and is kept as the record of HOW they were found: profiles/r05/rs1_probe.txt, rsp_*_probe.txt.)
+Stand-alone time and agreement of the one-shot wide fused pointwise kernels (csrc/rsc1.cuh, MPMAE_OPT_RSC1) against the chunk-streaming
 kernels (rsc.cuh) at the stage-2 / stage-3 shapes of the headline workload: mpmae_rs which = 0 (LN + pw1 + GELU^2 sums) and
 which = 1 (pw2.dgrad + statistics).  python tools/probes/rs1_probe.py"""
 import ctypes as C

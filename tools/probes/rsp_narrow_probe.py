@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""Stand-alone time and agreement of the persistent burst-load NARROW fused pointwise kernels (csrc/rsp.cuh, MPMAE_OPT_RSP) against the
+"""(Round 6: the workgroup-count options this probe swept - RSP_WGS, RSP_NWGS, RSC1_WGS, RSC1_CPS - are frozen at the values it found; the sweep below
+fails with KeyError on those names and is kept as the record of HOW they were found: profiles/r05/rs1_probe.txt, rsp_*_probe.txt.)
+Stand-alone time and agreement of the persistent burst-load NARROW fused pointwise kernels (csrc/rsp.cuh, MPMAE_OPT_RSP) against the
 chunk-streaming kernels (rsc.cuh) at the stage-0 / stage-1 shapes of the headline workload: mpmae_rs which = 4 (GRN + pw2 + residual, folded
 finalisation) and which = 5 (dz recomputed, dh, pw1.dgrad, LayerNorm backward).   python tools/probes/rsp_narrow_probe.py"""
 import ctypes as C

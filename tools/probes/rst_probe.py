@@ -2,7 +2,8 @@
 """Stand-alone time of the weight-gradient-as-statistics pass (csrc/rst.cuh, mpmae_rs which = 6: T = dout^T gelu(h) + db2, incl. its slab fold)
 against the two launches it replaces at the stage-0 / stage-1 shapes of the headline workload: the statistics-only pass (mpmae_rs which = 1,
 out = NULL, incl. its fold) and pwconv2's weight gradient with the GRN operand prologue (mpmae_wgrad, gemm_tn2 + fold).
-    python tools/probes/rst_probe.py [RST_WGS values ...]"""
+    python tools/probes/rst_probe.py
+(the sweep over workgroup counts that fixed the launch shapes - RST_WGS, an option until the round-6 prune - is in profiles/r06/rst_probe.txt)"""
 import ctypes as C
 import math
 import os
@@ -36,7 +37,7 @@ def timed(fn, reps=40):
 
 
 def main():
-    wgs = [int(v) for v in sys.argv[1:]] or [0]
+    wgs = [0]
     for M, Cc in ((311296, 40), (77824, 80)):
         H = 4 * Cc
         torch.manual_seed(M + Cc)
@@ -72,16 +73,17 @@ def main():
         f0, f1, fW, fb = torch.zeros(H, device=dev), torch.zeros(H, device=dev), torch.zeros(Cc, H, device=dev), torch.zeros(Cc, device=dev)
         for nw in (4, 16):
             for w in wgs:
-                old = lib.mpmae_get_option(L.OPT["RST_WGS"]), lib.mpmae_get_option(L.OPT["RST_NW"])
-                lib.mpmae_set_option(L.OPT["RST_WGS"], w)
+                old = lib.mpmae_get_option(L.OPT["RST_NW"])
                 lib.mpmae_set_option(L.OPT["RST_NW"], nw)
                 try:
                     t = timed(rs(6, A=dout, R=h, s0=T, s1=T[Cc * H:]))
-                    tf = timed(rs(6, A=dout, R=h, W=W2, ldw=H, v0=scale, v1=beta, s0=f0, s1=f1, fin_dgamma=fW, fin_dbeta=fb))
+                    rows = C.c_int(0)
+                    tf = timed(rs(6, A=dout, R=h, W=W2, ldw=H, s0=f0, s1=f1, wg_rows=C.addressof(rows)))
+                    tw = timed(lambda: lib.mpmae_rs_wgrad_fold(Cc, H, ws.data_ptr(), rows.value, scale.data_ptr(), beta.data_ptr(), fW.data_ptr(), fb.data_ptr(), st()))
                 finally:
-                    lib.mpmae_set_option(L.OPT["RST_WGS"], old[0])
-                    lib.mpmae_set_option(L.OPT["RST_NW"], old[1])
-                print(f"    which 6, RST_NW = {nw:2d}, RST_WGS = {w:5d}: raw T + reduce_partials {t:6.1f} us = {nbytes / t / 1e6:.2f} TB/s | fused fold (S0, S1, dW2, db2) {tf:6.1f} us",
+                    lib.mpmae_set_option(L.OPT["RST_NW"], old)
+                print(f"    which 6, RST_NW = {nw:2d}: raw T + reduce_partials {t:6.1f} us = {nbytes / t / 1e6:.2f} TB/s | with S0 / S1 shares + small fold (main lane) {tf:6.1f} us, "
+                      f"dW2 / db2 fold of {rows.value} slab rows (weight-gradient lane) {tw:6.1f} us",
                       flush=True)
 
 
