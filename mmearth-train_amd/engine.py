@@ -171,11 +171,21 @@ class Engine:
         self.fwd_ops, self.bwd_ops = [], []
         self._build_forward()
         self._build_backward()
-        if self._mx_wq:            # MX copies of the decoder weights: right behind the weight staging at the head of the forward program
+        if self._mx_wq:            # MX copies of the staged weights: right behind the weight staging, on ITS lane (round 6: the side lane - eight 6.5 us
+            # launches sat on the main lane in front of the forward); every MX GEMM waits for the last of them ("wq_done": in-order lane)
             wq = []
             for wname, (w, buf) in self._mx_wq.items():
                 self._quant(wq, "prep:" + wname + ".quant", w["t"], w["ld"], buf)
-            self.fwd_ops[1:1] = wq
+            at = next(i for i, op in enumerate(self.fwd_ops) if op[0] == "prep")
+            lane = self.fwd_ops[at][3]["lane"]
+            for op in wq:
+                op[3]["lane"] = lane
+            if lane:
+                wq[-1][3]["signal"] = "wq_done"
+                for op in self.fwd_ops + self.bwd_ops:
+                    if op[3]["kind"].startswith("gemm_mx"):
+                        op[3]["wait"] = tuple(op[3]["wait"]) + ("wq_done",)
+            self.fwd_ops[at + 1:at + 1] = wq
         self.step_count = 0
 
     # ------------------------------------------------------------------ params
@@ -718,6 +728,14 @@ class Engine:
     def _mx_block(self, blk):
         return self.fp8 and not blk["sparse"] and blk["C"] % 128 == 0
 
+    def _mx_sparse(self, blk):
+        """Round 6 (BASELINE config 5, 'fp8 MFMA pointwise path' on the ENCODER): the sparse blocks whose K = H pointwise products are plain tiled GEMMs
+        (stage 3 of atto: pwconv2 forward and pwconv1's data gradient, K = 1280, rows masked by the activity bytes) take the MX-fp8 GEMM too: the
+        activation operand (z, dh) is quantised by mpmae_quant_mx, the staged weights once per step. The K = C products of those blocks (320: not a
+        multiple of the 128-element MX slab) and every block of stages 0-2 run inside the fused row-streaming kernels, whose matrix time is 6 % of
+        their duration (profiles/r05/mfma_util.txt) - nothing for a faster MFMA to shorten."""
+        return self.fp8 and blk["sparse"] and blk.get("rs_n") is None and blk["H"] % 128 == 0 and blk["C"] % 8 == 0
+
     def _mx_weight(self, wname):
         """Staged bf16 weight [N][K] -> e4m3 + scales, re-quantised once per step right after weight staging (fwd op list)."""
         w = self.w[wname]
@@ -938,7 +956,7 @@ class Engine:
                      _p(P[nm["gb"]]), eps, M, H, rpg, _p(blk["Gx"]), _p(blk["Ainv"]), _p(blk["scale"]),
                      kind="grn_group_fwd", nbytes=2 * M * H * esz)
         afin = blk["afin"] = (not fold and not gg and rs_n != "fused" and G == 1 and blk["sparse"] and bool(self.opt["grn_apply_fin"])
-                              and not self._mx_block(blk) and H % 8 == 0 and H <= 8160)
+                              and H % 8 == 0 and H <= 8160)
         if gg or afin:
             pass
         elif not fold:
@@ -967,7 +985,7 @@ class Engine:
         elif not gg:
             self._op(lst, tag + ":grn.apply", lib.mpmae_grn_apply, dt, _p(blk["h"]), _p(blk["z"]), _p(blk["scale"]),
                      _p(P[nm["gb"]]), M, H, rpg, _p(act), kind="grn_apply", nbytes=2 * M * H * esz)
-        if self._mx_block(blk):
+        if self._mx_block(blk) or self._mx_sparse(blk):
             qz, qw = self._mx_buf(tag + ".z", M, H), self._mx_weight(tag + ".W2")
             self._quant(lst, tag + ":z.quant", blk["z"], H, qz)
             self._gemm_mx(lst, tag + ":pw2", "RESID", qz, qw, bias=P[nm["b2"]], C=blk["out"], R=x, M=M, N=Cc, K=H, ldc=Cc, ldr=Cc, act=act)
@@ -1107,7 +1125,7 @@ class Engine:
                      **(dict(fin_sum=blk["S1"], fin_sum0=blk["S0"], fin_gamma=P[nm["gg"]], fin_gx=blk["Gx"],
                              fin_ainv=blk["Ainv"], fin_out=blk["coef"], fin_dgamma=Gd[nm["gg"]],
                              fin_dbeta=Gd[nm["gb"]]) if fold else {}))
-        elif self._mx_block(blk):
+        elif self._mx_block(blk) or self._mx_sparse(blk):
             qd, qw = self._mx_buf(tag + ".dh", M, H), self._mx_weight(tag + ".W1T")
             self._quant(lst, tag + ":dh.quant", dz, H, qd)
             self._gemm_mx(lst, tag + ":pw1.dgrad", "STORE", qd, qw, C=dxn, M=M, N=Cc, K=H, ldc=Cc)
@@ -1237,7 +1255,7 @@ class Engine:
         C0, p, k = dims[0], self.p, cfg.stem_k
         orig = self.orig_stem = bool(getattr(cfg, "use_orig_stem", False))
         # weight staging only feeds the first GEMM: on the side lane next to mask / activity / im2col (which only read the inputs)
-        prep_side = self.lanes and bool(self.opt["prep_side"]) and not self.fp8
+        prep_side = self.lanes and bool(self.opt["prep_side"])
         # (prep_late: issued behind the activity ops instead, see below)
         prep_late = (prep_side and bool(self.opt["prep_late"]) and bool(self.opt["front_side"]) and self.track_activity
                      and bool(self.opt["stem_front"]) and bool(self.opt["stem_fused"]) and bool(self.opt["stem_im2col"]) and dt != F32 and p == 8

@@ -3,7 +3,7 @@
 (max(algorithmic bytes / 8 TB/s, flops / 2.5 PF)), in program order, with per-lane totals: where the dependent chain is far from
 its bound. An op's time includes the second-stage folds its entry point launches.
 
-    MPMAE_ENGINE_OPTS="..." python tools/op_table.py [--batch 256] [--reps 5]
+    MPMAE_ENGINE_OPTS="..." python tools/op_table.py [--batch 256] [--reps 5] [--dtype bf16|fp8] [--subset all_mod|pix_mod]
 """
 import argparse
 import os
@@ -22,9 +22,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--subset", default="all_mod")
     a = ap.parse_args()
-    cfg = make_cfg()
-    eng = Engine(cfg, a.batch, dtype="bf16", device="cuda:0")
+    from mmearth_train_amd import MODALITIES as M
+    cfg = make_cfg(out_modalities=M.subset(a.subset))
+    eng = Engine(cfg, a.batch, dtype=a.dtype, device="cuda:0")
     eng.load_state_dict(make_state_dict(cfg, seed=0))
     eng.set_inputs(*make_inputs(cfg, a.batch, seed=1))
     eng.forward(); eng.backward()
