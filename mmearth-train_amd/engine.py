@@ -608,6 +608,8 @@ class Engine:
         self._group_pending.append((name, list(reads), kw))
         # a ring slot is reused every len(ring) blocks: flush before a later block of the same stage could overwrite an operand
         # (flushing a stage's groups every 2-3 blocks, so that the side lane starts under the stage's own chain: 3.66-3.68 vs 3.648 ms - not kept)
+        # (re-measured in round 6 with the lighter weight-gradient lane, which idles ~300 us under the stage-2 chain: every 2 / 3 blocks 3.407-3.420 / 3.412 vs
+        #  3.420-3.428 ms - inside the noise again, profiles/r06/ab_group_flush_not_kept.txt)
         if len(self._group_pending) >= 2 * min(_lib.TNG_MAXP // 2, max(1, min(len(self.scr_dz2), len(self.scr_dx)) - 2)):
             self._group_flush(lst)
 
