@@ -195,6 +195,11 @@ typedef struct MpmaeRsArgs {
    * pwconv1's transpose-read product over dh and xn nor the forward's xn store is needed. mpmae_rs_wgrad_fold folds the slab rows into the
    * parameter gradients. wg_ws_floats >= workgroups * (H * C + H) (2 workgroups per CU). which = 6 writes ITS slab-row count to *wg_rows too. */
   float* wg_ws; size_t wg_ws_floats; int* wg_rows;
+  /* Optional (which = 4, C = 40 / 80 / 96, the LAST block of a stage; round 6): the LayerNorm in front of the 2x2/2 downsample convolution
+   * (convnextv2_sparse.py:131-137) fused into this kernel's epilogue - exactly mpmae_ln_fwd_down on the row it has just computed: dn_xhat [M,C],
+   * dn_rstd [M], dn_y = affine output in the grouped [M/4][4C] operand layout of the convolution, dn_gamma / dn_beta [C], dn_S = points per patch
+   * side of THIS stage (even). `out` may then be NULL (nothing else reads the stage output). */
+  void* dn_xhat; float* dn_rstd; void* dn_y; const float* dn_gamma; const float* dn_beta; int dn_S;
 } MpmaeRsArgs;
 int mpmae_rs(int which, const MpmaeRsArgs* args, mpmae_stream_t stream);
 /* Second stage of the weight gradients accumulated inside main-lane kernels (MpmaeRsArgs.wg_ws; mpmae_rs which = 6): `rows` fp32 slab rows [A*B | A] ->

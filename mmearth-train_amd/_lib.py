@@ -104,7 +104,8 @@ class RsArgs(C.Structure):
                 ("fin_ainv", c_void_p), ("fin_out", c_void_p), ("fin_dgamma", c_void_p), ("fin_dbeta", c_void_p),
                 ("fin_eps", C.c_float), ("dz_dout", c_void_p), ("dz_w2t", c_void_p), ("dz_ldw2", c_int), ("dz_bias", c_void_p),
                 ("defer_fold", c_void_p), ("ln_done", c_int),
-                ("wg_ws", c_void_p), ("wg_ws_floats", c_size_t), ("wg_rows", c_void_p)]
+                ("wg_ws", c_void_p), ("wg_ws_floats", c_size_t), ("wg_rows", c_void_p),
+                ("dn_xhat", c_void_p), ("dn_rstd", c_void_p), ("dn_y", c_void_p), ("dn_gamma", c_void_p), ("dn_beta", c_void_p), ("dn_S", c_int)]
 
 
 class FoldDesc(C.Structure):

@@ -24,6 +24,10 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
   p.fin_out = a.fin_out; p.fin_dgamma = a.fin_dgamma; p.fin_dbeta = a.fin_dbeta; p.fin_eps = a.fin_eps;
   p.D = (const bf16_t*)a.dz_dout; p.W2 = (const bf16_t*)a.dz_w2t; p.ldw2 = a.dz_ldw2; p.hb = a.dz_bias;
   p.s0a = nullptr; p.s1a = nullptr; p.perwave = 0; p.wg_ws = a.wg_ws;
+  p.dn_xhat = (bf16_t*)a.dn_xhat; p.dn_rstd = a.dn_rstd; p.dn_y = (bf16_t*)a.dn_y; p.dn_g = a.dn_gamma; p.dn_b = a.dn_beta; p.dn_S = a.dn_S;
+  if (a.dn_y && (which != 4 || !a.dn_xhat || !a.dn_rstd || !a.dn_gamma || !a.dn_beta || a.dn_S < 2 || (a.dn_S & 1) || KC > 96 ||
+                 (((uintptr_t)a.dn_gamma | (uintptr_t)a.dn_beta) & 15))) return (int)hipErrorInvalidValue;
+  if (which == 4 && !a.out && !a.dn_y) return (int)hipErrorInvalidValue;
   const int HN = a.H;
   if (HN != 4 * KC) return (int)hipErrorInvalidValue;      // the kernels assume H = 4C (compile-time row pitch)
   if (((uintptr_t)a.bias | (uintptr_t)a.v0 | (uintptr_t)a.v1 | (uintptr_t)a.lng | (uintptr_t)a.W) & 15) return (int)hipErrorInvalidValue;
@@ -242,7 +246,7 @@ static int launch_rsc(int which, const MpmaeRsArgs& a, hipStream_t st) {
       // which 4 ties at C = 40 (36 us = 4.2 TB/s: HBM + GELU, not latency) and both lose at C = 80 (28 vs 25, 52 vs 43 us: 55-127 KB of resident weights
       // leave one or two workgroups per CU). MPMAE_OPT_RSP_NARROW: bit 0 = which 4 at C = 40, bit 1 = which 5 at C = 40, bit 2 / 3 = the same at C = 80
       const int nbit = (KC == 80 ? 4 : 1) << (which == 5 ? 1 : 0);
-      if (rp > 0 && (g_opt[MPMAE_OPT_RSP_NARROW] & nbit) && pf && ((which == 4 && !dzr) || (which == 5 && dzr))) {
+      if (rp > 0 && (g_opt[MPMAE_OPT_RSP_NARROW] & nbit) && pf && !a.dn_y && ((which == 4 && !dzr) || (which == 5 && dzr))) {      // (the fused downsample LayerNorm lives in rsc_narrow)
         const int nwv = g_opt[MPMAE_OPT_RSP_NWV] > 0 ? g_opt[MPMAE_OPT_RSP_NWV] : ((KC == 80 && which == 5) ? 8 : 4);
         if (nwv != 4 && nwv != 8) return (int)hipErrorInvalidValue;
         const int ntiles = cdiv(a.M, 16 * nwv);

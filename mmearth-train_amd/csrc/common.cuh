@@ -230,6 +230,16 @@ __device__ __forceinline__ int geom_row_of(const Geom& g, int n, int gy, int gx)
   return (n * g.keep + slot) * g.S * g.S + (gy - py * g.S) * g.S + (gx - px * g.S);
 }
 
+// Element offset of row m of a stage with S points per patch side inside the "grouped" matrix
+// [parent rows][4][C] that the 2x2-stride-2 downsample convolution reads as a plain GEMM operand:
+// parent = (patch, iy/2, ix/2), group kidx = (ix&1)*2 + (iy&1) (k = kidx*C + c, gemm.cuh down_child_row).
+__device__ __forceinline__ size_t down_group_off(int m, int S, int C) {
+  const int P = S * S, nk = m / P, q = m - nk * P, cy = q / S, cx = q - cy * S;
+  const int Sp = S >> 1;
+  const int parent = nk * (Sp * Sp) + (cy >> 1) * Sp + (cx >> 1);
+  return ((size_t)parent * 4 + ((cx & 1) * 2 + (cy & 1))) * C;
+}
+
 // An all-ones / zero mask (in a VGPR) the optimizer cannot see through. `x = ptr ? load(ptr + i) : 0` (and `load(...) & (ptr ? ~0 : 0)`,
 // which instcombine folds back into the select) compile to a branch around the load with an `s_waitcnt vmcnt(0)` at its join: N optional
 // operands in a row become N serial round trips. With an opaque mask the load stays unconditional (from `ptr ? ptr + i : some_valid_address`)

@@ -20,15 +20,7 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
-// Element offset of row m of a stage with S points per patch side inside the "grouped" matrix
-// [parent rows][4][C] that the 2x2-stride-2 downsample convolution reads as a plain GEMM operand:
-// parent = (patch, iy/2, ix/2), group kidx = (ix&1)*2 + (iy&1) (k = kidx*C + c, gemm.cuh down_child_row).
-__device__ __forceinline__ size_t down_group_off(int m, int S, int C) {
-  const int P = S * S, nk = m / P, q = m - nk * P, cy = q / S, cx = q - cy * S;
-  const int Sp = S >> 1;
-  const int parent = nk * (Sp * Sp) + (cy >> 1) * Sp + (cx >> 1);
-  return ((size_t)parent * 4 + ((cx & 1) * 2 + (cy & 1))) * C;
-}
+// (down_group_off: common.cuh)
 
 template <typename T, int G, int PER>
 __global__ __launch_bounds__(256) void ln_fwd_v2_kernel(const T* __restrict__ x, T* __restrict__ xhat,

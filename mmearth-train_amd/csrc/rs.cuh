@@ -33,6 +33,7 @@ struct RsP {
   float fin_eps;
   const bf16_t* D; const bf16_t* W2; int ldw2;     // rsc_narrow with operand recomputation: dout / xn [M][C], W2^T / W1 [H][ldw2]
   const float* hb;                                 // MODE 0: pwconv1 bias [H]
+  bf16_t* dn_xhat; float* dn_rstd; bf16_t* dn_y; const float* dn_g; const float* dn_b; int dn_S;   // rsc_narrow MODE 0: the downsample LayerNorm of the stage's output, fused (see MpmaeRsArgs.dn_*)
   float* wg_ws;                                    // rsp_narrow<.., WG>: slab rows [gridDim.x][H * C + H] of the fused pwconv1 weight gradient
   float* s0a; float* s1a;                          // rsc_wide: accumulate the column statistics HERE with no-return float atomics (no slab, no fold launch)
   int perwave;                                     // rsc_wide: one LDS statistics row per wave, added in a fixed order (0: one shared row, LDS float atomics)

@@ -564,6 +564,7 @@ __global__ __launch_bounds__(64 * NWV) void rsc_narrow_kernel(const RsP p, int H
         rraw[j] = *reinterpret_cast<const uint2*>(rp + n4c);
         b4[j] = *reinterpret_cast<const float4*>(bp + n4c);
       }
+      float ob[NT][4];                                // the row as the next reader sees it (bf16-rounded), for the fused LayerNorm below
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int n4 = j * 16 + lg * 4;
@@ -574,7 +575,48 @@ __global__ __launch_bounds__(64 * NWV) void rsc_narrow_kernel(const RsP p, int H
         const float bb[4] = {hb ? b4[j].x : 0.f, hb ? b4[j].y : 0.f, hb ? b4[j].z : 0.f, hb ? b4[j].w : 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = live[rt] ? acc[rt][j][r] + bb[r] + x[r] : 0.f;
-        if (inb[rt] && nin) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = pack_bf16x4(o);
+        const uint2 ov = pack_bf16x4(o);
+        if (inb[rt] && nin && p.out) *reinterpret_cast<uint2*>(p.out + (size_t)row * KC + n4) = ov;
+        unpack4(and2(ov, nin), ob[j]);
+      }
+      // Fused downsample LayerNorm (round 6, p.dn_y): the LAST block of a stage feeds the LayerNorm in front of the 2x2/2 convolution
+      // (convnextv2_sparse.py:131-137, 210-212). A lane holds 4 columns per 16-column tile of its row, the row sums fold over the 4 lane groups
+      // (two shuffles, as in the LayerNorm backward of MODE 1): x-hat, rstd and the affine output in the convolution's grouped operand layout
+      // leave from here - exactly what mpmae_ln_fwd_down computes from the stored bf16 row, one launch and one read of the stage output less.
+      if (p.dn_y) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s += ob[j][r];
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        const float mean = s / KC;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float d = (!PAD || j * 16 + lg * 4 < KC) ? ob[j][r] - mean : 0.f; q += d * d; }
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        const float rstd = rsqrtf(q / KC + 1e-6f);
+        if (lg == 0 && inb[rt]) p.dn_rstd[row] = live[rt] ? rstd : 0.f;
+        const size_t goff = down_group_off(min(row, p.M - 1), p.dn_S, KC);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n4 = j * 16 + lg * 4, n4c = min(n4, KC - 4);
+          const float4 g4 = *reinterpret_cast<const float4*>(p.dn_g + n4c), b4n = *reinterpret_cast<const float4*>(p.dn_b + n4c);
+          const float gv[4] = {g4.x, g4.y, g4.z, g4.w}, bv[4] = {b4n.x, b4n.y, b4n.z, b4n.w};
+          float xh[4], y[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xh[r] = live[rt] ? (ob[j][r] - mean) * rstd : 0.f;
+          const uint2 xv = pack_bf16x4(xh);
+          unpack4(xv, xh);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) y[r] = live[rt] ? xh[r] * gv[r] + bv[r] : 0.f;
+          if (inb[rt] && (!PAD || n4 < KC)) {
+            *reinterpret_cast<uint2*>(p.dn_xhat + (size_t)row * KC + n4) = xv;
+            *reinterpret_cast<uint2*>(p.dn_y + goff + n4) = pack_bf16x4(y);
+          }
+        }
       }
     } else {
       // LayerNorm backward: row sums are lane-local over (j, r) plus the 4 lane groups

@@ -72,6 +72,7 @@ ENGINE_OPTIONS = dict(
     ln_fold_defer=1,        # the LayerNorm gamma / beta gradient folds of the fused pointwise backward kernels leave the main lane: one mpmae_fold_group per stage on the weight-gradient lane
     grn_group=1,            # dense decoder blocks: GRN statistics + finalisation + application as ONE launch per direction (mpmae_grn_group_fwd / _bwd, rows of a sample in registers between the passes), gamma / beta gradient folds deferred to the side lane
     wgrad_group=1,          # ONE launch (+ one fold) for all pwconv1 / pwconv2 weight gradients of an encoder stage (mpmae_wgrad_group), issued behind the stage's data-gradient chain
+    down_fused=1,           # round 6: the LayerNorm in front of a 2x2/2 downsample convolution computed in the epilogue of the stage's LAST fused pwconv2 kernel (MpmaeRsArgs.dn_*: stages 0 -> 1 and 1 -> 2; x-hat, rstd and the grouped affine output leave from the kernel that has the row in registers): no mpmae_ln_fwd_down launch, the stage output itself is never stored or re-read
     wg_fused=1,             # round 6: pwconv1's weight gradient of the stage-0 blocks (C = 40, dz recomputed) INSIDE the fused backward kernel (MpmaeRsArgs.wg_ws: U = dh^T x-hat and db1 per persistent workgroup, folded by mpmae_rs_wgrad_fold with the LayerNorm affine applied by linearity): dh is never stored (100 MB per block), the transpose-read product over dh and xn and its fold leave the weight-gradient lane, the forward does not store xn
     stats_wgrad=1,          # blocks that recompute dz (C <= dzr_maxc): the GRN backward statistics come from pwconv2's weight gradient - T = dout^T gelu(h) on the MAIN lane (mpmae_rs which = 6, csrc/rst.cuh: one read of dout and h at the price of the statistics-only pass it replaces, 33.9 vs 34.7 us at stage 0), then mpmae_grn_stats_from_wgrad -> S0, S1, dW2, db2: the weight-gradient lane loses pwconv2's transpose-read product and fold over the same two tensors (72 + 12 us per stage-0 block), the forward never stores z at those widths. Round 6: 3.471 vs 3.569 ms (profiles/r06/ab_stats_wgrad.txt). 0 = statistics pass + separate weight gradient (round 5's route to the same T - the generic gemm_tn2 kernel on the main lane - measured 3.65 ms, slower than off, and is removed)
     grn_apply_fin=1,        # unfused sparse blocks (C = 320: tiled GEMMs + element-wise GRN passes): the GRN finalisation runs in the prologue of the element-wise pass (mpmae_grn_apply_fin / _bwd_apply_fin) - two launches fewer per block on the main lane
@@ -1394,7 +1395,22 @@ class Engine:
                 Ci = dims[i - 1]
                 wd = self.w[f"down{i - 1}.Wt"]
                 dn["grouped"] = (self.down_grouped and Ci % 8 == 0 and Ci <= 1024 and self.S[i - 1] % 2 == 0)      # (the grouped LayerNorm kernels: C <= 1024; huge has 1408 in front of stage 3)
-                if dn["grouped"]:
+                # down_fused: the producer of x - the last block's [GRN + pwconv2 + residual] kernel - also does this LayerNorm (its args are patched here)
+                last = f[-1]
+                fuse = (dn["grouped"] and bool(self.opt["down_fused"]) and dt == BF16 and last[0].endswith(":grn.apply+pw2") and last[3]["kind"] == "rs<4>"
+                        and Ci <= 96 and lib.mpmae_get_option(_lib.OPT["RSP_NARROW"]) & (4 if Ci == 80 else 1) == 0)
+                dn["fused"] = fuse
+                if fuse:
+                    if "yg" not in dn:
+                        dn["yg"] = self._t(self.M[i] * 4 * Ci)
+                    ra = last[2][1]._obj
+                    ra.dn_xhat, ra.dn_rstd, ra.dn_y = dn["xhat"].data_ptr(), dn["rstd"].data_ptr(), dn["yg"].data_ptr()
+                    ra.dn_gamma, ra.dn_beta, ra.dn_S = P[pre + ".0.ln.weight"].data_ptr(), P[pre + ".0.ln.bias"].data_ptr(), self.S[i - 1]
+                    ra.out = 0                      # nothing else reads the stage output
+                    f[-1] = (last[0] + "+down.ln", last[1], last[2], dict(last[3], bytes=last[3]["bytes"] + 2 * self.M[i - 1] * Ci * 2))
+                    self._gemm(f, pre + ":conv", "NONE", "STORE", A=dn["yg"], B=wd["t"], bias=P[pre + ".1.bias"], C=dn["out"],
+                               M=self.M[i], N=dims[i], K=4 * Ci, lda=4 * Ci, ldb=wd["ld"], ldc=dims[i], act=self.act[i])
+                elif dn["grouped"]:
                     # LN writes its affine output straight into the [M_i][4*Ci] operand layout of the 2x2/2 convolution,
                     # which then is a plain GEMM (and its weight gradient a plain TN product)
                     if "yg" not in dn:

@@ -504,3 +504,45 @@ def test_pointwise1_weight_gradient_inside_the_fused_backward_kernel(M):
     xn = xhat.float() * lng + lnb
     ref_w, ref_b = dh0.float().t() @ xn, dh0.float().sum(0)
     assert _rel(dW1 - 0.25, ref_w) < 2e-4 and _rel(db1 - 0.25, ref_b) < 2e-4
+
+
+@pytest.mark.parametrize("N,keep,S,Cc", [(3, 19, 8, 40), (2, 19, 4, 80), (1, 5, 4, 96)])
+def test_downsample_layernorm_fused_into_the_pointwise2_kernel(N, keep, S, Cc):
+    """MpmaeRsArgs.dn_* (round 6): mpmae_rs which = 4 also emits the LayerNorm in front of the 2x2/2 downsample convolution - x-hat, rstd and the affine
+    output in the convolution's grouped [M/4][4C] operand layout - from the row it has just computed, against mpmae_ln_fwd_down on the stored bf16 row
+    (identical arithmetic on identical bf16 inputs: a bf16 ulp where the two kernels contract an fma differently); inactive rows write zeros; `out`
+    may be NULL."""
+    L, lib = _lib()
+    dev, H = "cuda", 4 * Cc
+    M = N * keep * S * S
+    torch.manual_seed(N + S + Cc)
+    ws = torch.empty(4 << 20, dtype=torch.float32, device=dev)
+
+    def args(**kw):
+        a = L.RsArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else (0 if v is None else v))
+        a.M, a.C, a.H, a.ws, a.ws_floats = M, Cc, H, ws.data_ptr(), ws.numel()
+        return a
+
+    act = (torch.rand(M, device=dev) > 0.1).to(torch.uint8)
+    live = act.bool()[:, None]
+    h = torch.randn(M, H, device=dev).to(bf) * live
+    x = torch.randn(M, Cc, device=dev).to(bf) * live
+    W2 = (torch.randn(Cc, H, device=dev) / math.sqrt(H)).to(bf)
+    b2, scale, gbeta = torch.randn(Cc, device=dev) * 0.1, torch.rand(H, device=dev) + 0.5, torch.randn(H, device=dev) * 0.1
+    lng, lnb = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.2
+    out0, xh0, rs0, y0 = (torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, Cc, device=dev, dtype=bf), torch.empty(M, device=dev),
+                          torch.empty(M // 4, 4 * Cc, device=dev, dtype=bf))
+    xh1, rs1, y1 = torch.empty_like(xh0), torch.empty_like(rs0), torch.empty_like(y0)
+    assert lib.mpmae_rs(4, C.byref(args(A=h, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=out0, R=x, act=act)), _st()) == 0
+    assert lib.mpmae_ln_fwd_down(1, out0.data_ptr(), xh0.data_ptr(), rs0.data_ptr(), y0.data_ptr(), lng.data_ptr(), lnb.data_ptr(), 1e-6, M, Cc, S,
+                                 act.data_ptr(), _st()) == 0
+    assert lib.mpmae_rs(4, C.byref(args(A=h, W=W2, ldw=H, bias=b2, v0=scale, v1=gbeta, out=None, R=x, act=act, dn_xhat=xh1, dn_rstd=rs1, dn_y=y1,
+                                        dn_gamma=lng, dn_beta=lnb, dn_S=S)), _st()) == 0
+    torch.cuda.synchronize()
+    assert _rel(rs1, rs0) < 1e-5 and (rs1[~act.bool()] == 0).all()
+    assert _rel(xh1, xh0) < 8e-3 and (xh1 != xh0).float().mean().item() < 2e-2
+    assert _rel(y1, y0) < 8e-3 and (y1.view(M // 4, 4, Cc)[:, :, :] != 0).any()
+    # inactive rows: zeros in both outputs
+    assert (xh1[~act.bool()] == 0).all()
