@@ -607,7 +607,7 @@ def main():
                    value=round(value, 1), unit="images/sec", n_gpus=world, steps=a.steps, warmup=a.warmup,
                    ms_per_step=round(ms_per_step, 4), ms_per_step_median_hip_events=round(median_ms, 4),
                    ms_per_step_with_input_stage=round(ms_with_inputs, 4), higher_is_better=True, scaling="weak", vs_baseline=None,
-                   dtype={"bf16": "bf16", "fp8": "fp8 (OCP e4m3 + E8M0 MX block scales on the decoder pointwise GEMMs, bf16 elsewhere, fp32 accumulation)"}.get(a.dtype, "f32"), data="synthetic",
+                   dtype={"bf16": "bf16", "fp8": "fp8 (OCP e4m3 + E8M0 MX block scales on the decoder block's pointwise GEMMs and the K = 1280 pointwise GEMMs of encoder stage 3, bf16 elsewhere, fp32 accumulation)"}.get(a.dtype, "f32"), data="synthetic",
                    config=dict(workload=f"{a.subset} {a.model.replace('convnextv2_', '')} {a.img}x{a.img} patch{a.patch} "
                                         f"mask0.6 uncertainty loss, fwd+loss+bwd+allreduce+AdamW",
                                per_gpu_batch=a.batch, global_batch=a.batch * world,
