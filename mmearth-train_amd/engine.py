@@ -63,7 +63,7 @@ ENGINE_OPTIONS = dict(
     ps=2,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage. 2 since late round 4: with the decoder / head GEMMs on the vendor route the per-block kernels at stage 3 (2 blocks, M = 3584) measure 3.868-3.873 vs 3.892-3.897 ms for 3 in three interleaved pairs (a tie in round 3); 1: 4.04
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     act_in_stem=1,          # the fused stem kernel writes the pixel-activity bytes itself (it computes them anyway): no activity launch, the first stage-0 op waits for nothing on the side lane, the poolings run behind the stem
-    tail_main=0,            # 1: the LAST depthwise weight gradient of the backward (stage 0, block 0) and its fused pwconv1 fold on the main lane behind the data gradient (round 4: the weight-gradient lane ended 115 us after the main lane, 4.06 -> 4.02 ms). Round 6: with pwconv1 / pwconv2's weight gradients of stages 0-1 gone from that lane it has slack again: 0 measures 3.435 / 3.451 vs 3.462 / 3.467 ms (profiles/r06/option_sweep.txt); 2: the pointwise pw1 weight gradient too (unfused blocks)
+    tail_main=-1,           # the LAST depthwise weight gradient of the backward (stage 0, block 0) and its folds in order on the MAIN lane behind the data gradient (1) or on the weight-gradient lane (0); -1 = by the lane's load: 0 where the stage-0 blocks carry their pointwise weight gradients inside the main-lane kernels (wg_fused: the lane has slack - atto 3.435 / 3.451 vs 3.462 / 3.467 ms, profiles/r06/option_sweep.txt), 1 otherwise (round 4: the lane ended 115 us after the main lane, 4.06 -> 4.02 ms; tiny 112/16 in round 6: 14.635 vs 14.70 ms, profiles/r06/tiny_option_sweep.txt); 2: the unfused pointwise pw1 weight gradient too
     dz_ring=16,             # depth of the dz / dh scratch ring (the pw1 weight gradient on the side lane reads dh); >= blocks of the net:
     ring=16,                # / of the dd / dx rings: no main-lane op ever waits for the side lane to release a scratch buffer (3 / 4: +60 us)
     rsn_maxc=192,           # largest C with the GRN application / its backward fused into the NARROW row-streaming kernels (beyond: tiled GEMMs + element-wise kernels; 384 on tiny 112/16: 16.64 vs 15.15 ms)
@@ -1143,7 +1143,7 @@ class Engine:
             # second stage of the weight gradient the fused kernel accumulated (LayerNorm affine applied by linearity): nothing on the chain reads it
             def wfold(stream, _b=blk, _c=Cc, _h=H, _g=P[nm["ln_w"]], _bt=P[nm["ln_b"]], _dw=Gd[nm["w1"]], _db=Gd[nm["b1"]]):
                 return lib.mpmae_rs_wgrad_fold(_h, _c, _p(_b["wg_slab"]), _b["wg_rows"].value, _p(_g), _p(_bt), _p(_dw), _p(_db), stream)
-            if self.lanes and not (int(self.opt["tail_main"]) >= 1 and tag == "encoder.stages.0.0"):
+            if self.lanes and not (self._tail_main() >= 1 and tag == "encoder.stages.0.0"):
                 k = self._after(lst)
                 self._evseq += 1
                 self._op(lst, tag + ":pw1.wgrad.fold", wfold, kind="rs_wgrad_fold", nbytes=blk["wg_slab"].numel() * 4, lane=1, wait=(k,) if k else (),
@@ -1153,7 +1153,7 @@ class Engine:
         elif grouped or (sw and self._group_ok(blk, "NONE")):
             self._group_add(lst, tag + ":pw1.wgrad", [dz], **w1_args)
         elif not late_all:
-            if self.lanes and int(self.opt["tail_main"]) >= 2 and tag == "encoder.stages.0.0":
+            if self.lanes and self._tail_main() >= 2 and tag == "encoder.stages.0.0":
                 self._wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", **w1_args)      # (tail_main = 2: in order on the main lane)
             else:
                 self._side_wgrad(lst, tag + ":pw1.wgrad", "NONE", "NONE", [dz], **w1_args)
@@ -1189,7 +1189,7 @@ class Engine:
         a.act = act.data_ptr() if act is not None else 0
         a.ws, a.ws_floats = (self.ws3 if self.lanes else self.ws).data_ptr(), self.ws_floats
         self._keepalive.append(a)
-        if self.lanes and int(self.opt["tail_main"]) >= 1 and tag == "encoder.stages.0.0":
+        if self.lanes and self._tail_main() >= 1 and tag == "encoder.stages.0.0":
             # in order on the main lane right behind the block's data gradient (its operands are fresh: no event, no scratch-ring guard)
             a.ws = self.ws.data_ptr()              # main-lane scratch
             self._op(lst, tag + ":dw.wgrad", lib.mpmae_dwconv7_wgrad, dt, C.byref(a), 2048, kind="dwconv7_wgrad",
@@ -1820,7 +1820,7 @@ class Engine:
             self._dwg_flush(b)            # the stage's grouped depthwise / pointwise weight gradients: side lane, behind its data-gradient chain
             self._group_flush(b)
             # (tail_main: the last fold group in order on the main lane - the weight-gradient lane is the later one at the end of the step)
-            self._fold_flush(b, f"encoder.stages.{i}", lane=0 if (i == 0 and self.lanes and int(self.opt["tail_main"]) >= 1) else 1)
+            self._fold_flush(b, f"encoder.stages.{i}", lane=0 if (i == 0 and self.lanes and self._tail_main() >= 1) else 1)
             if i > 0:
                 dn = self.down[i - 1]
                 pre = f"encoder.downsample_layers.{i - 1}"
@@ -1941,6 +1941,12 @@ class Engine:
         if self.opt["det"] and lib.get("DET") == 1:
             lib.pop("DET")
         return dict(engine=eng, library=lib)
+
+    def _tail_main(self):
+        v = int(self.opt["tail_main"])
+        if v >= 0:
+            return v
+        return 0 if any(b.get("wgf") for b in self.blocks if b["stage"] == 0) else 1
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

@@ -662,7 +662,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N):
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
                                   "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "loss_onepass=0", "grn_apply_fin=0", "stats_wgrad=0", "wg_fused=0", "down_fused=0", "RST_NW=4", "stats_wgrad=0,wg_fused=0", "img_dgrad_side=0", "EVX=0", "FOLD_GROUP=-1,tail_fold_group=0", 
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
-                                  "img_side=0,prep_side=0", "front_side=0,zero_side=0", "prep_late=0", "proj_compact=0", "z_free=0", "wgrad_late=0", "ring=2,dz_ring=2", "tail_main=0", "act_in_stem=0", "ps=3"])
+                                  "img_side=0,prep_side=0", "front_side=0,zero_side=0", "prep_late=0", "proj_compact=0", "z_free=0", "wgrad_late=0", "ring=2,dz_ring=2", "tail_main=0", "tail_main=1", "act_in_stem=0", "ps=3"])
 def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
     """Every kernel generation still in the library is reachable through mpmae_set_option (include/mpmae_hip.h): a full bf16 step with
     the option set against the step on the default kernels - same losses (1e-2: bf16 rounding points differ between generations) and
