@@ -228,8 +228,10 @@ def test_bench_refuses_timing_experiment_variables_and_stamps_options():
     assert r.returncode == 0, r.stderr[-1500:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert d["config"]["options"] == {"engine": {"tail_main": 1}, "library": {"TN3_BLOCKS": 64}}
-    src = open(os.path.join(ROOT, "mmearth-train_amd", "engine.py")).read()
-    assert "MPMAE_SKIP_OPS" not in src and "MPMAE_DEFER_EXPERIMENT" not in src
+    import glob
+    for f in glob.glob(os.path.join(ROOT, "mmearth-train_amd", "engine*.py")):
+        src = open(f).read()
+        assert "MPMAE_SKIP_OPS" not in src and "MPMAE_DEFER_EXPERIMENT" not in src, f
 
 
 def test_xcd_tile_order_is_a_permutation_that_keeps_a_row_tile_on_one_xcd():
