@@ -373,7 +373,7 @@ int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* args, const uint32_t* scales_a, 
  * are the measured-best choices on MI355X. */
 enum MpmaeOption {
   MPMAE_OPT_DW = 0,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = positional-tile / generic kernels (dwconv3.cuh, dwconv.cuh: S = 1 in fp32 mode, odd shapes). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
-  MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 6 = packed kernel for S >= 2; 5 = per-sample LDS-map kernels */
+  MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 5 = per-sample LDS-map kernels everywhere (6, a packed kernel for S >= 2 that measured slower, was removed in round 6: the value now behaves like 5) */
   MPMAE_OPT_NT_GLDS64,   /* default 1: direct-to-LDS NT GEMM also for 64-wide N tiles */
   MPMAE_OPT_NT_BK32,   /* default 1: 32-deep K slabs for K <= 512 */
   MPMAE_OPT_NT_GLDS,   /* default 1: direct-to-LDS operand slabs in the NT GEMM (2 = always 32-deep) */
@@ -590,7 +590,11 @@ int mpmae_hp_fetch(const float* ring_pinned, int slots, int* counter, float* hp,
  * issuing them (the stream argument is ignored). run() issues ops [first, first+count) in order:
  * lane 0 on `main`, lane k on the program's k-th side stream (forked from / joined to `main`
  * around the call); an op first waits for the events named in `waits` that were signalled earlier
- * in the same run() call and records its own `signal` event (ids > 0; 0 = none) when enqueued. */
+ * in the same run() call and records its own `signal` event (ids > 0; 0 = none) when enqueued.
+ * Argument structs (Mpmae*Args, problem arrays) are consumed AT THE CALL, recorded or not: the caller's copy may live on the stack and be
+ * reused or freed before run() (enforced since round 6 - the depthwise / per-modality loss entry points used to read the caller's struct at
+ * replay; tests/test_hip_kernels_bf16.py overwrites every host struct between recording and replay). Device buffers, and the pinned host
+ * source of mpmae_memcpy_h2d_async, are read at replay and must outlive the program. */
 typedef struct MpmaeProgram MpmaeProgram;
 MpmaeProgram* mpmae_program_create(void);
 void mpmae_program_destroy(MpmaeProgram* p);

@@ -344,19 +344,6 @@ static bool launch_dw_v6(const MpmaeDwArgs& a, hipStream_t st) {
   return true;
 }
 
-template <int S>
-static bool launch_dwwg_v6(const MpmaeDwWgArgs& a, int nblocks, hipStream_t st) {
-  constexpr int CW = 64 / S;
-  const int nthreads = dw6_threads(S);
-  size_t lds = dw5_map_bytes<bf16_t, S>(a.g.grid);
-  const size_t red = (size_t)(nthreads / 64) * 50 * CW * sizeof(float);
-  if (red > lds) lds = red;
-  if (lds > 64 * 1024) return false;
-  dim3 g(nblocks, a.C / CW);
-  LAUNCH((dwconv7_wgrad_v6_kernel<S>), g, dim3(nthreads), lds, st, a);
-  return true;
-}
-
 static int dw_variant() {      // MPMAE_DW=4 forces the per-patch kernels (A/B measurements)
   int v;
   v = g_opt[MPMAE_OPT_DW];
@@ -399,6 +386,7 @@ static int try_dw_mfma(const DwP& a, hipStream_t st) {
 
 int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  const MpmaeDwArgs& A = *a;      // LAUNCH captures the referenced struct BY VALUE: a launch recorded into a program must not read the caller's struct at replay time
   if (dt == 1 && dw_variant() >= 8) {
     const int r = try_dw_mfma(*a, S_(s));
     if (r >= 0) return r;
@@ -406,7 +394,7 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   if (dt == 1 && a->g.S == 1 && a->g.grid == 7 && (a->C & 15) == 0 && dw_variant() >= 6 &&
       (((uintptr_t)a->x) & 15) == 0 && (((uintptr_t)a->out | (uintptr_t)a->add) & 3) == 0) {
     dim3 g(a->g.N, cdiv(a->C, 64));
-    LAUNCH((dwconv7_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a);
+    LAUNCH((dwconv7_v6s1_kernel<7>), g, dim3(256), 0, S_(s), A);
     RET();
   }
   if (dw_v4_ok(a->C, a->g.S) && dw_variant() >= 5) {
@@ -428,8 +416,8 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
     const size_t esz = dt == 0 ? 4 : 2;
     const size_t lds = (DW_HP + W64_MAXL) * sizeof(int) + (size_t)nw * (DW_HP * 8 * esz + 49 * 8 * sizeof(float));
     dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(chunks, nw));
-    if (dt == 0) LAUNCH(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), *a);
-    else LAUNCH(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), *a);
+    if (dt == 0) LAUNCH(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), A);
+    else LAUNCH(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), A);
     RET();
   }
   const size_t lds = dw_lds_bytes(a->CC, false);
@@ -437,10 +425,10 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
   dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
   if (dt == 0) {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    LAUNCH(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_fwd_kernel<float>, g, dim3(256), lds, S_(s), A);
   } else {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    LAUNCH(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_fwd_kernel<bf16_t>, g, dim3(256), lds, S_(s), A);
   }
   RET();
 }
@@ -492,6 +480,7 @@ static int try_dwwg_mfma(const DwWgP& a, hipStream_t st, const DwWgGroupP& gr, i
 
 int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_stream_t s) {
   if (!a || a->CC < 1 || a->CC > 256 || a->TP * a->g.S > 8) return (int)hipErrorInvalidValue;
+  const MpmaeDwWgArgs& A = *a;      // (captured by value, as above: the group entry below passes a stack copy)
   if (dt == 1 && a->ws) {
     DwWgGroupP gr;
     gr.count = 0;
@@ -514,7 +503,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     dim3 g(nb, cdiv(a->C, 64));
     DwWgGroupP gr;
     gr.count = 0;
-    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), *a, gr);
+    LAUNCH((dwconv7_wgrad_v6s1_kernel<7>), g, dim3(256), 0, S_(s), A, gr);
     launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }
@@ -526,20 +515,10 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     int nb = a->g.N < nbmax ? a->g.N : nbmax;
     if ((size_t)nb * per > a->ws_floats) nb = (int)(a->ws_floats / per);
     bool ok = false;
-    // the packed weight-gradient kernel needs 98 accumulator VGPRs per lane and measured slower than v5
-    // (62 vs 45 us at stage 1); it stays available for experiments (MPMAE_DWW=6)
-    int wg6;
-    wg6 = g_opt[MPMAE_OPT_DWW] == 6 ? 1 : 0;
-    if (wg6 && dt == 1 && (a->C & 1) == 0 && (((uintptr_t)a->x | (uintptr_t)a->dd) & 3) == 0) {
-      switch (a->g.S) { case 8: ok = launch_dwwg_v6<8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v6<4>(*a, nb, S_(s)); break;
-                        default: ok = launch_dwwg_v6<2>(*a, nb, S_(s)); }
-    }
-    if (!ok) {
 #define DWW5(TT) do { switch (a->g.S) { case 8: ok = launch_dwwg_v5<TT, 8>(*a, nb, S_(s)); break; case 4: ok = launch_dwwg_v5<TT, 4>(*a, nb, S_(s)); break; \
                                        default: ok = launch_dwwg_v5<TT, 2>(*a, nb, S_(s)); } } while (0)
     if (dt == 0) DWW5(float); else DWW5(bf16_t);
 #undef DWW5
-    }
     if (ok) {
       launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
       RET();
@@ -551,8 +530,8 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
     if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
     if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
     dim3 g(nblocks, a->C / 8);
-    if (dt == 0) LAUNCH(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), *a);
-    else LAUNCH(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), *a);
+    if (dt == 0) LAUNCH(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), A);
+    else LAUNCH(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), A);
     launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
     RET();
   }
@@ -562,10 +541,10 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
   dim3 g(nblocks, cdiv(a->C, a->CC));
   if (dt == 0) {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    LAUNCH(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_wgrad_kernel<float>, g, dim3(256), lds, S_(s), A);
   } else {
     { static size_t cur = 0; if (lds > cur) { if (hipFuncSetAttribute((const void*)dwconv7_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return (int)hipGetLastError(); cur = lds; } }
-    LAUNCH(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), *a);
+    LAUNCH(dwconv7_wgrad_kernel<bf16_t>, g, dim3(256), lds, S_(s), A);
   }
   RET();
 }
@@ -575,7 +554,7 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
 int mpmae_dwconv7_wgrad_group(int dt, const MpmaeDwWgArgs* probs, int count, float* ws, size_t ws_floats, mpmae_stream_t s) {
   if (!probs || count < 1 || !ws) return (int)hipErrorInvalidValue;
   const MpmaeDwWgArgs& a0 = probs[0];
-  bool ok = dt == 1 && count <= DWG_MAX && dw_variant() >= 6 && g_opt[MPMAE_OPT_DWW] != 6 && a0.CC >= 1 && a0.TP * a0.g.S <= 8;
+  bool ok = dt == 1 && count <= DWG_MAX && dw_variant() >= 6 && a0.CC >= 1 && a0.TP * a0.g.S <= 8;
   for (int i = 0; ok && i < count; ++i) {
     const MpmaeDwWgArgs& a = probs[i];
     ok = a.C == a0.C && a.g.N == a0.g.N && a.g.keep == a0.g.keep && a.g.grid == a0.g.grid && a.g.S == a0.g.S && a.g.vis == a0.g.vis &&
@@ -726,30 +705,35 @@ int mpmae_pool_rows(int dt, const void* x, void* pooled, int N, int L, int C, mp
 
 // ------------------------------------------------------------------------------------------
 int mpmae_loss_pix_cont(int dt, int bwd, const MpmaePixContArgs* a, int npatches, mpmae_stream_t s) {
+  if (!a || a->L < 1) return (int)hipErrorInvalidValue;
+  const MpmaePixContArgs& A = *a;      // (captured by value by LAUNCH)
   dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 512) ;   // forward: one 16-wave block per sample
-  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else LAUNCH((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) LAUNCH((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else LAUNCH((loss_pix_cont_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cont_kernel<float, true>), g, b, 0, S_(s), A);
+                 else LAUNCH((loss_pix_cont_kernel<float, false>), g, b, 0, S_(s), A); }
+  else { if (bwd) LAUNCH((loss_pix_cont_kernel<bf16_t, true>), g, b, 0, S_(s), A);
+         else LAUNCH((loss_pix_cont_kernel<bf16_t, false>), g, b, 0, S_(s), A); }
   RET();
 }
 
 int mpmae_loss_pix_cat(int dt, int bwd, const MpmaePixCatArgs* a, int npatches, mpmae_stream_t s) {
-  if (a->K > 16) return (int)hipErrorInvalidValue;
+  if (!a || a->K > 16 || a->L < 1) return (int)hipErrorInvalidValue;
+  const MpmaePixCatArgs& A = *a;      // (captured by value by LAUNCH)
   dim3 g(bwd ? npatches : npatches / a->L), b(bwd ? 256 : 1024);   // forward: one 16-wave block per sample
-  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else LAUNCH((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) LAUNCH((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else LAUNCH((loss_pix_cat_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_pix_cat_kernel<float, true>), g, b, 0, S_(s), A);
+                 else LAUNCH((loss_pix_cat_kernel<float, false>), g, b, 0, S_(s), A); }
+  else { if (bwd) LAUNCH((loss_pix_cat_kernel<bf16_t, true>), g, b, 0, S_(s), A);
+         else LAUNCH((loss_pix_cat_kernel<bf16_t, false>), g, b, 0, S_(s), A); }
   RET();
 }
 
 int mpmae_loss_img(int dt, int bwd, const MpmaeImgArgs* a, mpmae_stream_t s) {
+  if (!a || a->N < 1) return (int)hipErrorInvalidValue;
+  const MpmaeImgArgs& A = *a;      // (captured by value by LAUNCH)
   dim3 g(a->N), b(256);
-  if (dt == 0) { if (bwd) LAUNCH((loss_img_kernel<float, true>), g, b, 0, S_(s), *a);
-                 else LAUNCH((loss_img_kernel<float, false>), g, b, 0, S_(s), *a); }
-  else { if (bwd) LAUNCH((loss_img_kernel<bf16_t, true>), g, b, 0, S_(s), *a);
-         else LAUNCH((loss_img_kernel<bf16_t, false>), g, b, 0, S_(s), *a); }
+  if (dt == 0) { if (bwd) LAUNCH((loss_img_kernel<float, true>), g, b, 0, S_(s), A);
+                 else LAUNCH((loss_img_kernel<float, false>), g, b, 0, S_(s), A); }
+  else { if (bwd) LAUNCH((loss_img_kernel<bf16_t, true>), g, b, 0, S_(s), A);
+         else LAUNCH((loss_img_kernel<bf16_t, false>), g, b, 0, S_(s), A); }
   RET();
 }
 

@@ -157,88 +157,9 @@ __global__ __launch_bounds__(512) void dwconv7_v6_kernel(const DwP p) {
   }
 }
 
-// weight / bias gradient: persistent workgroups over samples; grid = (nblocks, C/CW); slab ws[blockIdx.x][50][C]
-template <int S>
-__global__ __launch_bounds__(512) void dwconv7_wgrad_v6_kernel(const DwWgP q) {
-  using T = bf16_t;
-  constexpr int CW = 64 / S, CP = CW / 2;
-  extern __shared__ __attribute__((aligned(16))) unsigned char dw5_smem[];
-  const int MS = q.g.grid * S + 6;
-  T* map = reinterpret_cast<T*>(dw5_smem);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, NW = blockDim.x >> 6;
-  const int C = q.C, c0 = blockIdx.y * CW;
-  const int cp = lane % CP, ox = (lane / CP) % S, sub = lane / (CP * S);
-  const int c = c0 + 2 * cp;
-  const T* dd = reinterpret_cast<const T*>(q.dd);
-  const T* x = reinterpret_cast<const T*>(q.x);
-  {
-    uint4* m4 = reinterpret_cast<uint4*>(dw5_smem);
-    const int nvec = (int)(dw5_map_bytes<T, S>(q.g.grid) / 16);
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = tid; i < nvec; i += blockDim.x) m4[i] = z;
-  }
-  f32x2_t adw[49], adb = {0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < 49; ++k) adw[k] = (f32x2_t){0.f, 0.f};
-
-  for (int n = blockIdx.x; n < q.g.N; n += gridDim.x) {
-    __syncthreads();
-    dw5_scatter<T, S, false>(q.g, n, x, map, MS, C, c0);
-    __syncthreads();
-    for (int slot = wave * 2 + sub; slot < q.g.keep; slot += NW * 2) {
-      const int nk = n * q.g.keep + slot;
-      const int patch = q.g.vis ? q.g.vis[nk] : slot;
-      const int py = patch / q.g.grid, px = patch - py * q.g.grid;
-      const T* tile = map + ((size_t)(py * S) * MS + px * S + ox) * CW + 2 * cp;
-      const size_t r0 = (size_t)nk * (S * S) + ox;
-      f32x2_t g[S];
-#pragma unroll
-      for (int o = 0; o < S; ++o) {
-        g[o] = bf2x2_to_f2(*reinterpret_cast<const uint32_t*>(dd + (r0 + o * S) * C + c));
-        adb += g[o];
-      }
-      int toff = 0;     // data dependence between kx-slabs: stops hipcc hoisting all LDS reads (see dwconv3.cuh)
-#pragma unroll
-      for (int kx = 0; kx < 7; ++kx) {
-        if (kx > 0)
-          asm volatile("" : "+v"(toff) : "v"(adw[kx - 1].x), "v"(adw[7 + kx - 1].x), "v"(adw[14 + kx - 1].x),
-                       "v"(adw[21 + kx - 1].x), "v"(adw[28 + kx - 1].x), "v"(adw[35 + kx - 1].x), "v"(adw[42 + kx - 1].x));
-        uint32_t raw[S + 6];      // column first: independent LDS reads in flight (hipcc serialises them through one register otherwise)
-#pragma unroll
-        for (int y = 0; y < S + 6; ++y) raw[y] = *reinterpret_cast<const uint32_t*>(tile + toff + (y * MS + kx) * CW);
-#pragma unroll
-        for (int y = 0; y < S + 6; ++y) {
-          const f32x2_t v = bf2x2_to_f2(raw[y]);
-#pragma unroll
-          for (int o = 0; o < S; ++o) {
-            const int ky = y - o;
-            if (ky >= 0 && ky < 7) adw[ky * 7 + kx] = g[o] * v + adw[ky * 7 + kx];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    dw5_scatter<T, S, true>(q.g, n, x, map, MS, C, c0);      // clear only what was written
-  }
-  // fold lanes that share a channel pair (lane bits above log2(CP)), then the NW waves through LDS
-  __syncthreads();
-  float* red = reinterpret_cast<float*>(dw5_smem);           // [NW][50][CW]
-#pragma unroll
-  for (int k = 0; k < 50; ++k) {
-    f32x2_t v = (k < 49) ? adw[k < 49 ? k : 0] : adb;
-#pragma unroll
-    for (int o = CP; o < 64; o <<= 1) { v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); }
-    if (lane < CP) *reinterpret_cast<f32x2_t*>(red + (wave * 50 + k) * CW + 2 * cp) = v;
-  }
-  __syncthreads();
-  float* slab = q.ws + (size_t)blockIdx.x * 50 * C;
-  for (int i = tid; i < 50 * CW; i += blockDim.x) {
-    float v = 0.f;
-    for (int w = 0; w < NW; ++w) v += red[w * 50 * CW + i];
-    const int k = i / CW, cc = i - k * CW;
-    slab[k * C + c0 + cc] = v;
-  }
-}
+// (a packed weight-gradient twin of this kernel - 98 accumulator registers per lane - measured slower than dwconv7_wgrad_v5 in round 2 (62 vs 45 us at stage 1),
+//  stayed selectable as MPMAE_OPT_DWW = 6 until round 6: removed. The memory access fault its bs-256 run ended in was not the kernel's: the one-by-one
+//  branch of mpmae_dwconv7_wgrad_group handed a stack copy of the arguments to an entry point whose recorded launch read them at replay - capi.hip, "A")
 
 // ---------------------------------------------------------------------------------------------
 // S = 1 (stage 3: 19 of the GxG positions visible; dense decoder: all of them), G = 7:
