@@ -315,7 +315,8 @@ class ForwardMixin:
                                        and -(-(mc_ * self.p * (cfg.img_size // 4)) // 512) <= 12 and -(-(mc_ * self.p * self.p // 4) // 64) <= 12)
             cat_ok = (not cat_m) or (bool(self.opt["loss_rows"]) and mk_ <= 16 and ldp0 % 4 == 0
                                      and all(self.head_cols[om.name] % 4 == 0 for om in cat_m) and (self.p * self.p * mk_) % 4 == 0
-                                     and 16 * self.p * self.p * mk_ * 4 <= 150 * 1024)
+                                     and 16 * self.p * self.p * mk_ * 4 <= 150 * 1024)      # (x 4 although the bf16 slots are 2-byte: with x 2 patch 16 qualifies too -
+            # tiny 112/16 then runs the wave kernel + one-pass losses and measured 15.00 / 15.04 vs 14.945 / 14.95 ms, profiles/r06/ab_tiny_onepass_not_kept.txt)
             onepass = self.loss_onepass = (bool(self.opt["loss_onepass"]) and dt == BF16 and bool(cfg.pix_mods) and cont_ok and cat_ok
                                            and bool(self.heads_merged.get("pix")) and self.D % 8 == 0
                                            and bool(self.opt["loss_rows_bwd"]))
