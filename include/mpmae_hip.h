@@ -372,7 +372,7 @@ int mpmae_gemm_mx(int epi, const MpmaeGemmArgs* args, const uint32_t* scales_a, 
  * recorded programs are the only state it keeps - every other entry point is a pure function of its arguments. Defaults
  * are the measured-best choices on MI355X. */
 enum MpmaeOption {
-  MPMAE_OPT_DW = 0,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = positional-tile / generic kernels (dwconv3.cuh, dwconv.cuh: S = 1 in fp32 mode, odd shapes). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
+  MPMAE_OPT_DW = 0,   /* default 8: depthwise forward / data-gradient kernels: 8 = matrix-core kernels at S = 8 / 4 (dwmfma.cuh, bf16-rounded taps) + 6 elsewhere; 7 = (the band kernel of rounds 2-3, removed in round 4: same as 6); 6 = packed per-sample kernels; 5 = per-sample LDS-map kernels (fp32 mode); < 5 = the generic positional-tile kernels of dwconv.cuh (S = 1 in fp32 mode, bf16 at S = 1 on grids other than 7 x 7, odd shapes; the wave-granular 8 x 8-tile kernels of dwconv3.cuh that stood in front of them were removed in round 6). The per-patch (v4) and block-granular (v2) generations were removed in round 5 */
   MPMAE_OPT_DWW,   /* default 7: depthwise weight gradient: 7 = matrix-core kernels at S = 8 / 4 (dwmfma_wg.cuh) + 5 elsewhere; 5 = per-sample LDS-map kernels everywhere (6, a packed kernel for S >= 2 that measured slower, was removed in round 6: the value now behaves like 5) */
   MPMAE_OPT_NT_GLDS64,   /* default 1: direct-to-LDS NT GEMM also for 64-wide N tiles */
   MPMAE_OPT_NT_BK32,   /* default 1: 32-deep K slabs for K <= 512 */

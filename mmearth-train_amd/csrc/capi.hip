@@ -7,7 +7,6 @@
 #include "dwconv.cuh"
 #include "misc.cuh"
 #include "loss.cuh"
-#include "dwconv3.cuh"
 #include "rows2.cuh"
 #include "dwconv6.cuh"
 #include "stemtail.cuh"
@@ -352,7 +351,7 @@ static int dw_variant() {      // MPMAE_DW=4 forces the per-patch kernels (A/B m
 
 static bool dw_v4_ok(int C, int S) {
   // per-visible-patch tiles pay for S >= 2; at S == 1 (stage 3, dense decoder) every output would drag
-  // its own 49-point halo, so the positional 8x8 tiles of dwconv3.cuh are used there
+  // its own 49-point halo, so the positional tiles of dwconv.cuh are used there
   if (S != 8 && S != 4 && S != 2) return false;
   return C % (64 / S) == 0;
 }
@@ -410,16 +409,8 @@ int mpmae_dwconv7_fwd(int dt, const MpmaeDwArgs* a, mpmae_stream_t s) {
 #undef DW5
     if (ok) RET();
   }
-  if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
-    const int chunks = a->C / 8;
-    const int nw = chunks <= 8 ? chunks : (chunks % 5 == 0 ? 5 : 8);      // waves per block sharing the tables
-    const size_t esz = dt == 0 ? 4 : 2;
-    const size_t lds = (DW_HP + W64_MAXL) * sizeof(int) + (size_t)nw * (DW_HP * 8 * esz + 49 * 8 * sizeof(float));
-    dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(chunks, nw));
-    if (dt == 0) LAUNCH(dwconv7_w64_kernel<float>, g, dim3(64 * nw), lds, S_(s), A);
-    else LAUNCH(dwconv7_w64_kernel<bf16_t>, g, dim3(64 * nw), lds, S_(s), A);
-    RET();
-  }
+  // (the wave-granular 8 x 8-tile kernels of dwconv3.cuh - fp32 at S = 1, bf16 on grids other than 7 x 7 - were removed in round 6: those cases
+  //  run the generic tile kernels below)
   const size_t lds = dw_lds_bytes(a->CC, false);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
   dim3 g(a->g.N * a->tiles_side * a->tiles_side, cdiv(a->C, a->CC));
@@ -523,17 +514,6 @@ int mpmae_dwconv7_wgrad(int dt, const MpmaeDwWgArgs* a, int nblocks, mpmae_strea
       launch_reduce(2, a->ws, nb, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
       RET();
     }
-  }
-  if ((a->C & 7) == 0 && a->g.grid * a->g.grid <= W64_MAXL) {
-    const size_t per = (size_t)50 * a->C;
-    if (!a->ws || a->ws_floats < per) return (int)hipErrorInvalidValue;
-    if (nblocks > a->ntiles_total) nblocks = a->ntiles_total;
-    if ((size_t)nblocks * per > a->ws_floats) nblocks = (int)(a->ws_floats / per);
-    dim3 g(nblocks, a->C / 8);
-    if (dt == 0) LAUNCH(dwconv7_wgrad_w64_kernel<float>, g, dim3(64), 0, S_(s), A);
-    else LAUNCH(dwconv7_wgrad_w64_kernel<bf16_t>, g, dim3(64), 0, S_(s), A);
-    launch_reduce(2, a->ws, nblocks, 50 * a->C, a->dw, a->db, a->C, a->s_kh, a->s_kw, a->s_c, S_(s));
-    RET();
   }
   const size_t lds = dw_lds_bytes(a->CC, true);
   if (lds > 160 * 1024) return (int)hipErrorInvalidValue;

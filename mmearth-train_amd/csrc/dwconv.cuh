@@ -45,7 +45,9 @@ __global__ __launch_bounds__(256) void dwconv7_fwd_kernel(const DwP p) {
   int any = 0;
   for (int i = threadIdx.x; i < TS * TS; i += blockDim.x) {
     const int oy = i / TS, ox = i - oy * TS;
-    any |= (rowtab[(oy + 3) * DW_HALO + ox + 3] >= 0);
+    // a row that EXISTS (visible patch), active or not: inactive rows are written as zeros below. (Until round 6 this looked at the activity-masked
+    // table, so a tile whose rows were all inactive - a sample with an all-zero image - returned without writing them; nothing reached this kernel then)
+    any |= (geom_row_of(p.g, n, ty0 + oy, tx0 + ox) >= 0);
   }
   if (!__syncthreads_or(any)) return;
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(512) void dwconv7_wgrad_v5_kernel(const DwWgP q, co
         g[o] = ldf<T>(dd + (r0 + o * S) * C + c);
         adb += g[o];
       }
-      int toff = 0;     // data dependence between kx-slabs: stops hipcc hoisting all LDS reads (see dwconv3.cuh)
+      int toff = 0;     // data dependence between kx-slabs: stops hipcc hoisting all LDS reads (found with the wave-granular kernels of rounds 1-5, dwconv3.cuh, removed in round 6)
 #pragma unroll
       for (int kx = 0; kx < 7; ++kx) {
         if (kx > 0)

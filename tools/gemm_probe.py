@@ -29,7 +29,13 @@ def gelu(x):
 shapes = [(12544, 2048, 512, "dec pw1"), (12544, 512, 2048, "dec pw2"), (12544, 2816, 512, "head pix fwd"),
           (12544, 512, 2816, "head pix dgrad"), (77824, 768, 192, "tiny s1 pw1"), (77824, 192, 768, "tiny s1 pw2"),
           (19456, 1536, 384, "tiny s2 pw1"), (19456, 384, 1536, "tiny s2 pw2"), (4864, 3072, 768, "tiny s3 pw1"), (4864, 768, 3072, "tiny s3 pw2"),
-          (4000, 1280, 320, "ragged M")]
+          (4000, 1280, 320, "ragged M"),
+          # the short-grid products of the atto step (<= 1 tile per CU: stage 3, proj, downsample convolutions and their data gradients)
+          (4864, 320, 1280, "s3 pw2/pw1.dg"), (4864, 1280, 320, "s3 pw1 (plain)"), (4864, 512, 320, "proj"), (4864, 320, 512, "proj.dgrad"),
+          (77824, 80, 160, "ds0 conv"), (19456, 160, 320, "ds1 conv"), (4864, 320, 640, "ds2 conv"), (19456, 320, 160, "ds1 dgrad"), (4864, 640, 320, "ds2 dgrad"),
+          (4864, 768, 3072, "tiny s3 pw2"), (4864, 512, 768, "tiny proj")]
+if os.environ.get("ONLY"):
+    shapes = [s_ for s_ in shapes if any(k in s_[3] for k in os.environ["ONLY"].split(","))]
 ws = torch.empty(16 << 20, device="cuda")
 for M, N, K, name in shapes:
     torch.manual_seed(M + N + K)
