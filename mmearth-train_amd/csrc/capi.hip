@@ -1176,6 +1176,11 @@ int mpmae_program_run(MpmaeProgram* p, int first, int count, mpmae_stream_t main
   }
   if (lanes) {                                   // join
     for (size_t l = 0; l < p->side.size(); ++l) {
+      // ... unless the main lane has ALREADY waited for this lane's last op of the run (the step: the optimizer's first op waits for the last
+      // weight gradient of every lane): the record + wait pair would be two more barrier packets at the step boundary for an implied order
+      int last = -1;
+      for (int i = first + count - 1; i >= first && last < 0; --i) if (p->ops[i].lane == (int)l + 1) last = i;
+      if (last < 0 || seen[0][l + 1] >= last) continue;
       if (hipEventRecord(p->join[l], p->side[l]) != hipSuccess) return (int)hipGetLastError();
       if (hipStreamWaitEvent(main, p->join[l], 0) != hipSuccess) return (int)hipGetLastError();
     }
