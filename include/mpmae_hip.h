@@ -396,6 +396,7 @@ enum MpmaeOption {
   MPMAE_OPT_RSN3,   /* default 5: the fused pointwise BACKWARD kernel at C = 160 (mpmae_rs which = 5, single GRN group, dz materialised) in its ring-pipelined form (csrc/rsn3.cuh: weight slabs by DMA into a three-slot LDS ring, rows two chunks ahead, one bare barrier per chunk); value = waves per workgroup (4 or 5); 0 = rsc_narrow */
   MPMAE_OPT_EVX,   /* default 1: in a launch program an op's cross-lane signal is the completion event of its last kernel launch (hipExtLaunchKernelGGL stopEvent) instead of a hipEventRecord - a barrier packet of its own - behind it: 1.65 us less per signal on the signalling lane (tools/probes/ext_event_probe.hip); 0 = hipEventRecord */
   MPMAE_OPT_RST_NW,   /* default 16: waves per workgroup of that pass (16: 1024 threads, 256-row tiles, one workgroup per CU - a quarter of the slab rows; 4: 256 threads, 64-row tiles, 2-3 per CU) */
+  MPMAE_OPT_NT_RING,   /* default 1: ring form of the direct-to-LDS NT GEMM (gemm_nt_ring_kernel, NST stages of BK-deep slabs): 1 = by shape (<= one tile per CU: 3 x 64; K <= 512: 3 x 32; else the two-buffer kernel), 0 = off, NST * 100 + BK (332, 432, 632, 364, 464) = that ring for every eligible product (probes) */
   MPMAE_OPT_COUNT_
 };
 int mpmae_set_option(int option, int value);

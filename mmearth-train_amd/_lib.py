@@ -153,7 +153,7 @@ class StemFrontArgs(C.Structure):
                 ("track_activity", c_int), ("act_out", c_void_p)]
 
 
-OPT = {n: i for i, n in enumerate("DW DWW NT_GLDS64 NT_BK32 NT_GLDS TN CS_SPLIT RSC_PF RSC_N40 RSC_N80 TN3_BLOCKS TNG_BLOCKS FOLD_GROUP RSC_W5 RSC_ATOMIC DET RSC1 RSC1_ATOMIC RSP RSP_NWV RSP_NARROW RSN3 EVX RST_NW".split())}      # enum MpmaeOption (include/mpmae_hip.h)
+OPT = {n: i for i, n in enumerate("DW DWW NT_GLDS64 NT_BK32 NT_GLDS TN CS_SPLIT RSC_PF RSC_N40 RSC_N80 TN3_BLOCKS TNG_BLOCKS FOLD_GROUP RSC_W5 RSC_ATOMIC DET RSC1 RSC1_ATOMIC RSP RSP_NWV RSP_NARROW RSN3 EVX RST_NW NT_RING".split())}      # enum MpmaeOption (include/mpmae_hip.h)
 PRO = dict(NONE=0, LN_AFFINE=1, GRN=2, GRN_BWD=3, DOWN_GATHER=4, ROW_GATHER=5, IM2COL3=6)
 EPI = dict(STORE=0, GELU_SUMSQ=1, RESID=2, DZ_STATS=3, SCATTER_ROWS=4, DOWN_DGRAD=5)
 

@@ -68,6 +68,7 @@ int g_opt[MPMAE_OPT_COUNT_] = {
     /* MPMAE_OPT_RSN3 */ 5,
     /* MPMAE_OPT_EVX */ 1,
     /* MPMAE_OPT_RST_NW */ 16,
+    /* MPMAE_OPT_NT_RING */ 1,
 };
 
 int mpmae_set_option(int option, int value) {

@@ -246,6 +246,33 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   glds = g_opt[MPMAE_OPT_NT_GLDS];
   if (glds && (epi == EPI_STORE || epi == EPI_RESID) && (BN == 128 || glds_bn64()) && a.M >= 4096 && a.K % 64 == 0) {
     // direct global -> LDS slabs, swizzled unpadded rows
+    int ring = g_opt[MPMAE_OPT_NT_RING];
+    if (ring == 1) {
+      // auto (stand-alone numbers of the 22 step shapes: profiles/r06/gemm_ring_probe.txt): a grid of at most one tile per CU has nobody to hide a
+      // round trip behind - three 64-deep stages (stage-3 pwconv2 / pwconv1.dgrad 14.5 -> 11.9 us, tiny's K = 3072 products 37.4 -> 33.1; four stages
+      // are 0.6 / 1.2 us faster alone and 0.007 ms slower in the step); short K on a large grid - three 32-deep stages (decoder pwconv1 47.6 -> 44.9,
+      // pixel heads 57.9 -> 52.5); long K on a large grid stays on the two-buffer kernel, whose 64 KB let two workgroups share a CU (decoder pwconv2
+      // 33.1 vs 37.4 / 44.7 us for the rings). In the step: 3.375 vs 3.425 ms (atto), 14.70 vs 14.78 (tiny) - profiles/r06/ab_nt_ring.txt
+      const int tiles = (int)(g.x * g.y);
+      ring = (tiles <= ps_num_cus() && a.K >= 256) ? 364 : (a.K <= 512 ? 332 : 0);
+    }
+    if (ring > 1) {      // NST * 100 + BK: the ring form (gemm_nt_ring_kernel), more than one slab in flight per workgroup
+#define NT_RING(BK_, NST_) do { \
+        const size_t l = (size_t)NST_ * (FBM + BN) * BK_ * sizeof(bf16_t); \
+        static bool once = false; \
+        if (!once && l > 64 * 1024) { \
+          if (hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, BK_, NST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) return (int)hipGetLastError(); \
+          once = true; \
+        } \
+        LAUNCH((gemm_nt_ring_kernel<BN, BK_, NST_>), g, dim3(256), l, st, a); \
+        return launch_status(); } while (0)
+      if (ring == 332) NT_RING(32, 3);
+      if (ring == 432) NT_RING(32, 4);
+      if (ring == 632) NT_RING(32, 6);
+      if (ring == 364) NT_RING(64, 3);
+      if (ring == 464) NT_RING(64, 4);
+#undef NT_RING
+    }
     if (glds == 2 || a.K <= 512) {
       const size_t l = (size_t)(2 * FBM * 32 + 2 * BN * 32) * sizeof(bf16_t);
       const size_t need = l > (size_t)128 * 68 * 4 ? l : (size_t)128 * 68 * 4;

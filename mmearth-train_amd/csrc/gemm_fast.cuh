@@ -38,6 +38,198 @@ __device__ __forceinline__ uint4 ldg16_guard(const bf16_t* base, int row, int nr
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Epilogue of the direct-to-LDS kernels: the MFMAs are issued transposed over interleaved column-tile pairs, so a lane holds 8 CONSECUTIVE output
+// columns of one row and stores them as one 16-byte vector straight from the accumulators (bias, optional residual, row mask).
+template <int BN>
+__device__ __forceinline__ void nt_glds_epilogue(const GemmP& p, f32x4_t (&acc)[4][BN / 32], int m0, int n0, int wm, int wn, int lr, int lg) {
+  constexpr int NJ = BN / 32;
+  // epilogue: lane = row m0 + wm*64 + i*16 + lr, columns n0 + wn*(BN/2) + jp*32 + lg*8 + (t*4 + r)
+  bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+  const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
+  if constexpr (NJ == 2) {
+    // 64-wide tiles (stage 3, downsample, stem: activity bytes AND residuals): every optional operand of the tile's rows is
+    // requested first - clamped addresses, pointer selects, opaque masks - and consumed afterwards; in the store loop below
+    // (`live = !act || act[row]; if (R) ld8(R...)`) they are two dependent round trips per 16-row group. (At 128-wide tiles the
+    // extra 32 + 16 registers cost more occupancy than the round trips: head GEMM 69 -> 80 us.)
+    const unsigned act_m = opaque_mask(p.act != nullptr) & 0xffu, r_m = opaque_mask(Rg != nullptr), b_m = opaque_mask(p.bias != nullptr);
+    const int colc = min(n0 + wn * (BN / 2) + lg * 8, p.N - 8);
+    const float* bp = p.bias ? p.bias + colc : reinterpret_cast<const float*>(p.B);
+    const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+    uint8_t lv[4];
+    uint4 rraw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rowc = min(m0 + wm * 64 + i * 16 + lr, p.M - 1);
+      lv[i] = *(p.act ? p.act + rowc : reinterpret_cast<const uint8_t*>(p.B));
+      rraw[i] = *reinterpret_cast<const uint4*>(Rg ? Rg + (size_t)rowc * p.ldr + colc : reinterpret_cast<const bf16_t*>(p.B));
+    }
+    const int col = n0 + wn * (BN / 2) + lg * 8;
+    if (col < p.N) {
+      const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + wm * 64 + i * 16 + lr;
+        if (row >= p.M) continue;
+        const bool live = ((lv[i] & act_m) | (~act_m & 1u)) != 0;
+        const uint4 rm = make_uint4(rraw[i].x & r_m, rraw[i].y & r_m, rraw[i].z & r_m, rraw[i].w & r_m);
+        float v[8], rr[8];
+        rr[0] = __uint_as_float(rm.x << 16); rr[1] = __uint_as_float(rm.x & 0xffff0000u);
+        rr[2] = __uint_as_float(rm.y << 16); rr[3] = __uint_as_float(rm.y & 0xffff0000u);
+        rr[4] = __uint_as_float(rm.z << 16); rr[5] = __uint_as_float(rm.z & 0xffff0000u);
+        rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][e >> 2][e & 3] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
+        st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int jp = 0; jp < NJ / 2; ++jp) {
+    const int col = n0 + wn * (BN / 2) + jp * 32 + lg * 8;
+    if (col >= p.N) continue;                          // N % 8 == 0 guaranteed by the dispatcher
+    float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+      bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + wm * 64 + i * 16 + lr;
+      if (row >= p.M) continue;
+      const bool live = !p.act || p.act[row];
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * jp + (e >> 2)][e & 3] + bv[e];
+      if (Rg) {
+        float rr[8];
+        ld8<bf16_t>(Rg + (size_t)row * p.ldr + col, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      if (!live) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
+    }
+  }
+}
+
+// Ring form of the direct-to-LDS NT kernel (round 6): the same 128 x BN tile, fragment layout, swizzle and epilogue, with the K slabs in a ring of
+// NST stages instead of two buffers. gemm_nt_bf16_kernel<.., GLDS> requests slab kt + 1 at the top of iteration kt and ends the iteration with
+// __syncthreads(), whose vmcnt(0) waits for that request: a workgroup has ONE slab in flight, and an iteration of 16-32 MFMAs per wave is shorter
+// than a round trip under load - it lives off the second workgroup of the CU. Here NST - 1 slabs are in flight per workgroup: the wait at the top of
+// iteration kt is a COUNTED vmcnt (PER requests per thread and slab, NST - 2 slabs may stay outstanding), the only barrier a bare s_barrier that
+// publishes slab kt and frees the stage slab kt + NST - 1 lands in. The fragment reads are inline assembly (hipcc puts an s_waitcnt vmcnt(0) in
+// front of any LDS read it believes a global_load_lds may alias - gemm_tn3.cuh) with their own lgkmcnt waits.
+template <int BN, int BK, int NST>
+__global__ __launch_bounds__(256) void gemm_nt_ring_kernel(const GemmP p) {
+  constexpr int CPR = BK / 8, ACH = FBM * CPR / 256, BCH = BN * CPR / 256, PER = ACH + BCH, NJ = BN / 32, KS = BK / 32;
+  constexpr int A_B = FBM * BK * 2, B_B = BN * BK * 2, STAGE_B = A_B + B_B;
+  static_assert((BK == 64 || BK == 32) && NJ % 2 == 0 && NST >= 3 && (NST - 2) * PER <= 63, "ring shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lg = lane >> 4;
+  int mt, nt;
+  xcd_tile(mt, nt);
+  const int m0 = mt * FBM, n0 = nt * BN;
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+  f32x4_t acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  auto swz = [](int row) { return BK == 64 ? ((row & 3) | (((row >> 3) & 1) << 2)) : ((row & 1) | (((row >> 3) & 1) << 1)); };
+  // per-thread DMA sources of slab 0 (row clamped: products of rows / columns beyond M / N are never stored); slab kt is + kt * BK elements
+  const bf16_t* srcA[ACH];
+  const bf16_t* srcB[BCH];
+#pragma unroll
+  for (int i = 0; i < ACH; ++i) {
+    const int sl = i * 256 + tid, row = sl / CPR, ch = (sl % CPR) ^ swz(row);
+    srcA[i] = A + (size_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < BCH; ++i) {
+    const int sl = i * 256 + tid, row = sl / CPR, ch = (sl % CPR) ^ swz(row);
+    srcB[i] = B + (size_t)min(n0 + row, p.N - 1) * p.ldb + ch * 8;
+  }
+  auto dma = [&](int stage, int kt) {
+    unsigned char* as = smem_raw + stage * STAGE_B;
+    unsigned char* bs = as + A_B;
+#pragma unroll
+    for (int i = 0; i < ACH; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcA[i] + kt * BK), (lptr_t)(as + (i * 256 + wave * 64) * 16), 16, 0, 0);      // wave-uniform base; lane l lands at + 16 l
+#pragma unroll
+    for (int i = 0; i < BCH; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(srcB[i] + kt * BK), (lptr_t)(bs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+  };
+  // fragment addresses (bytes from the stage base; the tile index is an instruction immediate): A rows (mod 16) = lr; B rows of a tile PAIR are
+  // interleaved, row = (lr >> 2) * 8 + t * 4 + (lr & 3) (gemm_nt_bf16_kernel)
+  const int swa = swz(lr), browl = (lr >> 2) * 8 + (lr & 3), swb = swz(browl);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem_raw;
+  unsigned aa[KS], ba[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    aa[ks] = lds0 + ((wm * 64 + lr) * BK + (((ks * 4) + lg) ^ swa) * 8) * 2;
+    ba[ks] = lds0 + A_B + ((wn * (BN / 2) + browl) * BK + (((ks * 4) + lg) ^ swb) * 8) * 2;
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+#define NTR_RD(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm))
+  const int nk = p.K / BK;                     // K % BK == 0 (dispatcher)
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) dma(s, s);
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + NST - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * PER) : "memory");      // slab kt has landed, NST - 2 later ones may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                              // (the last NST - 2 iterations wait for everything)
+    __builtin_amdgcn_s_barrier();                    // ... for every wave's share; and every wave is done with slab kt - 1, whose stage is refilled now
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) dma((kt + NST - 1) % NST, kt + NST - 1);
+    const unsigned so = (unsigned)(kt % NST) * STAGE_B;
+    u32x4_t af[KS][4], bfr[KS][NJ];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i == 0) NTR_RD(af[ks][0], aa[ks] + so, 0);
+        else if (i == 1) NTR_RD(af[ks][1], aa[ks] + so, 16 * BK * 2);
+        else if (i == 2) NTR_RD(af[ks][2], aa[ks] + so, 32 * BK * 2);
+        else NTR_RD(af[ks][3], aa[ks] + so, 48 * BK * 2);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {      // j = 2 jp + t: rows (jp * 32 + t * 4) * BK
+        if (j == 0) NTR_RD(bfr[ks][0], ba[ks] + so, 0);
+        else if (j == 1) NTR_RD(bfr[ks][1], ba[ks] + so, 4 * BK * 2);
+        else if (j == 2) NTR_RD(bfr[ks][j], ba[ks] + so, 32 * BK * 2);
+        else NTR_RD(bfr[ks][j], ba[ks] + so, 36 * BK * 2);
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // LDS returns in order: "<= (KS - 1 - ks) * (4 + NJ) outstanding" covers the reads of k-step ks; the fragment registers are in / out operands
+      // of the wait so that no MFMA is scheduled above it
+      if (ks + 1 < KS) {
+        if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(bfr[ks][0]), "+v"(bfr[ks][1]), "+v"(bfr[ks][2]), "+v"(bfr[ks][3]));
+        else asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(bfr[ks][0]), "+v"(bfr[ks][1]));
+      } else {
+        if constexpr (NJ == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(bfr[ks][0]), "+v"(bfr[ks][1]), "+v"(bfr[ks][2]), "+v"(bfr[ks][3]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[ks][0]), "+v"(af[ks][1]), "+v"(af[ks][2]), "+v"(af[ks][3]), "+v"(bfr[ks][0]), "+v"(bfr[ks][1]));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bfr[ks][j]), __builtin_bit_cast(bf16x8_t, af[ks][i]), acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);      // k-step ks's MFMAs stay in front of the wait for k-step ks + 1 (hipcc had sunk 15 of 16 behind it)
+    }
+  }
+#undef NTR_RD
+  nt_glds_epilogue<BN>(p, acc, m0, n0, wm, wn, lr, lg);
+}
+
 template <int BN, int EPI, int BK = FBK, bool GLDS = false>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
   constexpr int LDK = GLDS ? BK : BK + FPAD, CPR = BK / 8, ACH = FBM * CPR / 256;   // LDS row, 16-byte chunks per row, A chunks per thread
@@ -142,77 +334,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_kernel(const GemmP p) {
       }
       __syncthreads();                      // carries the vmcnt(0) that retires the slab just requested
     }
-    // epilogue: lane = row m0 + wm*64 + i*16 + lr, columns n0 + wn*(BN/2) + jp*32 + lg*8 + (t*4 + r)
-    bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
-    const bf16_t* Rg = reinterpret_cast<const bf16_t*>(p.R);
-    if constexpr (NJ == 2) {
-      // 64-wide tiles (stage 3, downsample, stem: activity bytes AND residuals): every optional operand of the tile's rows is
-      // requested first - clamped addresses, pointer selects, opaque masks - and consumed afterwards; in the store loop below
-      // (`live = !act || act[row]; if (R) ld8(R...)`) they are two dependent round trips per 16-row group. (At 128-wide tiles the
-      // extra 32 + 16 registers cost more occupancy than the round trips: head GEMM 69 -> 80 us.)
-      const unsigned act_m = opaque_mask(p.act != nullptr) & 0xffu, r_m = opaque_mask(Rg != nullptr), b_m = opaque_mask(p.bias != nullptr);
-      const int colc = min(n0 + wn * (BN / 2) + lg * 8, p.N - 8);
-      const float* bp = p.bias ? p.bias + colc : reinterpret_cast<const float*>(p.B);
-      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-      uint8_t lv[4];
-      uint4 rraw[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rowc = min(m0 + wm * 64 + i * 16 + lr, p.M - 1);
-        lv[i] = *(p.act ? p.act + rowc : reinterpret_cast<const uint8_t*>(p.B));
-        rraw[i] = *reinterpret_cast<const uint4*>(Rg ? Rg + (size_t)rowc * p.ldr + colc : reinterpret_cast<const bf16_t*>(p.B));
-      }
-      const int col = n0 + wn * (BN / 2) + lg * 8;
-      if (col < p.N) {
-        const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = m0 + wm * 64 + i * 16 + lr;
-          if (row >= p.M) continue;
-          const bool live = ((lv[i] & act_m) | (~act_m & 1u)) != 0;
-          const uint4 rm = make_uint4(rraw[i].x & r_m, rraw[i].y & r_m, rraw[i].z & r_m, rraw[i].w & r_m);
-          float v[8], rr[8];
-          rr[0] = __uint_as_float(rm.x << 16); rr[1] = __uint_as_float(rm.x & 0xffff0000u);
-          rr[2] = __uint_as_float(rm.y << 16); rr[3] = __uint_as_float(rm.y & 0xffff0000u);
-          rr[4] = __uint_as_float(rm.z << 16); rr[5] = __uint_as_float(rm.z & 0xffff0000u);
-          rr[6] = __uint_as_float(rm.w << 16); rr[7] = __uint_as_float(rm.w & 0xffff0000u);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = live ? acc[i][e >> 2][e & 3] + __uint_as_float(__float_as_uint(bv[e]) & b_m) + rr[e] : 0.f;
-          st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
-        }
-      }
-      return;
-    }
-#pragma unroll
-    for (int jp = 0; jp < NJ / 2; ++jp) {
-      const int col = n0 + wn * (BN / 2) + jp * 32 + lg * 8;
-      if (col >= p.N) continue;                          // N % 8 == 0 guaranteed by the dispatcher
-      float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (p.bias) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col), b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + wm * 64 + i * 16 + lr;
-        if (row >= p.M) continue;
-        const bool live = !p.act || p.act[row];
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * jp + (e >> 2)][e & 3] + bv[e];
-        if (Rg) {
-          float rr[8];
-          ld8<bf16_t>(Rg + (size_t)row * p.ldr + col, rr);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += rr[e];
-        }
-        if (!live) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = 0.f;
-        }
-        st8<bf16_t>(Cg + (size_t)row * p.ldc + col, v);
-      }
-    }
+    nt_glds_epilogue<BN>(p, acc, m0, n0, wm, wn, lr, lg);
     return;
   } else {
   gload(0);

@@ -658,7 +658,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N):
 
 
 @pytest.mark.parametrize("opts", ["DW=8", "DW=6", "DW=5", "DW=3", "TN=1", "TN3_BLOCKS=0", "TN3_BLOCKS=256", "rsc_small=0", "RSC_PF=0,rsc_small=0",
-                                  "RSC_N40=1,RSC_N80=0", "NT_GLDS=0", "NT_GLDS64=0,NT_BK32=0", "CS_SPLIT=0", "DWW=5", "FOLD_GROUP=1", "RSC_W5=0", "RSC_ATOMIC=320", "RSC1=0", "RSC1=2,RSC1_ATOMIC=0", "RSP=0", "RSP=2,RSP_NARROW=15", "RSP_NWV=8,RSP_NARROW=15", "RSN3=0", "RSN3=4",
+                                  "RSC_N40=1,RSC_N80=0", "NT_GLDS=0", "NT_GLDS64=0,NT_BK32=0", "CS_SPLIT=0", "DWW=5", "FOLD_GROUP=1", "RSC_W5=0", "RSC_ATOMIC=320", "RSC1=0", "RSC1=2,RSC1_ATOMIC=0", "RSP=0", "RSP=2,RSP_NARROW=15", "RSP_NWV=8,RSP_NARROW=15", "RSN3=0", "RSN3=4", "NT_RING=0", "NT_RING=364", "NT_RING=432",
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
                                   "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "loss_onepass=0", "grn_apply_fin=0", "stats_wgrad=0", "wg_fused=0", "down_fused=0", "RST_NW=4", "stats_wgrad=0,wg_fused=0", "img_dgrad_side=0", "EVX=0", "FOLD_GROUP=-1,tail_fold_group=0", 
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",

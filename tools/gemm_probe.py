@@ -37,6 +37,7 @@ shapes = [(12544, 2048, 512, "dec pw1"), (12544, 512, 2048, "dec pw2"), (12544, 
 if os.environ.get("ONLY"):
     shapes = [s_ for s_ in shapes if any(k in s_[3] for k in os.environ["ONLY"].split(","))]
 ws = torch.empty(16 << 20, device="cuda")
+RINGS = [int(v) for v in os.environ.get("RINGS", "").split(",") if v]      # NT_RING values to time next to the default kernel (e.g. RINGS=332,432,364)
 for M, N, K, name in shapes:
     torch.manual_seed(M + N + K)
     a = torch.randn(M, K, device="cuda", dtype=bf); w = torch.randn(N, K, device="cuda", dtype=bf) / K ** 0.5
@@ -53,7 +54,18 @@ for M, N, K, name in shapes:
     us = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
     us0 = us
     usv = t(lambda: torch.nn.functional.linear(a, w))
-    print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF (128-row tiles {us0:6.1f} us) | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}", flush=True)
+    ring_txt = ""
+    for rv in RINGS:
+        lib.mpmae_set_option(_lib.OPT["NT_RING"], rv)
+        try:
+            c.zero_()
+            assert lib.mpmae_gemm(1, 0, 0, C.byref(g), st) == 0
+            er = rel(c.float(), ref)
+            ur = t(lambda: lib.mpmae_gemm(1, 0, 0, C.byref(g), st))
+        finally:
+            lib.mpmae_set_option(_lib.OPT["NT_RING"], 0)
+        ring_txt += f" | ring {rv}: {ur:6.1f} us {2*M*N*K/ur/1e6:5.0f} TF err {er:.0e}"
+    print(f"{name:15s} M={M} N={N} K={K}: bf16 {us:6.1f} us {2*M*N*K/us/1e6:6.0f} TF (128-row tiles {us0:6.1f} us) | vendor {usv:6.1f} us {2*M*N*K/usv/1e6:6.0f} TF | rel err {err0:.1e}{ring_txt}", flush=True)
     if os.environ.get("BRIEF"):
         continue
     # epilogues: residual + row mask, GELU^2 sums, dz statistics
