@@ -122,7 +122,7 @@ FAMILY_SYMBOLS = {
     "wgrad": ("gemm_tn2_kernel", "gemm_tn3_kernel", "gemm_tng_kernel", "gemm_tn_bf16_kernel"),
     "dwconv7": ("dwconv7_mfma_kernel", "dwconv7_v6_kernel", "dwconv7_v6s1_kernel"),
     "dwconv7_wgrad": ("dwconv7_wgrad_mfma_kernel", "dwconv7_wgrad_mfma4_kernel", "dwconv7_wgrad_v5_kernel", "dwconv7_wgrad_v6s1_kernel"),
-    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt3_kernel"),
+    "gemm_nt": ("gemm_nt_bf16_kernel", "gemm_nt_ring_kernel", "gemm_nt3_kernel"),
     "ps_fwd": ("ps_fwd_kernel",),
 }
 FAMILY_TEXT = {

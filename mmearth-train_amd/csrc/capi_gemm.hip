@@ -244,7 +244,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
   bk32 = g_opt[MPMAE_OPT_NT_BK32];
   int glds;
   glds = g_opt[MPMAE_OPT_NT_GLDS];
-  if (glds && (epi == EPI_STORE || epi == EPI_RESID) && (BN == 128 || glds_bn64()) && a.M >= 4096 && a.K % 64 == 0) {
+  if (glds && (epi == EPI_STORE || epi == EPI_RESID) && (BN == 128 || glds_bn64()) && a.M >= 4096 && (a.K % 64 == 0 || (a.K % 32 == 0 && a.K <= 512))) {      // (K = 160: downsample 0 - the 32-deep kernels)
     // direct global -> LDS slabs, swizzled unpadded rows
     int ring = g_opt[MPMAE_OPT_NT_RING];
     if (ring == 1) {
@@ -256,6 +256,7 @@ static int launch_gemm_fast_bn(int epi, const GemmP& a, hipStream_t st) {
       const int tiles = (int)(g.x * g.y);
       ring = (tiles <= ps_num_cus() && a.K >= 256) ? 364 : (a.K <= 512 ? 332 : 0);
     }
+    if ((ring == 364 || ring == 464) && (a.K & 63)) ring = 332;      // (K = 160: 32-deep slabs only)
     if (ring > 1) {      // NST * 100 + BK: the ring form (gemm_nt_ring_kernel), more than one slab in flight per workgroup
 #define NT_RING(BK_, NST_) do { \
         const size_t l = (size_t)NST_ * (FBM + BN) * BK_ * sizeof(bf16_t); \

@@ -19,7 +19,7 @@ FAMILIES = collections.OrderedDict([
     ("dwconv7", r"dwconv7_mfma_kernel|dwconv7_v6_kernel|dwconv7_v6s1_kernel|dwconv7_v5_kernel"),
     ("dwconv7_wgrad", r"dwconv7_wgrad|reduce_partials_kernel<2>|reduce_partials_group2_kernel"),
     ("ps_fwd", r"ps_fwd_kernel"),
-    ("gemm_nt", r"gemm_nt_bf16_kernel|gemm_nt3_kernel|gemm_kernel"),
+    ("gemm_nt", r"gemm_nt_bf16_kernel|gemm_nt_ring_kernel|gemm_nt3_kernel|gemm_kernel"),
     ("loss", r"loss_"),
     ("ln", r"ln_fwd|ln_bwd"),
     ("stem", r"stem_front_kernel|stem_tail|im2col3_kernel|dwstride2_"),
