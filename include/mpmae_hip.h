@@ -216,12 +216,15 @@ int mpmae_fold_group(const MpmaeFoldDesc* descs, int count, mpmae_stream_t strea
  * barrier per block for the GRN statistics (device-scope float atomics into G2 + a monotonic arrival counter).
  * bf16 activations only. Supported shapes: (C = 160, S = 2, keep <= 20) and (C = 320, S = 1, keep <= 32), N <= number of
  * compute units of the device (every workgroup must be resident), nblk <= MPMAE_PS_MAXBLK; anything else returns
- * hipErrorInvalidValue and the caller uses mpmae_dwconv7_fwd / mpmae_rs. `sync` = 4 zero-initialised device words
- * {arrivals, departures, error, -}: the kernel leaves arrivals / departures at zero again; error != 0 after a launch means a
+ * hipErrorInvalidValue and the caller uses mpmae_dwconv7_fwd / mpmae_rs. `sync` = `sync_words` zero-initialised device words, 4
+ * {arrivals, departures, error, -} for the flat arrival counter or MPMAE_PS_SYNC_WORDS (640: + a top counter, 8 group counters and 8 group
+ * flags on 128-byte lines of their own) for the XCD-hierarchical barrier of round 6 (8 groups of workgroups arrive on their own counter, the
+ * groups' last arrivers on the top counter; MI355X_MICROARCH.md "barrier-xcd"): the kernel leaves every counter at zero again; error != 0 after a launch means a
  * workgroup never became resident within the spin bound (e.g. another persistent kernel shares the GPU) and the results
  * are invalid. The forward writes, per block, exactly what the backward and the weight gradients read: x-hat, rstd, xn
  * (LayerNorm output), h (pwconv1 output), z (GRN output), out, and Gx / Ainv / scale of the GRN. */
 #define MPMAE_PS_MAXBLK 9
+#define MPMAE_PS_SYNC_WORDS 640
 typedef struct MpmaePsBlock {
   const float* dw_w; const float* dw_b;        /* ME depthwise kernel (49, C), index (kw*7 + kh)*C + c; bias (C) */
   const float* ln_g; const float* ln_b;
@@ -239,6 +242,7 @@ typedef struct MpmaePsArgs {
   int C, nblk; float eps;
   int ng;                                      /* accumulator copies per statistics vector (1 .. 16): measured best 4 at 256 workgroups */
   unsigned* sync;
+  int sync_words, pad_;                        /* words behind `sync`: >= MPMAE_PS_SYNC_WORDS selects the XCD-hierarchical grid barrier, 4 .. the flat counter */
   MpmaePsBlock blk[MPMAE_PS_MAXBLK];
 } MpmaePsArgs;
 int mpmae_ps_fwd(const MpmaePsArgs* args, mpmae_stream_t stream);

@@ -113,6 +113,7 @@ class FoldDesc(C.Structure):
 
 
 PS_MAXBLK = 9          # MPMAE_PS_MAXBLK
+PS_SYNC_WORDS = 640    # MPMAE_PS_SYNC_WORDS
 DWG_MAX = 12           # problems per mpmae_dwconv7_wgrad_group launch (csrc/dwconv.cuh)
 TNG_MAXP = 20          # problems per mpmae_wgrad_group launch (csrc/gemm_tng.cuh)
 
@@ -128,7 +129,7 @@ class PsBlock(C.Structure):
 class PsArgs(C.Structure):
     _fields_ = [("x_in", c_void_p), ("g", Geom), ("act", c_void_p),
                 ("C", c_int), ("nblk", c_int), ("eps", c_float), ("ng", c_int),
-                ("sync", c_void_p), ("blk", PsBlock * PS_MAXBLK)]
+                ("sync", c_void_p), ("sync_words", c_int), ("pad_", c_int), ("blk", PsBlock * PS_MAXBLK)]
 
 
 class Meters(C.Structure):

@@ -357,7 +357,7 @@ int ps_num_cus() {
 }
 
 static int ps_check(const MpmaePsArgs& a, int S, int keep_max) {
-  if (!a.x_in || !a.g.vis || !a.g.inv || !a.sync || a.nblk < 1 || a.nblk > MPMAE_PS_MAXBLK || a.ng < 1 || a.ng > 16) return (int)hipErrorInvalidValue;
+  if (!a.x_in || !a.g.vis || !a.g.inv || !a.sync || a.sync_words < 4 || a.nblk < 1 || a.nblk > MPMAE_PS_MAXBLK || a.ng < 1 || a.ng > 16) return (int)hipErrorInvalidValue;
   if (a.g.S != S || a.g.keep < 1 || a.g.keep > keep_max || a.g.N < 1 || a.g.N > ps_num_cus()) return (int)hipErrorInvalidValue;
   if ((size_t)a.g.keep * S * S * a.C * 4 >= 65535u) return (int)hipErrorInvalidValue;       // 16-bit LDS offsets of the neighbour table
   return 0;

@@ -60,10 +60,62 @@ __device__ __forceinline__ void grid_barrier(unsigned* sync, unsigned target) {
   __syncthreads();
 }
 
-__device__ __forceinline__ void grid_exit(unsigned* sync, unsigned nwg) {
+// XCD-hierarchical form (round 6; MI355X_MICROARCH.md "barrier-xcd": 4.1-4.8 us at 256 workgroups against 7.4 for the flat counter, whose 255
+// arrivals serialise on one word). Workgroup b arrives on the counter of group x = b % 8 (the dispatcher deals workgroups round-robin over the 8
+// XCDs; only the speed depends on that); the LAST arriver of a group arrives on the top counter and polls it (8 pollers), then publishes the
+// generation in its group's flag word, which the group's other workgroups poll (<= 32 pollers per 128-byte line instead of 256 on one).
+// All counters are monotonic over the launch (generation gen = 1, 2, ...: a workgroup cannot arrive for gen + 1 before gen is complete) and
+// every word sits on its own 128-byte line: sync[32] top, sync[64 + 32 x] group counters, sync[320 + 32 x] group flags (MPMAE_PS_SYNC_WORDS = 640).
+// Atomics / atomic loads on both sides of every exchange, as above; same spin bound and error word.
+constexpr int HB_TOP = 32, HB_CNT = 64, HB_FLAG = 320, HB_WORDS = 640;
+// Split in two so that a workgroup can ARRIVE as soon as its statistics are out and WAIT only after it has issued what does not depend on them
+// (pw2's first weight slabs, the residual rows and bias of its own tiles): `role` (thread 0 only) = 1 for the last arriver of its group.
+__device__ __forceinline__ unsigned grid_arrive_xcd(unsigned* sync, unsigned gen, unsigned nwg) {
+  __syncthreads();
+  unsigned role = 0;
+  if (threadIdx.x == 0) {
+    const unsigned x = blockIdx.x & 7u;
+    const unsigned gsz = (nwg >> 3) + ((nwg & 7u) > x ? 1u : 0u);
+    const unsigned old = __hip_atomic_fetch_add(&sync[HB_CNT + 32 * x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == gen * gsz) {                    // last of its group in this generation
+      __hip_atomic_fetch_add(&sync[HB_TOP], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      role = 1;
+    }
+  }
+  return role;
+}
+__device__ __forceinline__ void grid_wait_xcd(unsigned* sync, unsigned gen, unsigned nwg, unsigned role) {
+  if (threadIdx.x == 0) {
+    const unsigned x = blockIdx.x & 7u, ngroups = nwg < 8u ? nwg : 8u;
+    bool failed = false;
+    auto wait_for = [&](unsigned* w, unsigned target) {
+      unsigned spins = 0;
+      while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 21)) { __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); failed = true; break; }
+      }
+    };
+    if (role) {
+      wait_for(&sync[HB_TOP], gen * ngroups);
+      if (!failed) __hip_atomic_store(&sync[HB_FLAG + 32 * x], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      wait_for(&sync[HB_FLAG + 32 * x], gen);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void grid_exit(unsigned* sync, unsigned nwg, bool hier) {
   if (threadIdx.x == 0) {
     const unsigned old = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old == nwg - 1) {
+    if (old == nwg - 1) {                          // the last workgroup to leave: every other one is past its last barrier
+      if (hier) {
+        __hip_atomic_store(&sync[HB_TOP], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int x = 0; x < 8; ++x) {
+          __hip_atomic_store(&sync[HB_CNT + 32 * x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sync[HB_FLAG + 32 * x], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
       __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -259,6 +311,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
 
   const int tid0 = threadIdx.x;
   const int n = blockIdx.x, nwg = gridDim.x;
+  const bool hier = a.sync_words >= HB_WORDS;      // (the XCD-hierarchical grid barrier needs its 640 sync words; 4 words: the flat counter)
   const int keep = a.g.keep, R = keep * SS;
   const size_t rowbase = (size_t)n * R;
 
@@ -502,8 +555,21 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
         if (j < H) (void)unsafeAtomicAdd(B.G2 + (size_t)(n % a.ng) * H + j, csum[j]);      // ng accumulator copies: fewer colliding adds per line
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the adds are performed (acknowledged) before this workgroup arrives
+      unsigned role = 0;
+      if (hier) role = grid_arrive_xcd(a.sync, (unsigned)(b + 1), nwg);      // arrive early ...
       gemm_prefetch<NTL, KS2, D2>(wl2, 8 * 16 * B.ldw2, wq2, n % KS2);      // pw2's first weight slabs travel while the barrier is waited for
-      grid_barrier(a.sync, (unsigned)(b + 1) * nwg);
+      // ... and so do the residual rows and the bias of this wave's output tiles (consumed behind pw2)
+      const T* xr = xres + rowbase * C;
+      uint2 xraw[NTL][MT];
+      float4 b4[NTL];
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        b4[j] = *reinterpret_cast<const float4*>(B.b2 + (wave + 8 * j) * 16 + lg * 4);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          xraw[j][m] = *reinterpret_cast<const uint2*>(xr + (size_t)min(m * 16 + lr, R - 1) * C + (wave + 8 * j) * 16 + lg * 4);
+      }
+      if (hier) grid_wait_xcd(a.sync, (unsigned)(b + 1), nwg, role); else grid_barrier(a.sync, (unsigned)(b + 1) * nwg);      // ... wait late
       PS_STAMP(4);
       float gx[NJ], s = 0.f;
 #pragma unroll
@@ -555,18 +621,6 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
           }
         }
       }
-      // residual rows and bias: requested before the product, consumed after it
-      T* outg = reinterpret_cast<T*>(B.out) + rowbase * C;
-      const T* xr = xres + rowbase * C;
-      uint2 xraw[NTL][MT];
-      float4 b4[NTL];
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        b4[j] = *reinterpret_cast<const float4*>(B.b2 + (wave + 8 * j) * 16 + lg * 4);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          xraw[j][m] = *reinterpret_cast<const uint2*>(xr + (size_t)min(m * 16 + lr, R - 1) * C + (wave + 8 * j) * 16 + lg * 4);
-      }
       __syncthreads();
 
       PS_STAMP(6);
@@ -613,7 +667,7 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     }
     PS_STAMP(7);
   }
-  grid_exit(a.sync, nwg);
+  grid_exit(a.sync, nwg, hier);
 }
 
 }  // namespace ps

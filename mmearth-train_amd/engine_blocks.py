@@ -54,9 +54,11 @@ class BlocksMixin:
         a.x_in, a.g, a.act = x.data_ptr(), self._geom(stage), (self.act[stage].data_ptr() if self.act[stage] is not None else 0)
         a.C, a.nblk, a.eps, a.ng = blks[0]["C"], len(blks), 1e-6, self.PS_NG
         if not hasattr(self, "ps_sync"):
-            self.ps_sync = torch.zeros(8, 64, dtype=torch.int32, device=self.device)     # one {arrivals, departures, error, -, debug...} row per launch
+            # one row per launch: {arrivals, departures, error, -, debug...} + the counters / flags of the XCD-hierarchical grid barrier on their own lines
+            self.ps_sync = torch.zeros(8, _lib.PS_SYNC_WORDS, dtype=torch.int32, device=self.device)
             self._ps_launches = 0
         a.sync = self.ps_sync[self._ps_launches].data_ptr()
+        a.sync_words = _lib.PS_SYNC_WORDS if int(self.opt["ps_xcd_barrier"]) else 4
         self._ps_launches += 1
         nbytes = flops = 0
         for i, blk in enumerate(blks):

@@ -44,6 +44,7 @@ ENGINE_OPTIONS = dict(
     proj_compact=1,         # proj as a plain NT GEMM on compact rows: the token kernel assembles the decoder input, its backward gathers the visible rows (no scatter / gather GEMM variants)
     zero_side=1,            # the step's zero fills (statistics, flat gradients, padded stem dW) on the side lane, ONE loss finalisation per step
     wgrad_late=1,           # pw2's weight gradient issued behind the block's second fused kernel (one main-lane event per block)
+    ps_xcd_barrier=1,       # round 6: the persistent stage kernels' grid barrier in its XCD-hierarchical form (8 group counters + a top counter, MpmaePsArgs.sync_words = 640); 0 = the flat arrival counter
     ps=2,                   # persistent per-sample stage kernels (ps.cuh): bit 1 = (C, S) = (160, 2), bit 0 = (320, 1); one launch per stage. 2 since late round 4: with the decoder / head GEMMs on the vendor route the per-block kernels at stage 3 (2 blocks, M = 3584) measure 3.868-3.873 vs 3.892-3.897 ms for 3 in three interleaved pairs (a tie in round 3); 1: 4.04
     rsc=1,                  # chunked row-streaming kernels (rsc.cuh) at C = 160 / 320
     act_in_stem=1,          # the fused stem kernel writes the pixel-activity bytes itself (it computes them anyway): no activity launch, the first stage-0 op waits for nothing on the side lane, the poolings run behind the stem

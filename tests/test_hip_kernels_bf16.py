@@ -559,7 +559,7 @@ def test_depthwise_stem_2x2_stride2_bf16(Cc, S, NK):
     assert _rel(dw, rdw) < 3e-4 and _rel(db, dout.float().sum(0)) < 3e-4
 
 
-def _ps_pair(N, seed):
+def _ps_pair(N, seed, xcd_barrier=1):
     """Two bf16 engines on the same weights / inputs / mask: persistent stage kernels (csrc/ps.cuh) vs the per-block kernels."""
     from mmearth_train_amd.config import make_cfg
     from mmearth_train_amd.engine import Engine
@@ -572,7 +572,7 @@ def _ps_pair(N, seed):
     engs = []
     for ps in (0, 1):
         # (z_free=0: the per-block reference stores z, which this comparison reads)
-        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=3 * ps, z_free=0))
+        e = Engine(cfg, N, dtype="bf16", device=DEV, options=dict(ps=3 * ps, z_free=0, ps_xcd_barrier=xcd_barrier))
         e.load_state_dict(sd)
         e.set_inputs(inputs, noise)
         engs.append(e)
@@ -620,20 +620,22 @@ def test_fused_stem_front_matches_im2col_gemm_and_stem_tail(N):
     assert torch.allclose(out[1]["losses"], out[0]["losses"], rtol=2e-2)
 
 
-@pytest.mark.parametrize("N", [3, 40])
-def test_persistent_stage_kernels_match_the_per_block_kernels(N):
-    """mpmae_ps_fwd (one launch per stage, grid barrier per block) against mpmae_dwconv7_fwd + mpmae_rs + GEMMs on the same bf16
+@pytest.mark.parametrize("N,xcd_barrier", [(3, 1), (40, 1), (9, 1), (40, 0), (5, 0)])
+def test_persistent_stage_kernels_match_the_per_block_kernels(N, xcd_barrier):
+    """mpmae_ps_fwd (one launch per stage, grid barrier per block: the XCD-hierarchical form, MpmaePsArgs.sync_words = 640 - N = 3 / 9 / 40: fewer
+    workgroups than groups, groups of unequal size, five per group - and the flat arrival counter, sync_words = 4) against mpmae_dwconv7_fwd + mpmae_rs + GEMMs on the same bf16
     operands: every tensor the backward reads (x-hat, rstd, xn, h, z, out, GRN vectors), the losses and all gradients.
     Stated bound: bf16 tensors within 3 bf16 ulps of each other relative to the tensor's max (both paths
     round the same fp32 values at slightly different points, and the differences of one block feed the next), statistics 1e-2."""
-    e0, e1 = _ps_pair(N, 31)
+    e0, e1 = _ps_pair(N, 31, xcd_barrier)
     assert any(op[0].endswith("ps.fwd[6]") for op in e1.fwd_ops) and not any("ps.fwd" in op[0] for op in e0.fwd_ops)
-    for e in (e0, e1):
-        e.forward()
-        e.backward()
+    for it in range(2):             # (twice: the second launch starts from the counters the first one left)
+        for e in (e0, e1):
+            e.forward()
+            e.backward()
     torch.cuda.synchronize()
     assert int(e1.ps_sync[:, 2].sum()) == 0, "a persistent kernel timed out at its grid barrier"
-    assert int(e1.ps_sync[:, :2].abs().sum()) == 0, "arrival / departure counters must be left at zero"
+    assert int(e1.ps_sync.abs().sum()) == 0, "every arrival / departure / group counter and flag must be left at zero"
     assert torch.equal(e0.mask, e1.mask)
     for b0, b1 in zip(e0.blocks, e1.blocks):
         if b0["stage"] not in (2, 3):
@@ -662,7 +664,7 @@ def test_persistent_stage_kernels_match_the_per_block_kernels(N):
                                   # engine (launch-program) options: lower-case names go to Engine(options=...)
                                   "stem_fused=0", "stem_im2col=0", "stem_front=0", "loss_multi=0", "loss_rows=0,loss_rows_bwd=0", "loss_onepass=0", "grn_apply_fin=0", "stats_wgrad=0", "wg_fused=0", "down_fused=0", "RST_NW=4", "stats_wgrad=0,wg_fused=0", "img_dgrad_side=0", "EVX=0", "FOLD_GROUP=-1,tail_fold_group=0", 
                                   "down_grouped=0", "heads_merged=0", "dzr=0", "grn_fold=0", "rsc=0", "rsc_small=0", "lanes=0",
-                                  "img_side=0,prep_side=0", "front_side=0,zero_side=0", "prep_late=0", "proj_compact=0", "z_free=0", "wgrad_late=0", "ring=2,dz_ring=2", "tail_main=0", "tail_main=1", "act_in_stem=0", "ps=3"])
+                                  "img_side=0,prep_side=0", "ps_xcd_barrier=0", "front_side=0,zero_side=0", "prep_late=0", "proj_compact=0", "z_free=0", "wgrad_late=0", "ring=2,dz_ring=2", "tail_main=0", "tail_main=1", "act_in_stem=0", "ps=3"])
 def test_fallback_kernel_generations_agree_with_the_default_kernels(opts):
     """Every kernel generation still in the library is reachable through mpmae_set_option (include/mpmae_hip.h): a full bf16 step with
     the option set against the step on the default kernels - same losses (1e-2: bf16 rounding points differ between generations) and
