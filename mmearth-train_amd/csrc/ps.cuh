@@ -360,10 +360,10 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
     // pairs of PPR patches at a time.
     {
       const int nU = keep * K::NFG, nT = nU + (K::CPR ? (keep + K::PPR - 1) / K::PPR : 0);
-      auto run_items = [&](int i0, int i1, bool rem, const f32x2_t (&w)[49], const f32x2_t bias) {
+      auto run_items = [&](int i0, int i1, int istep, bool rem, const f32x2_t (&w)[49], const f32x2_t bias) {
         const int cp = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
 #pragma unroll 1
-        for (int i = i0; i < i1; i += 8) {
+        for (int i = i0; i < i1; i += istep) {
           const int kk = rem ? (i - nU) * K::PPR + lane / (K::CPR ? K::CPR : 1) : i / K::NFG;
           const bool on = kk < keep;
           const int k = on ? kk : keep - 1;
@@ -381,16 +381,27 @@ __global__ __launch_bounds__(512) void ps_fwd_kernel(const PsP a) {
           }
         }
       };
-      auto run_set = [&](int i0, int i1, bool rem) {      // (requesting the first weight set one block ahead moved its wait into pw2: no gain)
+      auto run_set = [&](int i0, int i1, int istep, bool rem) {      // (requesting the first weight set one block ahead moved its wait into pw2: no gain)
         const int cpS = rem ? K::CPF + lane % (K::CPR ? K::CPR : 1) : (wave % K::NFG) * 64 + lane;
         f32x2_t w[49];
 #pragma unroll
         for (int t = 0; t < 49; ++t) w[t] = *reinterpret_cast<const f32x2_t*>(B.dw_w + ((t % 7) * 7 + t / 7) * C + 2 * cpS);   // t = ky*7 + kx -> (kw*7 + kh)*C
-        run_items(i0, i1, rem, w, *reinterpret_cast<const f32x2_t*>(B.dw_b + 2 * cpS));
+        run_items(i0, i1, istep, rem, w, *reinterpret_cast<const f32x2_t*>(B.dw_b + 2 * cpS));
       };
-      if (wave < nU) run_set(wave, nU, false);
-      const int r0 = nU + ((wave - nU % 8) + 8) % 8;        // this wave's first remainder item (items continue round-robin behind the uniform ones)
-      if (r0 < nT) run_set(r0, nT, true);
+      if constexpr (K::NFG == 1 && K::CPR > 0) {
+        // C = 160: waves 0-5 take the uniform items, waves 6-7 the remainder items - ONE tap set (49 register pairs, a round trip behind the previous
+        // block's stores) per wave. Dealt round-robin over all 8 waves, five waves needed both sets one after the other: at 19 patches the phase was
+        // set + 2 items + set + 1 item against set + 4 items here (sub-stamps of round 6: a set 6.2 k cycles behind the store drain, an item 2.6 k);
+        // 3.296 vs 3.304 ms in the step (profiles/r06/ab_ps_dw_split.txt). Requesting the next block's set in front of this block's `out` stores
+        // (one vmcnt for loads and stores on gfx950) spilled 91 registers and lost 0.09 ms.
+        constexpr int WU = 6;
+        if (wave < WU) { if (wave < nU) run_set(wave, nU, WU, false); }
+        else if (nU + wave - WU < nT) run_set(nU + wave - WU, nT, 8 - WU, true);
+      } else {
+        if (wave < nU) run_set(wave, nU, 8, false);
+        const int r0 = nU + ((wave - nU % 8) + 8) % 8;        // this wave's first remainder item (items continue round-robin behind the uniform ones)
+        if (r0 < nT) run_set(r0, nT, 8, true);
+      }
     }
     // LayerNorm vectors and pw1's first weight slabs: requested before the barrier in front of the LayerNorm phase
     constexpr int NCH = C / 8, NI = (NCH + 15) / 16;
